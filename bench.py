@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bags/sec, forward+backward(+optimizer step) of DeformCrossTransMIL on bags of 10 000 instances x 512
+features (BASELINE.json metric), whole bags data-parallel over the GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One step = one training step of the reference's per-branch slice (train_test.py:57-85,188) on B synthetic bags
+per GPU: DeformCrossTransMIL forward (fc1 -> fusion -> LayerNorm -> 2-D deformable cross-attention with
+continuous position bias over a 100 x 100 token grid / 625 sampled keys -> pooler -> heads), cross-entropy +
+BatchLoss (gathered over ranks), backward, gradient all-reduce (RCCL), Adam step.  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "subspace-multimodal-learning_amd"
+
+F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
+CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
+ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
+
+
+def mil_args(in_dim):
+    return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim)
+
+
+def algorithmic_flop_per_bag(N, J, in_dim, C=128, H=8):
+    """Forward flops of one DeformCrossTransMIL branch (SURVEY.md 8(d) formula); fwd+bwd = 3x."""
+    inner = 64 * H
+    attn = (2 * N * (C // 8) * inner + (2 * 36 * inner * J + 2 * inner * 2 * J) + 2 * (2 * J * (C // 8) * inner)
+            + 2 * (2 * H * N * J * 64) + H * N * J * CPB_FWD_FLOP_PER_PAIR + 2 * N * inner * C)
+    return 2 * N * in_dim * C + 2 * N * 2 * C * C + attn
+
+
+def cpu_baseline(pkg, in_dim, seconds_budget=25.0):
+    """The oracle (plain PyTorch fp32 port of the reference's op sequence) timed on this box's host cores on a
+    bounded sample: one bag on the reference's own 50 x 50 grid, fwd+bwd; scaled to the N = 10 000 workload by
+    the algorithmic-flop ratio."""
+    from oracle.mil import deform_cross_trans_mil
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    S = 50
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
+    params = pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench")
+    path = pkg.synth.bag(1, S * S, in_dim, 42, "bench:cpu")
+    omic = torch.relu(pkg.synth.normal((1, 128), 42, "bench:omic"))
+
+    def step():
+        p = {k: v.clone().requires_grad_() for k, v in params.items()}
+        enc, logits, _, vg = deform_cross_trans_mil(path, omic, p, grid_hw=(S, S))
+        (torch.nn.functional.cross_entropy(logits, torch.tensor([1])) + 1e-3 * vg.pow(2).sum() + enc.sum() * 0).backward()
+
+    step()                                            # warm-up
+    t0 = time.perf_counter(); n = 0
+    while True:
+        step(); n += 1
+        if n >= 3 and (time.perf_counter() - t0) > min(seconds_budget, 10.0) or (time.perf_counter() - t0) > seconds_budget:
+            break
+    dt = (time.perf_counter() - t0) / n
+    ratio = algorithmic_flop_per_bag(10000, 625, in_dim) / algorithmic_flop_per_bag(S * S, 144, in_dim)
+    return {"value": (1.0 / dt) / ratio, "unit": "bags/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (plain PyTorch fp32) fwd+bwd of 1 bag on the reference's 50x50 grid (N=2500, J=144), "
+                      f"{n} iters, {dt:.2f} s/bag measured = {1.0 / dt:.3f} bags/s at N=2500; scaled to N=10000 by the "
+                      f"algorithmic-flop ratio {ratio:.1f}x"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bags", type=int, default=4, help="bags per GPU per step")
+    ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
+    ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    pkg = importlib.import_module(PKG)
+    Fh = pkg.functional
+    S, B, in_dim = a.grid, a.bags, a.in_dim
+    N = S * S
+    J = pkg.lib().smml_offsets_out_len(S, 6, 4) ** 2
+
+    torch.manual_seed(42)
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
+    mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
+    mil = mil.to(dev).train()
+    mil.layer3.attn2d.dropout.p = 0.0      # attention dropout is not in the HIP path yet (eval-mode semantics)
+    model = pkg.BagDataParallel(mil) if world > 1 else mil
+    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True)
+    bloss = pkg.BatchLoss(B, world)
+    # synthetic bags, resident in HBM before timing; a different bag set per rank (whole bags per rank)
+    path = pkg.synth.bag(B, N, in_dim, 42 + rank, "bench:bag").to(dev)
+    omic = torch.relu(pkg.synth.normal((B, 128), 42 + rank, "bench:omicvec")).to(dev)
+    label = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(rank)).to(dev)
+
+    def step():
+        enc, logits, _, omic_t, vgrid = model(path, omic)
+        loss = torch.nn.functional.cross_entropy(logits, label) + torch.sum(bloss(omic_t, vgrid))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    Fh.TIMER.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    Fh.TIMER.enabled = False
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    kt = Fh.TIMER.collect()
+    if rank == 0:
+        out = {
+            "metric": "bags/sec fwd+bwd, DeformCrossTransMIL N=10k x 512",
+            "value": world * B * a.steps / dt, "unit": "bags/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeformCrossTransMIL training step (fwd + bwd + Adam), bag {N} x {in_dim} fp32, "
+                                   f"token grid {S}x{S}, {J} sampled keys, path_dim 128, heads 8, CE + BatchLoss",
+                       "bags_per_gpu": B, "global_batch": B * world, "instances": N, "feature_dim": in_dim,
+                       "parallelism": f"dp{world} (whole bags per rank, RCCL gradient all-reduce)"},
+        }
+        if "cpb_bwd" in kt:
+            n, ms, pairs = kt["cpb_bwd"]
+            flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops, recompute not counted
+            ach = flop / (ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "cpb_bwd_kernel<2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": n, "avg_ms": ms, "flop_per_launch": flop}
+        if "deform_attn_fwd" in kt:
+            n, ms, pairs = kt["deform_attn_fwd"]
+            flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
+            ach = flop / (ms * 1e-3) / 1e12
+            out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
+                                   "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                                   "launches": n, "avg_ms": ms, "flop_per_launch": flop}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, in_dim)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/* smml.h - C-ABI of the MI355X (gfx950) kernels for the multimodal-MIL attention / fusion hot path.
+ *
+ * Drop-in boundary for helenypzhang/Subspace-Multimodal-Learning.  The reference has no FFI layer: the
+ * path sits behind plain PyTorch nn.Module classes.  This library is what the
+ * host-side mirror of those modules (package `subspace-multimodal-learning_amd`) binds through ctypes;
+ * each entry point names the reference op sequence (file:line) it replaces.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, token-major (channel-last), and live in HBM of ONE device;
+ *     every pointer is a raw device pointer owned by the caller (PyTorch caching allocator on the
+ *     Python side); the library never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant;
+ *   - return value 0 = ok, negative = error; the message is read with smml_last_error()
+ *     (thread-local); no exception crosses the boundary;
+ *   - "accumulated into" outputs must be zeroed (or hold a running sum) by the caller.
+ */
+#ifndef SMML_H_
+#define SMML_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* smml_last_error(void);
+int smml_abi_version(void);
+/* 0 iff `device` is a usable gfx950 device of this process */
+int smml_device_check(int device);
+/* HIP events as plain handles: time one kernel on the stream it is launched on (bench.py roofline leg) */
+void* smml_event_create(void);
+int smml_event_destroy(void* ev);
+int smml_event_record(void* ev, void* stream);
+int smml_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Strided-batched fp32 GEMM on the f32 matrix cores (exact fp32):
+ *   C[b0,b1](m,n) (+)= act(alpha * sum_k A[b0,b1](m,k) B[b0,b1](k,n) + bias) + residual
+ * A(m,k) at A + b0*sa0 + b1*sa1 + m*sam + k*sak;  B(k,n) at B + b0*sb0 + b1*sb1 + k*sbk + n*sbn;
+ * C(m,n) at C + b0*sc0 + b1*sc1 + m*ldc + n;  residual shares C's batch offsets with row stride ldr.
+ * bias_mode 0 none | 1 bias[n] | 2 bias[(m / rows_per_bias) * bias_ld + n];  act 0 none | 1 relu | 2 tanh.
+ * splitk > 1: partial products are atomically added into C (caller zeroes C; no act / residual).
+ * Replaces nn.Linear / 1x1 nn.Conv sites of the path: models/DeformCrossTransMIL.py:35-37,83,93-95,
+ * 196; models/DeformableAttention2D.py:218-221; models/DeformableAttention1D.py:150-153;
+ * models/NystromAttention.py:60-65,86,122-140 - and their backward products. */
+int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                  int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
+                  long long ldc, long long ldr, int nb0, int nb1, long long sa0, long long sa1,
+                  long long sb0, long long sb1, long long sc0, long long sc1, long long sbias0,
+                  long long sbias1, int bias_mode, int rows_per_bias, long long bias_ld, int act,
+                  int splitk, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.
+ * Replaces nn.LayerNorm at models/DeformCrossTransMIL.py:44,71,75,90,144 and mil.py:175,187. */
+int smml_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                           float* rstd, long long R, int C, float eps, void* stream);
+/* dy row for x row i is dy[(i / rows_per_dy) * C + c] * dy_scale (rows_per_dy > 1 broadcasts one
+ * gradient row over a token block, e.g. the gradient of Pooler's mean, DeformCrossTransMIL.py:193);
+ * dx is overwritten (accumulate_dx = 0) or added to; dgamma / dbeta are accumulated into. */
+int smml_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* mean,
+                           const float* rstd, float* dx, float* dgamma, float* dbeta, long long R, int C,
+                           long long rows_per_dy, float dy_scale, int accumulate_dx, void* stream);
+
+/* out[b, c] += scale * sum_r x[b, r, c] for x [nb, R, C]; out accumulated into.
+ * Pooler mean (DeformCrossTransMIL.py:193) and bias gradients. */
+int smml_colsum_f32(const float* x, float* out, int nb, long long R, int C, float scale, void* stream);
+
+/* dx = dy * (y > 0)  (ReLU of _fc1, DeformCrossTransMIL.py:83) */
+int smml_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Offset network of the deformable attention (DeformableAttention2D.py:207-213,255-266;
+ * DeformableAttention1D.py:139-146,176-183): depthwise strided conv (kernel ks, stride r,
+ * pad (ks-r)/2) -> GELU -> 1x1 (dg -> posdim) -> tanh -> * offset_scale; vgrid = meshgrid + offsets
+ * (returned to the caller's loss un-normalised); vs = 2 vgrid / max(t-1, 1) - 1.
+ *   q [B, Hh, Ww, G*dg] (1-D module: Hh = 1)   w0 [dg, 1, ks(, ks)]  b0 [dg]  w2 [posdim, dg]
+ *   vgrid [(B G), posdim, th, tw]               vs [(B G), th*tw, posdim] */
+int smml_offsets_out_len(int s, int ks, int r);
+int smml_offsets_fwd_f32(const float* q, const float* w0, const float* b0, const float* w2, float* vgrid,
+                         float* vs, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
+                         float offset_scale, void* stream);
+/* upstream gradient = dvgrid (direct, nullable) + 2/max(t-1,1) * dvs (nullable); dq is accumulated
+ * into (float atomics); dw0 / db0 / dw2 accumulated into. */
+int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const float* w2,
+                         const float* dvgrid, const float* dvs, float* dq, float* dw0, float* db0,
+                         float* dw2, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
+                         float offset_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bilinear sampling = F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) of the
+ * grouped key/value stream (DeformableAttention2D.py:268-274; DeformableAttention1D.py:36-43,185-190).
+ *   x [B, Hh, Ww, G*cg]   vs [(B G), J, posdim]   kv [B, J, G*cg]
+ * The 1-D module's degenerate sampling is posdim = 1 with the map laid out [Hh = n, Ww = 1]. */
+int smml_bilinear_sample_fwd_f32(const float* x, const float* vs, float* kv, int B, int Hh, int Ww, int G,
+                                 int cg, int J, int posdim, void* stream);
+/* dx accumulated into (float atomics); dvs accumulated into (+=). */
+int smml_bilinear_sample_bwd_f32(const float* x, const float* vs, const float* dkv, float* dx, float* dvs,
+                                 int B, int Hh, int Ww, int G, int cg, int J, int posdim, void* stream);
+/* integer path only (bit-exact contract): corner indices cx, cy [n, 4] and in-bounds masks cm [n, 4]
+ * in the order (x0,y0) (x1,y0) (x0,y1) (x1,y1) for n sample points vs [n, posdim]. */
+int smml_bilinear_corners_f32(const float* vs, int* cx, int* cy, unsigned char* cm, int n, int Hh, int Ww,
+                              int posdim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused deformable cross-attention core: softmax(scale q k^T + CPB(gq - vs)) v with the continuous
+ * position bias MLP posdim -> 32 -> 32 -> heads/groups evaluated on the matrix cores per
+ * (query, key) pair and never materialised.
+ * Replaces DeformableAttention2D.py:120-157,284-312 and DeformableAttention1D.py:60-102,205-232.
+ *   q [B, N, H*64] (unscaled)  k, v [B, J, H*64]  vs [(B G), J, posdim]  gq [N, posdim]
+ *   w1 [32, posdim] b1 [32] w2 [32, 32] b2 [32] w3 [H/G, 32] b3 [H/G]
+ *   out [B, N, H*64]  lse [B, H, N]  logits_t [B, H, J, smml_deform_attn_nst(N)] (nullable: only
+ *   needed for backward).  H/G <= 2.
+ * ev_start / ev_stop (nullable, handles of smml_event_create) are recorded on `stream` around the fused
+ * forward kernel, resp. around the position-bias backward kernel (the dominant kernel of the step). */
+int smml_deform_attn_nst(int N);
+int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* w3, const float* b3, float* out, float* lse, float* logits_t,
+                             int B, int N, int J, int H, int G, int posdim, float scale, void* ev_start,
+                             void* ev_stop, void* stream);
+size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H);
+/* dlogits_t: scratch of logits_t's size (receives d scores); dq / dk / dv / dw* / db* overwritten;
+ * dvs overwritten (zeroed inside). */
+int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* w3, const float* b3, const float* out, const float* dout,
+                             const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
+                             float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                             float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
+                             int G, int posdim, float scale, void* ev_start, void* ev_stop, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMML_H_ */

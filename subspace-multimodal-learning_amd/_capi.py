@@ -1,0 +1,91 @@
+"""ctypes binding of lib/libsmml_hip.so (C-ABI declared in include/smml.h).
+
+The product path has no CPU or eager fallback: if the library is missing, or a tensor is not a
+contiguous fp32 CUDA(HIP) tensor, the call fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsmml_hip.so")
+
+_f = C.c_void_p          # device pointers travel as void*
+_i, _ll, _fl, _sz = C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/smml.h one to one
+SIGNATURES = {
+    "smml_last_error": (C.c_char_p, []),
+    "smml_abi_version": (_i, []),
+    "smml_device_check": (_i, [_i]),
+    "smml_gemm_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _ll, _ll, _ll, _ll,
+                           _ll, _ll, _ll, _ll, _i, _i, _ll, _i, _i, _fl, _f]),
+    "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),
+    "smml_layernorm_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _ll, _i, _ll, _fl, _i, _f]),
+    "smml_colsum_f32": (_i, [_f, _f, _i, _ll, _i, _fl, _f]),
+    "smml_relu_bwd_f32": (_i, [_f, _f, _f, _ll, _f]),
+    "smml_offsets_out_len": (_i, [_i, _i, _i]),
+    "smml_offsets_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
+    "smml_offsets_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
+    "smml_bilinear_sample_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
+    "smml_bilinear_sample_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
+    "smml_bilinear_corners_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "smml_deform_attn_nst": (_i, [_i]),
+    "smml_deform_attn_fwd_f32": (_i, [_f] * 14 + [_i, _i, _i, _i, _i, _i, _fl, _f, _f, _f]),
+    "smml_deform_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smml_deform_attn_bwd_f32": (_i, [_f] * 26 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _f]),
+    "smml_event_create": (C.c_void_p, []),
+    "smml_event_destroy": (_i, [_f]),
+    "smml_event_record": (_i, [_f, _f]),
+    "smml_event_elapsed_ms": (_i, [_f, _f, C.POINTER(C.c_float)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Loads the shared library once; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU or eager fallback for this path")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().smml_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"smml call failed ({rc}){': ' + what if what else ''}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a contiguous fp32/int32/uint8 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("smml kernels need tensors resident in GPU HBM (got a CPU tensor); "
+                           "this path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("smml kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def fptr(t: Optional[torch.Tensor]):
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError(f"smml fp32 kernel got dtype {t.dtype}")
+    return ptr(t)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,742 @@
+// Fused deformable cross-attention core for gfx950 (MI355X): QK^T + continuous position bias (CPB)
+// + softmax + PV, forward and backward, exact fp32 on the f32 matrix cores.
+//
+// Replaces the op sequence of the reference at
+//   models/DeformableAttention2D.py:284-312 (sim, rel_pos_bias, softmax, attn @ v) and :120-157 (CPB)
+//   models/DeformableAttention1D.py:205-232 and :60-102
+// without ever materialising the [pairs, 32] hidden activations of the CPB MLP (2.95 GB each at
+// the reference's B = 8).
+//
+// Data layout (all fp32, token-major, HBM resident):
+//   q [B, N, H*64]   k, v [B, J, H*64]   vs [B*G, J, PD]  (normalised sample positions)
+//   gq [N, PD]       (normalised query grid)             out [B, N, H*64]   lse [B, H, N]
+//   logits_t / dlogits_t [B, H, J, NST]  (scores incl. bias, key-major so that a wave's 32 queries
+//   are contiguous; NST = N rounded up to 32)            PD = 2 (2-D module) or 1 (1-D module)
+//
+// Matrix-core mapping (v_mfma_f32_32x32x2_f32, one wave = 32 queries on the lane axis):
+//   S^T[key,query]  = K . Q^T            A = K tile from LDS,  B = Q rows held in 32 VGPRs
+//   D[out,query]    = W2 . relu(W1 p+b1) one 16-MFMA chain per (key, 32 queries); W2 lives in VGPRs,
+//                                        layer 1 is evaluated straight into the B operand
+//   O^T[d,query]   += V^T . P^T          the softmax'd accumulator registers are the B operand as they
+//                                        stand (the sum runs over the accumulator's row index)
+// The 32x32 CPB layer is 2048 of the 2240 flop per (query, key) pair, i.e. the kernel is bound by the
+// f32 MFMA rate (157.3 TFLOP/s peak): roofline "mfma".
+#include "smml_common.h"
+
+namespace {
+
+constexpr int DH = 64;       // head dim (fixed: dim_head = 64 in both reference modules)
+constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
+constexpr int QT = 32;       // queries per wave
+constexpr int WAVES = 4;     // waves per workgroup
+constexpr int KT = 32;       // keys per tile
+
+struct CpbParams {
+  const float* w1;  // [32, PD]
+  const float* b1;  // [32]
+  const float* w2;  // [32, 32]
+  const float* b2;  // [32]
+  const float* w3;  // [o, 32]
+  const float* b3;  // [o]
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
+    float* __restrict__ LSE, float* __restrict__ LT, int N, int J, int H, int G, int NST, float scale) {
+  __shared__ float Ks[DH][KT + 1];           // K tile, d-major (A operand of S^T)
+  __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
+  __shared__ float vsl[KT][2];               // sample positions of the tile's keys
+  __shared__ float biasT[WAVES][KT][QT];     // per-wave bias tile [key][query]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const int HD = H * DH;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  // Q row of this lane's query: d = 32*hf + s, pre-multiplied by the softmax scale
+  float qreg[32];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(Q + ((size_t)b * N + qi) * HD + h * DH + hf * 32);
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float4 t = qp[s4];
+      qreg[4 * s4 + 0] = t.x * scale; qreg[4 * s4 + 1] = t.y * scale;
+      qreg[4 * s4 + 2] = t.z * scale; qreg[4 * s4 + 3] = t.w * scale;
+    }
+  }
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // CPB constants in the operand layouts they are consumed in
+  float w2a[16], w1x[16], w1y[16], b1v[16], b2v[16], w3v[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int ch = 16 * hf + s;                 // layer-2 input channel of k-step s
+    w2a[s] = cp.w2[c * CH + ch];                // A[i = out = c][k = in = ch]
+    w1x[s] = cp.w1[ch * PD];
+    w1y[s] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    b1v[s] = cp.b1[ch];
+    const int oc = acc_row(s, hf);              // output channel held in accumulator register s
+    b2v[s] = cp.b2[oc];
+    w3v[s] = cp.w3[oi * CH + oc];
+  }
+  const float b3 = cp.b3[oi];
+
+  floatx16 oacc0 = {0}, oacc1 = {0};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* Kb = K + (size_t)b * J * HD + h * DH;
+  const float* Vb = V + (size_t)b * J * HD + h * DH;
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  float* LTb = LT ? LT + ((size_t)(b * H + h) * J) * NST : nullptr;
+
+  const int ntiles = (J + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT;
+    __syncthreads();
+    // cooperative tile load: 32 keys x 64 d, two float4 per thread per tensor
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (j0 + key < J) {
+        kv = *reinterpret_cast<const float4*>(Kb + (size_t)(j0 + key) * HD + d4);
+        vv = *reinterpret_cast<const float4*>(Vb + (size_t)(j0 + key) * HD + d4);
+      }
+      Ks[d4 + 0][key] = kv.x; Ks[d4 + 1][key] = kv.y; Ks[d4 + 2][key] = kv.z; Ks[d4 + 3][key] = kv.w;
+      *reinterpret_cast<float4*>(&Vs[key][d4]) = vv;
+    }
+    if (tid < KT) {
+      const int key = j0 + tid;
+      vsl[tid][0] = (key < J) ? VSb[(size_t)key * PD] : 0.f;
+      vsl[tid][1] = (PD == 2 && key < J) ? VSb[(size_t)key * PD + 1] : 0.f;
+    }
+    __syncthreads();
+
+    // S^T[key, query] = K . (scale Q)^T
+    floatx16 s = {0};
+#pragma unroll
+    for (int st = 0; st < 32; ++st) s = mfma32(Ks[32 * hf + st][c], qreg[st], s);
+
+    // continuous position bias: one MFMA chain per key
+    const int nk = min(KT, J - j0);
+    for (int jj = 0; jj < nk; ++jj) {
+      const float p0 = signed_log1p(gq0 - vsl[jj][0]);
+      const float p1 = (PD == 2) ? signed_log1p(gq1 - vsl[jj][1]) : 0.f;
+      floatx16 d = {0};
+#pragma unroll
+      for (int sp = 0; sp < 16; ++sp) {
+        float hv = fmaf(w1x[sp], p0, b1v[sp]);
+        if (PD == 2) hv = fmaf(w1y[sp], p1, hv);
+        d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
+      }
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t = fmaf(fmaxf(d[r] + b2v[r], 0.f), w3v[r], t);
+      t = xhalf_sum(t) + b3;
+      if (hf == 0) biasT[wave][jj][c] = t;
+    }
+    wave_lds_fence();
+
+    // bias add, key mask, online softmax
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hf);
+      const float sv = (key < nk) ? s[r] + biasT[wave][key][c] : -INFINITY;
+      s[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    if (LTb && qvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = acc_row(r, hf);
+        if (key < nk) LTb[(size_t)(j0 + key) * NST + q0 + c] = s[r];
+      }
+    }
+    tmax = xhalf_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc0[r] *= alpha; oacc1[r] *= alpha; }
+
+    // O^T[d, query] += V^T . P^T   (accumulator registers of P^T are the B operand as they stand)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hf);
+      oacc0 = mfma32(Vs[key][c], s[r], oacc0);
+      oacc1 = mfma32(Vs[key][32 + c], s[r], oacc1);
+    }
+    wave_lds_fence();
+  }
+
+  l_run = xhalf_sum(l_run);
+  const float inv = 1.f / l_run;
+  if (qvalid) {
+    float* op = O + ((size_t)b * N + qi) * HD + h * DH;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(op + d) = make_float4(oacc0[4 * rg] * inv, oacc0[4 * rg + 1] * inv,
+                                                       oacc0[4 * rg + 2] * inv, oacc0[4 * rg + 3] * inv);
+      *reinterpret_cast<float4*>(op + 32 + d) = make_float4(oacc1[4 * rg] * inv, oacc1[4 * rg + 1] * inv,
+                                                            oacc1[4 * rg + 2] * inv, oacc1[4 * rg + 3] * inv);
+    }
+    if (hf == 0) LSE[(size_t)(b * H + h) * N + qi] = m_run + logf(l_run);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1 (query owners): dS^T = P^T (dP^T - delta), dQ = scale * dS K
+//   reads logits_t, writes dlogits_t (same layout) and dq
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
+    const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
+    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST, float scale) {
+  __shared__ float Vt[DH][KT + 1];   // V tile d-major (A operand of dP^T = V . dO^T)
+  __shared__ float Kr[KT][DH];       // K tile key-major (A operand of dQ^T = K^T . dS^T)
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int HD = H * DH;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  float doreg[32];
+  float delta = 0.f;
+  {
+    const size_t off = ((size_t)b * N + qi) * HD + h * DH + hf * 32;
+    const float4* dp = reinterpret_cast<const float4*>(dO + off);
+    const float4* op = reinterpret_cast<const float4*>(O + off);
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float4 t = dp[s4], u = op[s4];
+      doreg[4 * s4 + 0] = t.x; doreg[4 * s4 + 1] = t.y; doreg[4 * s4 + 2] = t.z; doreg[4 * s4 + 3] = t.w;
+      delta += t.x * u.x + t.y * u.y + t.z * u.z + t.w * u.w;
+    }
+  }
+  delta = xhalf_sum(delta);
+  const float lse = LSE[(size_t)(b * H + h) * N + qi];
+
+  floatx16 dq0 = {0}, dq1 = {0};
+  const float* Kb = K + (size_t)b * J * HD + h * DH;
+  const float* Vb = V + (size_t)b * J * HD + h * DH;
+  const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
+  float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+
+  const int ntiles = (J + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT;
+    const int nk = min(KT, J - j0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (j0 + key < J) {
+        kv = *reinterpret_cast<const float4*>(Kb + (size_t)(j0 + key) * HD + d4);
+        vv = *reinterpret_cast<const float4*>(Vb + (size_t)(j0 + key) * HD + d4);
+      }
+      Vt[d4 + 0][key] = vv.x; Vt[d4 + 1][key] = vv.y; Vt[d4 + 2][key] = vv.z; Vt[d4 + 3][key] = vv.w;
+      *reinterpret_cast<float4*>(&Kr[key][d4]) = kv;
+    }
+    __syncthreads();
+
+    // dP^T[key, query] = V . dO^T
+    floatx16 dp = {0};
+#pragma unroll
+    for (int st = 0; st < 32; ++st) dp = mfma32(Vt[32 * hf + st][c], doreg[st], dp);
+
+    floatx16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hf);
+      float v = 0.f;
+      if (key < nk && qvalid) {
+        const float p = expf(LTb[(size_t)(j0 + key) * NST + q0 + c] - lse);
+        v = p * (dp[r] - delta);
+        dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
+      }
+      ds[r] = v;
+    }
+    // dQ^T[d, query] += K^T . dS^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hf);
+      dq0 = mfma32(Kr[key][c], ds[r], dq0);
+      dq1 = mfma32(Kr[key][32 + c], ds[r], dq1);
+    }
+  }
+  if (qvalid) {
+    float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(qp + d) = make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale,
+                                                       dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale);
+      *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale,
+                                                            dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2 (key owners): dV = P^T dO, dK = scale * dS^T Q ; one workgroup per 32-key tile,
+// its four waves stride over the query tiles and are summed through LDS at the end (no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
+    const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
+    const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dK,
+    float* __restrict__ dV, int N, int J, int H, int NST, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // per wave: Qs[32][64], dOs[32][64]; after the loop reused as reduce[4][2][64][33]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * KT;
+  const int HD = H * DH;
+  float* Qs = smem + wave * (2 * QT * DH);
+  float* dOs = Qs + QT * DH;
+  const int nk = min(KT, J - j0);
+  const bool kvalid = c < nk;
+  const int key = j0 + (kvalid ? c : 0);
+  const float* LTk = LT + ((size_t)(b * H + h) * J + key) * NST;
+  const float* dLTk = dLT + ((size_t)(b * H + h) * J + key) * NST;
+  const float* LSEb = LSE + (size_t)(b * H + h) * N;
+
+  floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int nqt = (N + QT - 1) / QT;
+  for (int qt = wave; qt < nqt; qt += WAVES) {
+    const int q0 = qt * QT;
+    wave_lds_fence();
+    // stage this wave's Q and dO tiles (32 rows x 256 B each)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = i * 64 + lane, row = idx >> 4, d4 = (idx & 15) * 4;
+      const int qrow = min(q0 + row, N - 1);
+      const size_t off = ((size_t)b * N + qrow) * HD + h * DH + d4;
+      *reinterpret_cast<float4*>(Qs + row * DH + d4) = *reinterpret_cast<const float4*>(Q + off);
+      *reinterpret_cast<float4*>(dOs + row * DH + d4) = *reinterpret_cast<const float4*>(dO + off);
+    }
+    wave_lds_fence();
+    // P[query, key] and dS[query, key] with the query on the accumulator-row axis
+    float p[16], ds[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int qq = q0 + 8 * rg + 4 * hf;      // 4 consecutive queries, 16-B aligned
+      const float4 lt = *reinterpret_cast<const float4*>(LTk + qq);
+      const float4 dl = *reinterpret_cast<const float4*>(dLTk + qq);
+      const float lv[4] = {lt.x, lt.y, lt.z, lt.w};
+      const float dv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = kvalid && (qq + i) < N;
+        const float lse = LSEb[min(qq + i, N - 1)];
+        p[4 * rg + i] = ok ? expf(lv[i] - lse) : 0.f;
+        ds[4 * rg + i] = ok ? dv[i] : 0.f;
+      }
+    }
+    // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, hf);
+      dv0 = mfma32(dOs[row * DH + c], p[r], dv0);
+      dv1 = mfma32(dOs[row * DH + 32 + c], p[r], dv1);
+      dk0 = mfma32(Qs[row * DH + c], ds[r], dk0);
+      dk1 = mfma32(Qs[row * DH + 32 + c], ds[r], dk1);
+    }
+  }
+  __syncthreads();
+  // cross-wave reduction: red[wave][t][d][key], t = 0 (dK) / 1 (dV), row stride 33
+  float* red = smem;
+  {
+    float* rk = red + (wave * 2 + 0) * (DH * 33);
+    float* rv = red + (wave * 2 + 1) * (DH * 33);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = acc_row(r, hf);
+      rk[d * 33 + c] = dk0[r]; rk[(32 + d) * 33 + c] = dk1[r];
+      rv[d * 33 + c] = dv0[r]; rv[(32 + d) * 33 + c] = dv1[r];
+    }
+  }
+  __syncthreads();
+  // 256 threads: thread -> (key = tid >> 3, 8 d-values); coalesced 256-B rows in HBM
+  {
+    const int kk = tid >> 3, dbase = (tid & 7) * 8;
+    if (kk < nk) {
+      float ak[8], av[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float sk = 0.f, sv = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+          sk += red[(w * 2 + 0) * (DH * 33) + (dbase + i) * 33 + kk];
+          sv += red[(w * 2 + 1) * (DH * 33) + (dbase + i) * 33 + kk];
+        }
+        ak[i] = sk * scale; av[i] = sv;
+      }
+      float* kp = dK + ((size_t)b * J + j0 + kk) * HD + h * DH + dbase;
+      float* vp = dV + ((size_t)b * J + j0 + kk) * HD + h * DH + dbase;
+      *reinterpret_cast<float4*>(kp) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+      *reinterpret_cast<float4*>(kp + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
+      *reinterpret_cast<float4*>(vp) = make_float4(av[0], av[1], av[2], av[3]);
+      *reinterpret_cast<float4*>(vp + 4) = make_float4(av[4], av[5], av[6], av[7]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of the continuous position bias: given dS^T (= d bias) recompute the MLP per
+// (key, 32 queries) chain and accumulate
+//   dW3, db3, db2, dW1, db1 : per-lane partial sums in registers (reduced once at the end)
+//   dW2 [out, in]           : matrix-core contraction over the 32 queries of a chain (dD^T via LDS)
+//   d vs [b*g, key, PD]     : LDS accumulator per workgroup, flushed with float atomics
+// Per-workgroup partials go to a slab [numWG][CPB_SLAB] that cpb_reduce_kernel sums (deterministic).
+// slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
+// ------------------------------------------------------------------------------------------------
+constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
+
+template <int PD>
+__global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
+    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
+    float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // layout: tab[64] float4 | w3 tab[32] | dvs[J*2] | per wave: dDl[32][33], pl[32][2] | red[CPB_SLAB]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  float4* tab = reinterpret_cast<float4*>(smem);            // [64] float4 constant tables
+  float* dvs = smem + 288;                                  // [J][2]
+  float* wbase = dvs + ((2 * J + 3) & ~3);
+  float* dDl = wbase + wave * (32 * 33 + 64);               // [32 out][33]
+  float* pl = dDl + 32 * 33;                                // [32 query][2]
+  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
+
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // constants: W2 in both operand layouts and w3 stay in VGPRs; the layer-1 weights (needed in the k-step
+  // layout ch = 16 hf + s and in the accumulator layout ch = acc_row(r, hf)) are broadcast-read from LDS
+  float w2a[16], w2t[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    w2a[s] = cp.w2[c * CH + 16 * hf + s];                  // W2[out = c][in = 16 hf + s]
+    const int rc = acc_row(s, hf);
+    w2t[s] = cp.w2[rc * CH + c];                           // W2^T: A[i = in = c][k = out = rc]
+  }
+  if (tid < 64) {
+    const int thf = tid >> 4, ts = tid & 15;               // thf in 0..3: 0,1 -> tabB halves; 2,3 -> tabA halves
+    const int hh = thf & 1;
+    const int ch = (thf < 2) ? (16 * hh + ts) : acc_row(ts, hh);
+    float4 t;
+    t.x = cp.w1[ch * PD];
+    t.y = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    t.z = cp.b1[ch];
+    t.w = cp.b2[ch];
+    tab[(thf * 16 + ts)] = t;
+  } else if (tid < 96) {
+    const int i = tid - 64;                                // w3 of this head's output row, accumulator layout
+    smem[256 + i] = cp.w3[oi * CH + acc_row(i & 15, i >> 4)];
+  }
+  const float4* tabB = tab + hf * 16;                      // {w1x, w1y, b1, -} of channel 16 hf + s
+  const float4* tabA = tab + 32 + hf * 16;                 // {w1x, w1y, b1, b2} of channel acc_row(r, hf)
+  const float* tab3 = smem + 256 + hf * 16;                // w3[oi][acc_row(r, hf)]
+  // lane-channel layout (channel = c) for the dW2 B operand
+  const float w1xc = cp.w1[c * PD], w1yc = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, b1c = cp.b1[c];
+
+  floatx16 e = {0};                                        // dW2[out rows][in cols]
+  float aw3[16], ab2[16], aw1x[16], aw1y[16], ab1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aw3[r] = 0.f; ab2[r] = 0.f; aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
+  float ab3 = 0.f;
+
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+  __syncthreads();
+
+  for (int j = 0; j < J; ++j) {
+    const float vx = VSb[(size_t)j * PD];
+    const float vy = (PD == 2) ? VSb[(size_t)j * PD + 1] : 0.f;
+    const float dbias = qvalid ? dLTb[(size_t)j * NST + q0 + c] : 0.f;
+    const float d0 = gq0 - vx, d1 = gq1 - vy;
+    const float p0 = signed_log1p(d0);
+    const float p1 = (PD == 2) ? signed_log1p(d1) : 0.f;
+    if (hf == 0) { pl[c * 2] = p0; pl[c * 2 + 1] = p1; }
+
+    // forward recompute: D = W2 . h1
+    floatx16 d = {0};
+#pragma unroll
+    for (int sp = 0; sp < 16; ++sp) {
+      const float4 t = tabB[sp];
+      float hv = fmaf(t.x, p0, t.z);
+      if (PD == 2) hv = fmaf(t.y, p1, hv);
+      d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
+    }
+    // layer 3 backward: dD = dbias * w3 * [h2 > 0]
+    floatx16 dd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float h2 = fmaxf(d[r] + tabA[r].w, 0.f);
+      aw3[r] = fmaf(dbias, h2, aw3[r]);
+      const float g2 = (h2 > 0.f) ? dbias * tab3[r] : 0.f;
+      ab2[r] += g2;
+      dd[r] = g2;
+      dDl[acc_row(r, hf) * 33 + c] = g2;
+    }
+    ab3 += (hf == 0) ? dbias : 0.f;
+
+    // dh1[in, query] = W2^T . dD   (sum over the accumulator-row index: registers are the B operand)
+    floatx16 dh = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh = mfma32(w2t[r], dd[r], dh);
+
+    // layer 1 backward in accumulator layout (channel = acc_row(r, hf))
+    float dp0 = 0.f, dp1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 t = tabA[r];
+      float pre = fmaf(t.x, p0, t.z);
+      if (PD == 2) pre = fmaf(t.y, p1, pre);
+      const float g1 = (pre > 0.f) ? dh[r] : 0.f;
+      ab1[r] += g1;
+      aw1x[r] = fmaf(g1, p0, aw1x[r]);
+      dp0 = fmaf(g1, t.x, dp0);
+      if (PD == 2) {
+        aw1y[r] = fmaf(g1, p1, aw1y[r]);
+        dp1 = fmaf(g1, t.y, dp1);
+      }
+    }
+    // d vs[j] = - sum_query dp / (|d| + 1)
+    {
+      float t0 = wave_sum(-dp0 / (fabsf(d0) + 1.f));
+      if (lane == 0) atomicAdd(&dvs[2 * j], t0);
+      if (PD == 2) {
+        float t1 = wave_sum(-dp1 / (fabsf(d1) + 1.f));
+        if (lane == 0) atomicAdd(&dvs[2 * j + 1], t1);
+      }
+    }
+    wave_lds_fence();
+    // dW2[out, in] += sum_query dD[out, query] h1[in, query]:
+    //   A[i = out = c][k = query = 16 hf + s] from LDS, B[k = query][j = in = c] recomputed
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int qq = 16 * hf + s;
+      float hv = fmaf(w1xc, pl[qq * 2], b1c);
+      if (PD == 2) hv = fmaf(w1yc, pl[qq * 2 + 1], hv);
+      e = mfma32(dDl[c * 33 + qq], fmaxf(hv, 0.f), e);
+    }
+    wave_lds_fence();
+  }
+
+  // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
+  __syncthreads();
+  float* red = wbase + WAVES * (32 * 33 + 64);              // [CPB_SLAB] accumulators in LDS
+  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hf);
+    atomicAdd(&red[row * CH + c], e[r]);                    // dW2[out = row][in = c]
+    // per-channel partials: sum over the 32 query lanes of this half
+    float v;
+    v = aw3[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
+    v = ab2[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + row], v);
+    v = ab1[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
+    v = aw1x[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
+    v = aw1y[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
+  }
+  {
+    float v = wave_sum(ab3);
+    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
+  }
+  __syncthreads();
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* sl = slab + (size_t)wg * CPB_SLAB;
+  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
+  // sample-position gradients: float atomics, contiguous rows
+  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
+  for (int i = tid; i < J * PD; i += 256) {
+    const int j = i / PD, comp = i - j * PD;
+    atomicAdd(&dVSb[i], dvs[2 * j + comp]);
+  }
+}
+
+// sums the per-workgroup slabs: out[k] = sum_wg slab[wg][k]; one block per 64 outputs
+__global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o, float* __restrict__ dW1,
+                                  float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                  float* __restrict__ dW3, float* __restrict__ db3, int PD, int wg_per_head,
+                                  int H, int G) {
+  // slabs are ordered (b, h, qtile); dW3/db3 belong to output row oi = h % o, the rest is shared
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
+  __shared__ float acc[4][64][2];
+  float s0 = 0.f, s1 = 0.f;     // s0: rows with oi == 0 (or shared), s1: oi == 1
+  if (k < CPB_SLAB) {
+    for (int w = part; w < nwg; w += nparts) {
+      const int hh = (w / wg_per_head) % H;
+      const int oi = hh % o;
+      const float v = slab[(size_t)w * CPB_SLAB + k];
+      if (oi == 0) s0 += v; else if (oi == 1) s1 += v;
+    }
+  }
+  acc[part][threadIdx.x & 63][0] = s0;
+  acc[part][threadIdx.x & 63][1] = s1;
+  __syncthreads();
+  if (part == 0 && k < CPB_SLAB) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int p = 0; p < nparts; ++p) { t0 += acc[p][threadIdx.x][0]; t1 += acc[p][threadIdx.x][1]; }
+    if (k < 1024) dW2[k] = t0 + t1;
+    else if (k < 1024 + 64) {
+      const int ch = (k - 1024) >> 1, comp = (k - 1024) & 1;
+      if (comp < PD) dW1[ch * PD + comp] = t0 + t1;
+    } else if (k < 1024 + 96) db1[k - 1088] = t0 + t1;
+    else if (k < 1024 + 128) db2[k - 1120] = t0 + t1;
+    else if (k < 1024 + 160) {
+      dW3[k - 1152] = t0;
+      if (o > 1) dW3[CH + k - 1152] = t1;
+    } else if (k == 1024 + 160) {
+      db3[0] = t0;
+      if (o > 1) db3[1] = t1;
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int smml_deform_attn_nst(int N) { return (N + 31) & ~31; }
+
+size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H) {
+  const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
+  return nwg * CPB_SLAB * sizeof(float);
+}
+
+static int check_common(const char* fn, int B, int N, int J, int H, int G, int posdim) {
+  SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0 && G > 0, "%s: non-positive dimension", fn);
+  SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
+  SMML_REQUIRE(H / G <= 2, "%s: at most 2 heads per offset group are supported (got %d)", fn, H / G);
+  SMML_REQUIRE(posdim == 1 || posdim == 2, "%s: posdim must be 1 or 2 (got %d)", fn, posdim);
+  SMML_REQUIRE(B <= 65535 && H <= 65535, "%s: batch/heads exceed the grid limits", fn);
+  return SMML_OK;
+}
+
+int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* w3, const float* b3, float* out, float* lse, float* logits_t,
+                             int B, int N, int J, int H, int G, int posdim, float scale, void* ev_start,
+                             void* ev_stop, void* stream) {
+  int rc = check_common("smml_deform_attn_fwd_f32", B, N, J, H, G, posdim);
+  if (rc) return rc;
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && lse,
+               "smml_deform_attn_fwd_f32: null pointer");
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B), block(256);
+  const int nst = smml_deform_attn_nst(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (posdim == 2)
+    hipLaunchKernelGGL(deform_attn_fwd_kernel<2>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       N, J, H, G, nst, scale);
+  else
+    hipLaunchKernelGGL(deform_attn_fwd_kernel<1>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       N, J, H, G, nst, scale);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK("smml_deform_attn_fwd_f32");
+  return SMML_OK;
+}
+
+int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* w3, const float* b3, const float* out, const float* dout,
+                             const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
+                             float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                             float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
+                             int G, int posdim, float scale, void* ev_start, void* ev_stop, void* stream) {
+  int rc = check_common("smml_deform_attn_bwd_f32", B, N, J, H, G, posdim);
+  if (rc) return rc;
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits_t &&
+                   dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
+               "smml_deform_attn_bwd_f32: null pointer");
+  SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, H),
+               "smml_deform_attn_bwd_f32: workspace too small (%zu < %zu)", workspace_bytes,
+               smml_deform_attn_bwd_workspace_bytes(B, N, H));
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  hipStream_t st = (hipStream_t)stream;
+  const int nst = smml_deform_attn_nst(N);
+  const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
+  dim3 block(256);
+  // pass 1: dS^T, dQ
+  hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
+                     dlogits_t, dq, N, J, H, nst, scale);
+  SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
+  // pass 2: dK, dV
+  {
+    const size_t lds = (size_t)WAVES * 2 * DH * 33 * sizeof(float);   // >= WAVES * 2 * 32 * 64
+    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3((J + KT - 1) / KT, H, B), block, lds, st, q, dout, lse,
+                       logits_t, dlogits_t, dk, dv, N, J, H, nst, scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dkv");
+  }
+  // pass 3: position-bias MLP backward
+  {
+    hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
+    if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
+    const size_t lds = ((size_t)288 + ((2 * J + 3) & ~3) + WAVES * (32 * 33 + 64) + CPB_SLAB) * sizeof(float);
+    SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
+    float* slab = (float*)workspace;
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
+    if (posdim == 2)
+      hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
+                         J, H, G, nst);
+    else
+      hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
+                         J, H, G, nst);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
+    const int nwg = qtiles * H * B;
+    hipLaunchKernelGGL(cpb_reduce_kernel, dim3((CPB_SLAB + 63) / 64), dim3(256), 0, st, slab, nwg, H / G, dw1, db1,
+                       dw2, db2, dw3, db3, posdim, qtiles, H, G);
+    SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/reduce");
+  }
+  return SMML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// Row-wise / column-wise HBM-bound pieces of the path for gfx950 (wavefront reductions, no matrix cores):
+//   LayerNorm forward / backward          (models/DeformCrossTransMIL.py:44,71,75,90,144; mil.py:175,187)
+//   column sums / means over tokens       (Pooler mean, DeformCrossTransMIL.py:193; bias gradients)
+//   ReLU backward                         (_fc1, DeformCrossTransMIL.py:83)
+// One wave per row, 16-byte accesses when the row length allows it (C % 256 == 0 uses float4 per lane,
+// otherwise scalar with a 64-lane stride); partial column sums leave a workgroup through float atomics.
+#include "smml_common.h"
+
+namespace {
+
+constexpr int MAXV = 16;   // per-lane elements: supports C <= 1024
+
+// y = (x - mean) * rstd * gamma + beta ; saves mean / rstd per row
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, long long R,
+                                                            int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* xr = x + row * C;
+  float v[MAXV];
+  float s = 0.f;
+  const int nv = (C + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      v[i] = (c < C) ? xr[c] : 0.f;
+      s += v[i];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      const float d = (c < C) ? v[i] - mu : 0.f;
+      ss += d * d;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+  float* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) {
+      const int c = lane + 64 * i;
+      if (c < C) yr[c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx (+)= rstd * (g dy - mean(g dy) - xhat * mean(g dy xhat)); dgamma += sum dy xhat; dbeta += sum dy
+// dy row for x row i is dy[(i / rows_per_dy) * C ...] * dy_scale  (rows_per_dy > 1: broadcast rows, e.g. the
+// gradient of a mean over tokens).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            long long R, int C, long long rows_per_dy, float dy_scale,
+                                                            int accumulate_dx) {
+  __shared__ float red[2][4][64 * MAXV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (C + 63) >> 6;
+  float ag[MAXV], ab[MAXV], gm[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ag[i] = 0.f; ab[i] = 0.f;
+    const int c = lane + 64 * i;
+    gm[i] = (i < nv && c < C) ? gamma[c] : 0.f;
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < R; row += (long long)gridDim.x * 4) {
+    const float* xr = x + row * C;
+    const float* dr = dy + (row / rows_per_dy) * C;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[MAXV], gd[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (i < nv) {
+        const int c = lane + 64 * i;
+        const bool ok = c < C;
+        const float d = ok ? dr[c] * dy_scale : 0.f;
+        xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
+        gd[i] = d * gm[i];
+        s1 += gd[i];
+        s2 += gd[i] * xh[i];
+        ag[i] += d * xh[i];
+        ab[i] += d;
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    float* dxr = dx + row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (i < nv) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+          const float v = rs * (gd[i] - s1 - xh[i] * s2);
+          dxr[c] = accumulate_dx ? dxr[c] + v : v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) { red[0][wave][lane + 64 * i] = ag[i]; red[1][wave][lane + 64 * i] = ab[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(&dgamma[c], g);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+// out[b, c] += scale * sum_{r in chunk} x[b, r, c]   (x [nb, R, C] contiguous; out zeroed by the caller)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long R,
+                                                     int C, float scale, int rows_per_block) {
+  __shared__ float red[256];
+  const int b = blockIdx.y;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(R, r0 + rows_per_block);
+  // thread -> (column group, row lane): C <= 256 columns handled per pass
+  for (int cb = 0; cb < C; cb += 256) {
+    const int ncol = min(256, C - cb);
+    // rows interleaved over 256 / ncol_pow2 row lanes
+    int cp = 1;
+    while (cp < ncol) cp <<= 1;
+    const int rl = 256 / cp;
+    const int col = threadIdx.x % cp, rlane = threadIdx.x / cp;
+    float s = 0.f;
+    if (col < ncol && rlane < rl) {
+      const float* xb = x + ((long long)b * R) * C + cb + col;
+      for (long long r = r0 + rlane; r < r1; r += rl) s += xb[r * C];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cp && threadIdx.x < ncol) {
+      float t = 0.f;
+      for (int k = 0; k < rl; ++k) t += red[k * cp + threadIdx.x];
+      atomicAdd(&out[(long long)b * C + cb + threadIdx.x], t * scale);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 d = *reinterpret_cast<const float4*>(dy + i), v = *reinterpret_cast<const float4*>(y + i);
+    *reinterpret_cast<float4*>(dx + i) =
+        make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+  } else {
+    for (long long k = i; k < n; ++k) dx[k] = y[k] > 0.f ? dy[k] : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int smml_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                           long long R, int C, float eps, void* stream) {
+  SMML_REQUIRE(x && gamma && beta && y && mean && rstd, "smml_layernorm_fwd_f32: null pointer");
+  SMML_REQUIRE(R > 0 && C > 0 && C <= 64 * MAXV, "smml_layernorm_fwd_f32: need 0 < C <= %d (got %d)", 64 * MAXV, C);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, y, mean, rstd, R, C, eps);
+  SMML_LAUNCH_CHECK("smml_layernorm_fwd_f32");
+  return SMML_OK;
+}
+
+// dgamma / dbeta are accumulated into (callers zero them once; the shared LayerNorm of the two streams adds twice)
+int smml_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, float* dgamma, float* dbeta, long long R, int C, long long rows_per_dy,
+                           float dy_scale, int accumulate_dx, void* stream) {
+  SMML_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta, "smml_layernorm_bwd_f32: null pointer");
+  SMML_REQUIRE(R > 0 && C > 0 && C <= 64 * MAXV, "smml_layernorm_bwd_f32: need 0 < C <= %d (got %d)", 64 * MAXV, C);
+  SMML_REQUIRE(rows_per_dy >= 1, "smml_layernorm_bwd_f32: rows_per_dy must be >= 1");
+  const long long nblk = (R + 3) / 4;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)(nblk < 1024 ? nblk : 1024)), dim3(256), 0, (hipStream_t)stream,
+                     x, dy, gamma, mean, rstd, dx, dgamma, dbeta, R, C, rows_per_dy, dy_scale, accumulate_dx);
+  SMML_LAUNCH_CHECK("smml_layernorm_bwd_f32");
+  return SMML_OK;
+}
+
+// out [nb, C] must be zeroed by the caller; out[b, c] += scale * sum_r x[b, r, c]
+int smml_colsum_f32(const float* x, float* out, int nb, long long R, int C, float scale, void* stream) {
+  SMML_REQUIRE(x && out && nb > 0 && R > 0 && C > 0, "smml_colsum_f32: bad argument");
+  SMML_REQUIRE(nb <= 65535, "smml_colsum_f32: too many batches");
+  int rows_per_block = 256;
+  long long nblk = (R + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, R, C,
+                     scale, rows_per_block);
+  SMML_LAUNCH_CHECK("smml_colsum_f32");
+  return SMML_OK;
+}
+
+int smml_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, void* stream) {
+  SMML_REQUIRE(dy && y && dx && n > 0, "smml_relu_bwd_f32: bad argument");
+  const long long nthr = (n + 3) / 4;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+  SMML_LAUNCH_CHECK("smml_relu_bwd_f32");
+  return SMML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's deformable cross-attention modules on the HIP kernels.
+
+Same constructor keywords / defaults, forward signatures, tensor layouts and parameter names
+(= checkpoint format) as
+  models/DeformableAttention2D.py:161-325  DeformCrossAttention2D (+ CPB :120-157, Scale :110-116)
+  models/DeformableAttention1D.py:106-240  DeformCrossAttention1D (+ CPB :60-102)
+so `state_dict`s are interchangeable.  The nn.Conv / nn.Linear sub-modules only hold the parameters
+(identical default initialisation); the arithmetic runs in the kernels behind `functional`.
+
+Additive knob (reference default kept): `grid_hw` - the reference hard-wires a 50 x 50 token grid
+(DeformableAttention2D.py:239-240,318); here the grid defaults to the square root of the token count.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import functional as Fh
+
+
+def _default(v, d):
+    return d if v is None else v
+
+
+class Scale(nn.Module):
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class CPB(nn.Module):
+    """Parameter holder of the continuous position bias MLP (in -> dim -> dim -> heads // offset_groups)."""
+
+    def __init__(self, dim, *, heads, offset_groups, depth, in_dim=2, log_distance=True):
+        super().__init__()
+        self.heads, self.offset_groups, self.log_distance = heads, offset_groups, log_distance
+        self.mlp = nn.ModuleList([nn.Sequential(nn.Linear(in_dim, dim), nn.ReLU())])
+        for _ in range(depth - 1):
+            self.mlp.append(nn.Sequential(nn.Linear(dim, dim), nn.ReLU()))
+        self.mlp.append(nn.Linear(dim, heads // offset_groups))
+        if depth != 2 or dim != 32:
+            raise NotImplementedError("the position-bias kernels are built for depth 2 and width 32 (dim = 128)")
+
+    def tensors(self):
+        m = self.mlp
+        return (m[0][0].weight, m[0][0].bias, m[1][0].weight, m[1][0].bias, m[2].weight, m[2].bias)
+
+
+def _grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
+    """Normalised query grid [N, 2] = (x, y) per token, restating create_grid_like + normalize_grid(dim=0)
+    (DeformableAttention2D.py:88-108,296-297): x is divided by (rows - 1), y by (cols - 1)."""
+    qx = 2.0 * torch.arange(Ww, dtype=torch.float32, device=device) / max(Hh - 1, 1) - 1.0
+    qy = 2.0 * torch.arange(Hh, dtype=torch.float32, device=device) / max(Ww - 1, 1) - 1.0
+    return torch.stack((qx.view(1, Ww).expand(Hh, Ww), qy.view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(Hh * Ww, 2).contiguous()
+
+
+class DeformCrossAttention2D(nn.Module):
+    def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=4,
+                 offset_groups=8, offset_kernel_size=6, group_queries=True, group_key_values=True,
+                 grid_hw: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        offset_scale = _default(offset_scale, downsample_factor)
+        assert offset_kernel_size >= downsample_factor, \
+            'offset kernel size must be greater than or equal to the downsample factor'
+        assert (offset_kernel_size - downsample_factor) % 2 == 0
+        offset_groups = _default(offset_groups, heads)
+        assert heads % offset_groups == 0
+        inner_dim = dim_head * heads
+        self.scale = dim_head ** -0.5
+        self.heads, self.offset_groups = heads, offset_groups
+        self.dim, self.dim_head = dim, dim_head
+        offset_dims = inner_dim // offset_groups
+        self.downsample_factor = downsample_factor
+        self.offset_kernel_size, self.offset_scale = offset_kernel_size, float(offset_scale)
+        self.group_queries, self.group_key_values = group_queries, group_key_values
+        self.grid_hw = grid_hw
+        self.to_offsets = nn.Sequential(
+            nn.Conv2d(offset_dims, offset_dims, offset_kernel_size, groups=offset_dims, stride=downsample_factor,
+                      padding=(offset_kernel_size - downsample_factor) // 2),
+            nn.GELU(),
+            nn.Conv2d(offset_dims, 2, 1, bias=False),
+            nn.Tanh(),
+            Scale(offset_scale))
+        self.rel_pos_bias = CPB(dim // 4, offset_groups=offset_groups, heads=heads, depth=2)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Conv2d(dim, inner_dim, 1, groups=offset_groups if group_queries else 1, bias=False)
+        self.to_k = nn.Conv2d(dim, inner_dim, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_v = nn.Conv2d(dim, inner_dim, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_out = nn.Conv2d(inner_dim, dim, 1)
+
+    def _grid(self, n: int) -> Tuple[int, int]:
+        if self.grid_hw is not None:
+            return self.grid_hw
+        s = int(round(math.sqrt(n)))
+        if s * s != n:
+            raise ValueError(f"token count {n} is not a square; pass grid_hw=(rows, cols)")
+        return s, s
+
+    def forward_tokens(self, x1t, x2t, return_vgrid=False, residual=None):
+        """Token-major entry: x1t (queries) / x2t (keys, values) [B, N, C] -> [B, N, C] (+ residual)."""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("attention dropout is not implemented in the HIP path yet; call .eval() "
+                                      "or construct with dropout=0")
+        B, N, C = x1t.shape
+        Hh, Ww = self._grid(N)
+        G, H = self.offset_groups, self.heads
+        q = Fh.grouped_pointwise(x1t, self.to_q.weight, G if self.group_queries else 1)            # [B, N, inner]
+        vgrid, vs = Fh.offsets(q.view(B, Hh, Ww, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
+                               self.to_offsets[2].weight.reshape(2, -1), groups=G, ks=self.offset_kernel_size,
+                               r=self.downsample_factor, posdim=2, offset_scale=self.offset_scale)
+        kv = Fh.bilinear_sample(x2t.reshape(B, Hh, Ww, C), vs, groups=G, posdim=2)                  # [B, J, C]
+        gk = G if self.group_key_values else 1
+        k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
+        v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
+        gq = _grid_queries_2d(Hh, Ww, x1t.device)
+        o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale)
+        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
+        return (out, vgrid) if return_vgrid else out
+
+    def forward(self, x1, x2, return_vgrid=False):
+        """x1, x2 [B, C, N] channels-first as in the reference -> [B, C, N] (and vgrid [(B g), 2, th, tw])."""
+        r = self.forward_tokens(x1.transpose(1, 2), x2.transpose(1, 2), return_vgrid)
+        if return_vgrid:
+            return r[0].transpose(1, 2), r[1]
+        return r.transpose(1, 2)
+
+
+class DeformCrossAttention1D(nn.Module):
+    def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None,
+                 offset_groups=4, offset_kernel_size=6, cpb_log_distance=True, group_queries=False,
+                 group_key_values=False):
+        super().__init__()
+        offset_scale = _default(offset_scale, downsample_factor)
+        assert offset_kernel_size >= downsample_factor, \
+            'offset kernel size must be greater than or equal to the downsample factor'
+        assert (offset_kernel_size - downsample_factor) % 2 == 0
+        offset_groups = _default(offset_groups, heads)
+        assert heads % offset_groups == 0
+        if not cpb_log_distance:
+            raise NotImplementedError("the HIP position-bias kernels implement the log-distance form only")
+        inner_dim = dim_head * heads
+        self.scale = dim_head ** -0.5
+        self.heads, self.offset_groups = heads, offset_groups
+        self.dim, self.dim_head = dim, dim_head
+        offset_dims = inner_dim // offset_groups
+        self.downsample_factor = downsample_factor
+        self.offset_kernel_size, self.offset_scale = offset_kernel_size, float(offset_scale)
+        self.group_queries, self.group_key_values = group_queries, group_key_values
+        self.to_offsets = nn.Sequential(
+            nn.Conv1d(offset_dims, offset_dims, offset_kernel_size, groups=offset_dims, stride=downsample_factor,
+                      padding=(offset_kernel_size - downsample_factor) // 2),
+            nn.GELU(),
+            nn.Conv1d(offset_dims, 1, 1, bias=False),
+            nn.Identity(),          # placeholder for the reference's Rearrange('b 1 n -> b n') (no parameters)
+            nn.Tanh(),
+            Scale(offset_scale))
+        self.rel_pos_bias = CPB(dim // 4, offset_groups=offset_groups, heads=heads, depth=2, in_dim=1,
+                                log_distance=cpb_log_distance)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Conv1d(dim, inner_dim, 1, groups=offset_groups if group_queries else 1, bias=False)
+        self.to_k = nn.Conv1d(dim, inner_dim, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_v = nn.Conv1d(dim, inner_dim, 1, groups=offset_groups if group_key_values else 1, bias=False)
+        self.to_out = nn.Conv1d(inner_dim, dim, 1)
+
+    def forward_tokens(self, x1t, x2t, return_vgrid=False, residual=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("attention dropout is not implemented in the HIP path yet; call .eval() "
+                                      "or construct with dropout=0")
+        B, n, C = x1t.shape
+        G, H = self.offset_groups, self.heads
+        q = Fh.grouped_pointwise(x1t, self.to_q.weight, G if self.group_queries else 1)
+        vgrid, vs = Fh.offsets(q.view(B, 1, n, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
+                               self.to_offsets[2].weight.reshape(1, -1), groups=G, ks=self.offset_kernel_size,
+                               r=self.downsample_factor, posdim=1, offset_scale=self.offset_scale)
+        # bug-compatible degenerate sampling (DeformableAttention1D.py:36-43): map laid out [H = n, W = 1]
+        kv = Fh.bilinear_sample(x2t.reshape(B, n, 1, C), vs, groups=G, posdim=1)
+        gk = G if self.group_key_values else 1
+        k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
+        v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
+        seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
+        o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
+                                scale=self.scale)
+        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
+        return (out, vgrid) if return_vgrid else out
+
+    def forward(self, x1, x2, return_vgrid=False):
+        r = self.forward_tokens(x1.transpose(1, 2), x2.transpose(1, 2), return_vgrid)
+        if return_vgrid:
+            return r[0].transpose(1, 2), r[1]
+        return r.transpose(1, 2)

@@ -1,0 +1,452 @@
+"""Autograd bindings of the HIP kernels (C-ABI in include/smml.h, loaded by _capi.py).
+
+Each op is a torch.autograd.Function whose forward and backward launch hand-written gfx950 kernels on
+the current HIP stream; PyTorch only provides device memory, the stream and the autograd graph.  All
+tensors are fp32 and token-major (channel-last).  There is no CPU / eager fallback."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _capi as capi
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+class KernelTimer:
+    """Optional HIP-event timing of the two dominant kernels (fused attention forward, position-bias
+    backward) on the stream they are launched on; used by bench.py's roofline leg.  Off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pairs = {"deform_attn_fwd": [], "cpb_bwd": []}
+        self.work = {"deform_attn_fwd": [], "cpb_bwd": []}     # (query, key) pairs per launch
+
+    def events(self, name, pairs_count):
+        if not self.enabled:
+            return None, None
+        L = capi.lib()
+        a, b = L.smml_event_create(), L.smml_event_create()
+        self.pairs[name].append((a, b))
+        self.work[name].append(pairs_count)
+        return a, b
+
+    def collect(self):
+        """-> {name: (launches, mean ms, mean pairs per launch)}; destroys the events."""
+        import ctypes
+        L = capi.lib()
+        out = {}
+        for name, evs in self.pairs.items():
+            tot = 0.0
+            for a, b in evs:
+                ms = ctypes.c_float(0)
+                capi.check(L.smml_event_elapsed_ms(a, b, ctypes.byref(ms)), "event_elapsed")
+                tot += ms.value
+                L.smml_event_destroy(a); L.smml_event_destroy(b)
+            if evs:
+                out[name] = (len(evs), tot / len(evs), sum(self.work[name]) / len(evs))
+            self.pairs[name] = []
+            self.work[name] = []
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _gemm(A, B, C, *, M, N, K, sam, sak, sbk, sbn, ldc, bias=None, bias_mode=0, rows_per_bias=1, bias_ld=0,
+          residual=None, ldr=0, act=ACT_NONE, splitk=1, alpha=1.0, nb0=1, nb1=1, sa0=0, sa1=0, sb0=0, sb1=0,
+          sc0=0, sc1=0, sbias0=0, sbias1=0):
+    capi.check(capi.lib().smml_gemm_f32(
+        capi.fptr(A), capi.fptr(B), capi.fptr(C), capi.fptr(bias), capi.fptr(residual), M, N, K,
+        sam, sak, sbk, sbn, ldc, ldr, nb0, nb1, sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1,
+        bias_mode, rows_per_bias, bias_ld, act, splitk, float(alpha), capi.stream()), "gemm")
+
+
+def _splitk_for(out_rows: int, out_cols: int, k: int, batches: int = 1) -> int:
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 63) // 64) * batches
+    want = max(1, 1024 // max(tiles, 1))
+    return int(max(1, min(want, (k + 511) // 512, 65535 // max(batches, 1))))
+
+
+def colsum(x2d_or_3d: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """x [nb, R, C] -> [nb, C] column sums * scale."""
+    x = x2d_or_3d
+    nb, R, Cc = x.shape
+    out = torch.zeros(nb, Cc, device=x.device, dtype=torch.float32)
+    capi.check(capi.lib().smml_colsum_f32(capi.fptr(x), capi.fptr(out), nb, R, Cc, float(scale), capi.stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# y = act(x W^T + bias) [+ residual]; bias is [N] or one row per block of `rows_per_bias` rows
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, rows_per_bias, residual):
+        x = _c(x); weight = _c(weight)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = weight.shape[0]
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        bias_mode = 0
+        if bias is not None:
+            bias = _c(bias)
+            bias_mode = 2 if bias.dim() == 2 else 1
+        res = _c(residual) if residual is not None else None
+        _gemm(x, weight, y, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, bias=bias, bias_mode=bias_mode,
+              rows_per_bias=rows_per_bias, bias_ld=N, residual=res, ldr=N, act=act)
+        ctx.act, ctx.rows_per_bias, ctx.bias_mode = act, rows_per_bias, bias_mode
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _c(dy)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = weight.shape[0]
+        dres = dy if ctx.has_res else None
+        if ctx.act == ACT_RELU:
+            dpre = torch.empty_like(dy)
+            capi.check(capi.lib().smml_relu_bwd_f32(capi.fptr(dy), capi.fptr(y), capi.fptr(dpre), dy.numel(),
+                                                    capi.stream()), "relu_bwd")
+        elif ctx.act == ACT_TANH:
+            dpre = dy * (1.0 - y * y)          # only ever [B, C]-sized (Pooler)
+        else:
+            dpre = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm(dpre, weight, dx, M=M, N=K, K=N, sam=N, sak=1, sbk=K, sbn=1, ldc=K)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight)
+            _gemm(dpre, x, dw, M=N, N=K, K=M, sam=1, sak=N, sbk=K, sbn=1, ldc=K, splitk=_splitk_for(N, K, M))
+        if ctx.bias_mode and ctx.needs_input_grad[2]:
+            if ctx.bias_mode == 1:
+                db = colsum(dpre.reshape(1, M, N))[0]
+            else:
+                db = colsum(dpre.reshape(M // ctx.rows_per_bias, ctx.rows_per_bias, N))
+        return dx, dw, db, None, None, dres
+
+
+def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, residual=None):
+    return _Linear.apply(x, weight, bias, act, rows_per_bias, residual)
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped 1x1 convolution on token-major data: x [B, n, Cin], w [Cout, Cin / groups] -> [B, n, Cout]
+# ------------------------------------------------------------------------------------------------
+class _GroupedPointwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, groups):
+        x = _c(x)
+        w = _c(weight).reshape(weight.shape[0], -1)
+        Cin, Cout = x.shape[-1], w.shape[0]
+        cin_g, cout_g = Cin // groups, Cout // groups
+        assert w.shape[1] == cin_g, "weight does not match the group structure"
+        M = x.numel() // Cin
+        y = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
+        _gemm(x, w, y, M=M, N=cout_g, K=cin_g, sam=Cin, sak=1, sbk=1, sbn=cin_g, ldc=Cout, nb1=groups,
+              sa1=cin_g, sb1=cout_g * cin_g, sc1=cout_g)
+        ctx.groups = groups
+        ctx.wshape = weight.shape
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        G = ctx.groups
+        Cin, Cout = x.shape[-1], w.shape[0]
+        cin_g, cout_g = Cin // G, Cout // G
+        M = x.numel() // Cin
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm(dy, w, dx, M=M, N=cin_g, K=cout_g, sam=Cout, sak=1, sbk=cin_g, sbn=1, ldc=Cin, nb1=G,
+                  sa1=cout_g, sb1=cout_g * cin_g, sc1=cin_g)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            _gemm(dy, x, dw, M=cout_g, N=cin_g, K=M, sam=1, sak=Cout, sbk=Cin, sbn=1, ldc=cin_g, nb1=G,
+                  sa1=cout_g, sb1=cin_g, sc1=cout_g * cin_g, splitk=_splitk_for(cout_g, cin_g, M, G))
+            dw = dw.reshape(ctx.wshape)
+        return dx, dw, None
+
+
+def grouped_pointwise(x, weight, groups: int = 1):
+    return _GroupedPointwise.apply(x, weight, groups)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (optionally followed by the mean over tokens, Pooler's first step)
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, token_mean):
+        x = _c(x); gamma = _c(gamma); beta = _c(beta)
+        Cc = x.shape[-1]
+        R = x.numel() // Cc
+        y = torch.empty_like(x)
+        mean = torch.empty(R, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(R, device=x.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_layernorm_fwd_f32(capi.fptr(x), capi.fptr(gamma), capi.fptr(beta), capi.fptr(y),
+                                                     capi.fptr(mean), capi.fptr(rstd), R, Cc, float(eps),
+                                                     capi.stream()), "layernorm_fwd")
+        ctx.token_mean = token_mean
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        if token_mean:
+            assert x.dim() == 3
+            return colsum(y, 1.0 / x.shape[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        Cc = x.shape[-1]
+        R = x.numel() // Cc
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        rows_per_dy, scale = (x.shape[1], 1.0 / x.shape[1]) if ctx.token_mean else (1, 1.0)
+        capi.check(capi.lib().smml_layernorm_bwd_f32(capi.fptr(x), capi.fptr(dy), capi.fptr(gamma), capi.fptr(mean),
+                                                     capi.fptr(rstd), capi.fptr(dx), capi.fptr(dg), capi.fptr(db), R, Cc,
+                                                     rows_per_dy, float(scale), 0, capi.stream()), "layernorm_bwd")
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps, False)
+
+
+def layer_norm_token_mean(x, gamma, beta, eps: float = 1e-5):
+    """mean over tokens of LayerNorm(x): x [B, n, C] -> [B, C]."""
+    return _LayerNorm.apply(x, gamma, beta, eps, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# offset network: q [B, Hh, Ww, G*dg] -> vgrid [(B G), posdim, th, tw] (or [(B G), t]), vs [(B G), J, posdim]
+# ------------------------------------------------------------------------------------------------
+class _Offsets(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, w0, b0, w2, groups, ks, r, posdim, offset_scale):
+        q = _c(q); w0c = _c(w0); b0c = _c(b0); w2c = _c(w2)
+        B, Hh, Ww, inner = q.shape
+        dg = inner // groups
+        L = capi.lib()
+        tw = L.smml_offsets_out_len(Ww, ks, r)
+        th = L.smml_offsets_out_len(Hh, ks, r) if posdim == 2 else 1
+        if th <= 0 or tw <= 0:
+            raise RuntimeError("token grid too small for the offset convolution")
+        J = th * tw
+        vgrid = torch.empty((B * groups, 2, th, tw) if posdim == 2 else (B * groups, tw), device=q.device,
+                            dtype=torch.float32)
+        vs = torch.empty(B * groups, J, posdim, device=q.device, dtype=torch.float32)
+        capi.check(L.smml_offsets_fwd_f32(capi.fptr(q), capi.fptr(w0c), capi.fptr(b0c), capi.fptr(w2c),
+                                          capi.fptr(vgrid), capi.fptr(vs), B, Hh, Ww, groups, dg, ks, r, posdim,
+                                          float(offset_scale), capi.stream()), "offsets_fwd")
+        ctx.cfg = (groups, ks, r, posdim, float(offset_scale))
+        ctx.save_for_backward(q, w0c, b0c, w2c)
+        return vgrid, vs
+
+    @staticmethod
+    def backward(ctx, dvgrid, dvs):
+        q, w0, b0, w2 = ctx.saved_tensors
+        groups, ks, r, posdim, offset_scale = ctx.cfg
+        B, Hh, Ww, inner = q.shape
+        dg = inner // groups
+        dq = torch.zeros_like(q)
+        dw0, db0, dw2 = torch.zeros_like(w0), torch.zeros_like(b0), torch.zeros_like(w2)
+        dvgrid = _c(dvgrid) if dvgrid is not None else None
+        dvs = _c(dvs) if dvs is not None else None
+        capi.check(capi.lib().smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
+                                                   capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
+                                                   capi.fptr(db0), capi.fptr(dw2), B, Hh, Ww, groups, dg, ks, r, posdim,
+                                                   offset_scale, capi.stream()), "offsets_bwd")
+        return dq, dw0, db0, dw2, None, None, None, None, None
+
+
+def offsets(q, w0, b0, w2, *, groups, ks, r, posdim, offset_scale):
+    return _Offsets.apply(q, w0, b0, w2, groups, ks, r, posdim, offset_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# bilinear sampling: x [B, Hh, Ww, C], vs [(B G), J, posdim] -> kv [B, J, C]
+# ------------------------------------------------------------------------------------------------
+class _Sample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, vs, groups, posdim):
+        x = _c(x); vs = _c(vs)
+        B, Hh, Ww, Cc = x.shape
+        J = vs.shape[1]
+        kv = torch.empty(B, J, Cc, device=x.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_bilinear_sample_fwd_f32(capi.fptr(x), capi.fptr(vs), capi.fptr(kv), B, Hh, Ww, groups,
+                                                           Cc // groups, J, posdim, capi.stream()), "sample_fwd")
+        ctx.cfg = (groups, posdim)
+        ctx.save_for_backward(x, vs)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        x, vs = ctx.saved_tensors
+        groups, posdim = ctx.cfg
+        B, Hh, Ww, Cc = x.shape
+        J = vs.shape[1]
+        dx = torch.zeros_like(x)
+        dvs = torch.zeros_like(vs)
+        capi.check(capi.lib().smml_bilinear_sample_bwd_f32(capi.fptr(x), capi.fptr(vs), capi.fptr(_c(dkv)), capi.fptr(dx),
+                                                           capi.fptr(dvs), B, Hh, Ww, groups, Cc // groups, J, posdim,
+                                                           capi.stream()), "sample_bwd")
+        return dx, dvs, None, None
+
+
+def bilinear_sample(x, vs, *, groups, posdim):
+    return _Sample.apply(x, vs, groups, posdim)
+
+
+def bilinear_corners(vs, Hh: int, Ww: int, posdim: int):
+    """Integer path of the sampler for vs [n, posdim]: (cx [n,4] int32, cy [n,4] int32, mask [n,4] uint8)."""
+    vs = _c(vs).reshape(-1, posdim)
+    n = vs.shape[0]
+    cx = torch.empty(n, 4, device=vs.device, dtype=torch.int32)
+    cy = torch.empty(n, 4, device=vs.device, dtype=torch.int32)
+    cm = torch.empty(n, 4, device=vs.device, dtype=torch.uint8)
+    capi.check(capi.lib().smml_bilinear_corners_f32(capi.fptr(vs), capi.ptr(cx), capi.ptr(cy), capi.ptr(cm), n, Hh, Ww,
+                                                    posdim, capi.stream()), "corners")
+    return cx, cy, cm
+
+
+# ------------------------------------------------------------------------------------------------
+# fused attention core with continuous position bias
+# ------------------------------------------------------------------------------------------------
+class _DeformAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale):
+        q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
+        w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
+        B, N, HD = q.shape
+        J = k.shape[1]
+        posdim = vs.shape[-1]
+        if HD != heads * 64:
+            raise RuntimeError("the attention kernels are built for dim_head = 64")
+        if tuple(w2.shape) != (32, 32):
+            raise RuntimeError("the position-bias kernels are built for a hidden width of 32 (dim = 128)")
+        L = capi.lib()
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
+        need_grad = any(ctx.needs_input_grad)
+        logits = None
+        if need_grad:
+            logits = torch.empty(B, heads, J, L.smml_deform_attn_nst(N), device=q.device, dtype=torch.float32)
+        capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                              capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                              capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), B, N, J,
+                                              heads, groups, posdim, float(scale),
+                                              *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
+                   "deform_attn_fwd")
+        ctx.cfg = (heads, groups, float(scale))
+        ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits = ctx.saved_tensors
+        heads, groups, scale = ctx.cfg
+        B, N, _ = q.shape
+        J = k.shape[1]
+        posdim = vs.shape[-1]
+        L = capi.lib()
+        dout = _c(dout)
+        dlogits = torch.empty_like(logits)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dvs = torch.empty_like(vs)
+        dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
+        wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, heads)
+        ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
+        capi.check(L.smml_deform_attn_bwd_f32(
+            capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
+            capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
+            capi.fptr(logits), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+            capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
+            capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, *TIMER.events("cpb_bwd", B * heads * N * J),
+            capi.stream()), "deform_attn_bwd")
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None
+
+
+def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float):
+    """softmax(scale q k^T + CPB(gq - vs)) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P]."""
+    return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# token mean / token tile / Gram matrices (Pooler, omic tiling, BatchLoss)
+# ------------------------------------------------------------------------------------------------
+class _TokenMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.n = x.shape[1]
+        return colsum(x, 1.0 / x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy / ctx.n).unsqueeze(1).expand(-1, ctx.n, -1).contiguous()
+
+
+def token_mean(x):
+    """x [B, n, C] -> mean over tokens [B, C]."""
+    return _TokenMean.apply(x)
+
+
+class _TileTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, n):
+        return v.unsqueeze(1).repeat(1, n, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return colsum(_c(dy)), None
+
+
+def tile_tokens(v, n: int):
+    """v [B, C] -> [B, n, C] (values of v.unsqueeze(1).repeat(1, n, 1)); backward is a column sum."""
+    return _TileTokens.apply(v, n)
+
+
+class _Gram(torch.autograd.Function):
+    """x [nb, R, K] -> x x^T [nb, R, R]: skinny, HBM-bound (K up to N*C = 1.28 M): split-K over the long axis."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        nb, R, K = x.shape
+        g = torch.zeros(nb, R, R, device=x.device, dtype=torch.float32)
+        splitk = int(max(1, min((K + 2047) // 2048, 65535 // nb)))
+        _gemm(x, x, g, M=R, N=R, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=R, nb0=nb, sa0=R * K, sb0=R * K, sc0=R * R,
+              splitk=splitk)
+        ctx.save_for_backward(x)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (x,) = ctx.saved_tensors
+        nb, R, K = x.shape
+        s = _c(dg + dg.transpose(1, 2))
+        dx = torch.empty_like(x)
+        _gemm(s, x, dx, M=R, N=K, K=R, sam=R, sak=1, sbk=K, sbn=1, ldc=K, nb0=nb, sa0=R * R, sb0=R * K, sc0=R * K)
+        return dx
+
+
+def gram(x):
+    return _Gram.apply(x)

@@ -1,0 +1,74 @@
+"""Host-side mirror of the reference's batch-similarity / orthogonality losses and its gather layer.
+
+  BatchLoss      utils/loss.py:7-40        same ctor (batch_size, world_size) and forward(omic, vgrid)
+  GatherLayer    utils/gather.py:5-20      all_gather with the reference's backward (own-rank slice)
+  OrthogonalLoss models/cmta_utils.py:1212-1228
+
+The long contraction (Gram matrix of the [N_b, N*C] tiled omic matrix, K = 320 000 ... 1 280 000) runs
+through the split-K matrix-core kernel; everything after it is [N_b, N_b]-sized."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import functional as Fh
+
+
+class GatherLayer(torch.autograd.Function):
+    """Gather tensors from all ranks (RCCL all_gather over xGMI on GPU tensors, gloo on CPU tensors);
+    backward returns this rank's slice of the incoming gradients, as utils/gather.py:16-20 does
+    (every rank computes the same full loss and the data-parallel wrapper averages the parameter grads)."""
+
+    @staticmethod
+    def forward(ctx, input):
+        world = dist.get_world_size()
+        out = torch.empty((world,) + tuple(input.shape), dtype=input.dtype, device=input.device)
+        dist.all_gather_into_tensor(out, input.contiguous()) if input.is_cuda else \
+            dist.all_gather(list(out.unbind(0)), input.contiguous())
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return grads[dist.get_rank()].contiguous()
+
+
+def _row_normalised_gram(x3: torch.Tensor) -> torch.Tensor:
+    g = Fh.gram(x3)                                        # [nb, R, R] on the matrix cores
+    return g / g.norm(dim=2, keepdim=True)
+
+
+class BatchLoss(nn.Module):
+    def __init__(self, batch_size, world_size):
+        super().__init__()
+        self.batch_size = batch_size
+        self.world_size = world_size
+
+    def forward(self, omic, vgrid):
+        N = self.batch_size * self.world_size
+        if self.world_size > 1:
+            omic = torch.cat(GatherLayer.apply(omic), dim=0)
+            vgrid = torch.cat(GatherLayer.apply(vgrid), dim=0)
+        omic = omic.reshape(1, N, -1)
+        vgrid = vgrid.reshape(8, N, -1)                    # reinterprets the (b g)-major buffer, utils/loss.py:23
+        similarity = _row_normalised_gram(omic)[0]
+        mean_vgrid_sim = _row_normalised_gram(vgrid).mean(dim=0)
+        return (similarity - mean_vgrid_sim) ** 2 / N
+
+
+class OrthogonalLoss(nn.Module):
+    def __init__(self, gamma=0.5):
+        super().__init__()
+        self.gamma = gamma
+
+    @staticmethod
+    def _abs_cos(a, b, eps: float = 1e-8):
+        # F.cosine_similarity(dim=1): x.y / (max(|x|, eps) * max(|y|, eps)) on [B, d] rows
+        num = (a * b).sum(dim=1)
+        return (num / (a.norm(dim=1).clamp_min(eps) * b.norm(dim=1).clamp_min(eps))).abs()
+
+    def forward(self, P, P_hat, G, G_hat):
+        c = self._abs_cos
+        pos_pairs = (1 - c(P.detach(), P_hat)) + (1 - c(G.detach(), G_hat))
+        neg_pairs = c(P, G) + c(P.detach(), G_hat) + c(G.detach(), P_hat)
+        return pos_pairs + self.gamma * neg_pairs

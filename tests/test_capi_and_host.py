@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library loads and exports every symbol include/smml.h declares (no compute calls),
+the ctypes table mirrors the header, and the host-side mirror keeps the reference's interface."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import smml
+from test_oracle_golden import pathomic_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "smml.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(smml_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    assert os.path.exists(smml.LIB_PATH), "build the library first (__graft_entry__.build())"
+    handle = ctypes.CDLL(smml.LIB_PATH)
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/smml.h but not exported"
+    assert sorted(smml.SIGNATURES) == syms, "ctypes table and header disagree"
+    assert smml.lib().smml_abi_version() == 1
+
+
+def test_argument_counts_match_header():
+    txt = open(os.path.join(ROOT, "include", "smml.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for name, (_, args) in smml.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", txt, flags=re.S)
+        assert m, name
+        body = m.group(1).strip()
+        n = 0 if body in ("", "void") else body.count(",") + 1
+        assert n == len(args), f"{name}: header has {n} parameters, ctypes table {len(args)}"
+
+
+def test_error_channel_without_gpu():
+    L = smml.lib()
+    rc = L.smml_gemm_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1,
+                         0, 0, 1, 1.0, None)
+    assert rc < 0 and b"null" in L.smml_last_error()
+    assert L.smml_offsets_out_len(50, 6, 4) == 12 and L.smml_offsets_out_len(100, 6, 4) == 25
+    assert L.smml_offsets_out_len(2501, 6, 4) == 625 and L.smml_deform_attn_nst(2500) == 2528
+
+
+def test_reference_interface_is_kept():
+    """Constructor keywords / defaults and forward signatures of SURVEY.md section 8a/8b."""
+    sig = inspect.signature(smml.DeformCrossAttention2D.__init__).parameters
+    for k, d in dict(dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=4, offset_groups=8,
+                     offset_kernel_size=6, group_queries=True, group_key_values=True).items():
+        assert sig[k].default == d and sig[k].kind == inspect.Parameter.KEYWORD_ONLY
+    sig = inspect.signature(smml.DeformCrossAttention1D.__init__).parameters
+    for k, d in dict(dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None, offset_groups=4,
+                     offset_kernel_size=6, cpb_log_distance=True, group_queries=False, group_key_values=False).items():
+        assert sig[k].default == d
+    assert list(inspect.signature(smml.DeformCrossAttention2D.forward).parameters)[1:] == ["x1", "x2", "return_vgrid"]
+    assert list(inspect.signature(smml.DeformCrossTransMIL.forward).parameters)[1:] == ["path", "omic"]
+    assert list(inspect.signature(smml.BatchLoss.__init__).parameters)[1:] == ["batch_size", "world_size"]
+    m2 = smml.DeformCrossAttention2D(dim=128)
+    shapes = {k: tuple(v.shape) for k, v in m2.state_dict().items()}
+    assert shapes["to_offsets.0.weight"] == (64, 1, 6, 6) and shapes["to_offsets.2.weight"] == (2, 64, 1, 1)
+    assert shapes["rel_pos_bias.mlp.0.0.weight"] == (32, 2) and shapes["rel_pos_bias.mlp.2.weight"] == (1, 32)
+    assert shapes["to_q.weight"] == (512, 16, 1, 1) and shapes["to_out.weight"] == (128, 512, 1, 1)
+    m1 = smml.DeformCrossAttention1D(dim=128, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    shapes = {k: tuple(v.shape) for k, v in m1.state_dict().items()}
+    assert shapes["to_offsets.0.weight"] == (128, 1, 6) and shapes["to_offsets.2.weight"] == (1, 128, 1)
+    assert shapes["rel_pos_bias.mlp.2.weight"] == (2, 32) and shapes["to_q.weight"] == (512, 128, 1)
+    net = smml.DeformPathomicNet(pathomic_args())
+    assert sum(p.numel() for p in net.parameters()) == 1161288           # SURVEY.md C2 [probe]
+    assert sum(p.numel() for p in net.pathomic_net_tumor.parameters()) == 556679
+
+
+def test_product_path_has_no_cpu_fallback():
+    mod = smml.DeformCrossAttention2D(dim=128).eval()
+    with pytest.raises(RuntimeError, match="GPU|HBM|CPU"):
+        mod(torch.randn(1, 128, 144), torch.randn(1, 128, 144))
+    with pytest.raises(NotImplementedError):
+        smml.DeformPathomicNet(pathomic_args(fusion_type="pofusion"))

@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the whole-bag data-parallel step (gradient averaging that completes inside
+backward(), grad-less parameters, the gather layer of BatchLoss).  The collectives are device agnostic; on
+the GPU box the same code runs over RCCL / xGMI."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from helpers import smml
+from oracle.losses import batch_loss
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(6, 5)
+        self.unused = nn.Linear(3, 3)          # never receives a gradient (as attn1d.* with attn_dim = 2)
+        self.b = nn.Linear(5, 2)
+        self.shared = nn.LayerNorm(5)          # used twice per step (as layer3.norm)
+
+    def forward(self, x):
+        return self.b(self.shared(torch.tanh(self.shared(self.a(x)))))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = _Toy()
+    if rank == 1:                              # desynchronise on purpose: the wrapper must broadcast rank 0's weights
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    dp = smml.BagDataParallel(net, bucket_bytes=64)
+    xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+    out = {}
+    for step in range(2):                      # twice: bucket state must re-arm
+        net.zero_grad(set_to_none=True)
+        dp(xs[rank]).pow(2).sum().backward()
+        # gradients are final as soon as backward() returns (train_test.py:158 reads .grad right away)
+        out[f"ga{step}"] = net.a.weight.grad.clone()
+    out["unused_none"] = net.unused.weight.grad is None
+    # single-process reference: mean over ranks of the per-rank gradients with rank 0's weights
+    ref = _Toy()
+    g = []
+    for r in range(world):
+        ref.zero_grad()
+        ref(xs[r]).pow(2).sum().backward()
+        g.append(ref.a.weight.grad.clone())
+    out["ref"] = sum(g) / world
+    out["has_module"] = dp.module is net
+
+    # BatchLoss across ranks: gather layer forward / backward
+    B = 2
+    omic = torch.randn(B, 5, 4, generator=torch.Generator().manual_seed(20 + rank)).requires_grad_()
+    vgrid = torch.randn(B * 8, 2, 2, 2, generator=torch.Generator().manual_seed(30 + rank)).requires_grad_()
+    o_all = torch.cat(smml.GatherLayer.apply(omic), dim=0)
+    v_all = torch.cat(smml.GatherLayer.apply(vgrid), dim=0)
+    loss = batch_loss(o_all, v_all, B * world).sum()
+    loss.backward()
+    out["bl"] = loss.detach()
+    out["domic"] = omic.grad.clone()
+    # reference: full tensors on one process
+    os_ = [torch.randn(B, 5, 4, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+    vs_ = [torch.randn(B * 8, 2, 2, 2, generator=torch.Generator().manual_seed(30 + r)) for r in range(world)]
+    of = torch.cat(os_, 0).requires_grad_(); vf = torch.cat(vs_, 0).requires_grad_()
+    lref = batch_loss(of, vf, B * world).sum(); lref.backward()
+    out["bl_ref"] = lref.detach()
+    out["domic_ref"] = of.grad[rank * B:(rank + 1) * B].clone()
+    q.put((rank, {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()}))   # by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    res = {r: {k: (torch.from_numpy(v) if hasattr(v, 'dtype') else v) for k, v in o.items()} for r, o in res.items()}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = res[r]
+        assert o["has_module"] and o["unused_none"]
+        for step in range(2):
+            assert torch.allclose(o[f"ga{step}"], o["ref"], rtol=1e-5, atol=1e-6), f"rank {r} step {step}"
+        assert torch.allclose(o["bl"], o["bl_ref"], rtol=1e-5)
+        assert torch.allclose(o["domic"], o["domic_ref"], rtol=1e-5, atol=1e-7)
+    assert torch.equal(res[0]["ga0"], res[1]["ga0"])

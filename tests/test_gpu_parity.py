@@ -1,0 +1,261 @@
+"""GPU (MI355X) parity: the HIP kernels, called through the C-ABI, against the CPU oracle on identical
+seeded inputs, and against the golden vectors generated from the reference.
+
+Tolerances (north_star): fp32 within 1e-4 relative (to the tensor's scale); integer sampling path bit-exact.
+Parameter gradients that are sums over 1e7+ pairs with cancellation get 1e-3 (see test_oracle_golden)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, params_for, rel_err, smml, synth
+from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
+from oracle.losses import batch_loss
+from oracle.mil import deform_cross_trans_mil, deform_pathomic_net
+from test_oracle_golden import ZERO_GRADS, pathomic_args
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+TOL = 1e-4
+
+
+def _load(mod, params, dev):
+    mod.load_state_dict(params)
+    return mod.to(dev).eval()
+
+
+def _assert_close(name, got, ref, tol=TOL):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
+
+
+def _compare_param_grads(mod, pref, tol, skip=ZERO_GRADS):
+    for k, p in mod.named_parameters():
+        if k.endswith(skip):
+            continue
+        if pref[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, f"missing grad for {k}"
+        _assert_close("d" + k, p.grad, pref[k].grad, tol)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_gemm_layouts_and_epilogues(cuda):
+    """A = I check with asymmetric B plus random NN / NT / TN products, batches, bias, relu, residual, split-K."""
+    torch.manual_seed(0)
+    M, N, K = 200, 77, 45
+    A = torch.randn(M, K); Bm = torch.randn(K, N); bias = torch.randn(N); res = torch.randn(M, N)
+    Ad, Bd = A.to(cuda), Bm.to(cuda)
+    C = torch.empty(M, N, device=cuda)
+    Fh._gemm(Ad, Bd, C, M=M, N=N, K=K, sam=K, sak=1, sbk=N, sbn=1, ldc=N)
+    _assert_close("NN", C, A @ Bm, 1e-5)
+    eye = torch.eye(64, device=cuda); asym = torch.arange(64 * 64, device=cuda, dtype=torch.float32).reshape(64, 64)
+    C2 = torch.empty(64, 64, device=cuda)
+    Fh._gemm(eye, asym, C2, M=64, N=64, K=64, sam=64, sak=1, sbk=64, sbn=1, ldc=64)
+    assert torch.equal(C2, asym)
+    # NT with bias + relu + residual
+    W = torch.randn(N, K)
+    Fh._gemm(Ad, W.to(cuda), C, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, bias=bias.to(cuda), bias_mode=1,
+             residual=res.to(cuda), ldr=N, act=1)
+    _assert_close("NT+bias+relu+res", C, torch.relu(A @ W.t() + bias) + res, 1e-5)
+    # TN split-K (weight-gradient shape)
+    R = 5000
+    X = torch.randn(R, 40); dY = torch.randn(R, 24)
+    dW = torch.zeros(24, 40, device=cuda)
+    Fh._gemm(dY.to(cuda), X.to(cuda), dW, M=24, N=40, K=R, sam=1, sak=24, sbk=40, sbn=1, ldc=40, splitk=7)
+    _assert_close("TN splitk", dW, dY.t() @ X, 1e-5)
+    # batched (two batch dims) with per-row-block bias
+    a = torch.randn(2, 3, 50, 20); b = torch.randn(2, 3, 20, 30); rb = torch.randn(2, 3, 5, 30)
+    c = torch.empty(2, 3, 50, 30, device=cuda)
+    Fh._gemm(a.to(cuda), b.to(cuda), c, M=50, N=30, K=20, sam=20, sak=1, sbk=30, sbn=1, ldc=30, nb0=2, nb1=3,
+             sa0=3000, sa1=1000, sb0=1800, sb1=600, sc0=4500, sc1=1500, bias=rb.to(cuda), bias_mode=2, rows_per_bias=10,
+             bias_ld=30, sbias0=450, sbias1=150)
+    _assert_close("batched", c, a @ b + rb.repeat_interleave(10, dim=2), 1e-5)
+
+
+def test_linear_layernorm_autograd(cuda):
+    torch.manual_seed(1)
+    x = torch.randn(3, 70, 96); w = torch.randn(50, 96) / 10; b = torch.randn(50); g = torch.randn(50); be = torch.randn(50)
+    wy = torch.randn(3, 50)
+    def run(dev, lin, ln_mean):
+        xs, ws, bs, gs, bes = (t.clone().to(dev).requires_grad_() for t in (x, w, b, g, be))
+        y = lin(xs, ws, bs)
+        z = ln_mean(y, gs, bes)
+        (z * wy.to(dev)).sum().backward()
+        return [z, xs.grad, ws.grad, bs.grad, gs.grad, bes.grad]
+    ref = run("cpu", lambda a, ww, bb: torch.relu(a @ ww.t() + bb),
+              lambda y, gg, bb: torch.nn.functional.layer_norm(y, (50,), gg, bb).mean(dim=1))
+    got = run(cuda, lambda a, ww, bb: Fh.linear(a, ww, bb, act=Fh.ACT_RELU), Fh.layer_norm_token_mean)
+    for n, a, r in zip(("z", "dx", "dw", "db", "dgamma", "dbeta"), got, ref):
+        _assert_close(n, a, r, 2e-5)
+
+
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 12, 12), (1, 20, 20), (2, 14, 23), (1, 38, 38)])
+def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
+    """Small grids incl. non-square, N not a multiple of 128, J not a multiple of 32 (ragged tiles)."""
+    C, N = 128, Hh * Ww
+    tag = f"d2d:{B}:{Hh}:{Ww}"
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww))
+    params = params_for(mod, 7, tag)
+    mod = _load(mod, params, cuda)
+    x1 = synth.normal((B, C, N), 7, tag + ":x1"); x2 = synth.normal((B, C, N), 7, tag + ":x2")
+    w_out = synth.normal((B, C, N), 7, tag + ":wo")
+    # oracle
+    pref = {k: v.clone().requires_grad_() for k, v in params.items()}
+    a, b = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+    o_ref, vg_ref, aux = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), return_aux=True)
+    w_vg = synth.normal(tuple(vg_ref.shape), 7, tag + ":wvg")
+    ((o_ref * w_out).sum() + (vg_ref * w_vg).sum()).backward()
+    # HIP
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    o, vg = mod(ad, bd, return_vgrid=True)
+    ((o * w_out.to(cuda)).sum() + (vg * w_vg.to(cuda)).sum()).backward()
+    _assert_close("out", o, o_ref); _assert_close("vgrid", vg, vg_ref)
+    _assert_close("dx1", ad.grad, a.grad); _assert_close("dx2", bd.grad, b.grad)
+    _compare_param_grads(mod, pref, 2e-4)
+    # integer path: corners of the kernel's own sample positions, bit-exact against the oracle's formula
+    th, tw = vg.shape[-2:]
+    vgc = vg.detach().cpu()
+    vsx = (2.0 * vgc[:, 0] / max(th - 1, 1) - 1.0).reshape(B * 8, -1)
+    vsy = (2.0 * vgc[:, 1] / max(tw - 1, 1) - 1.0).reshape(B * 8, -1)
+    _, _, corners = sample_positions(vsx, vsy, Ww, Hh)
+    vs_dev = torch.stack((vsx, vsy), dim=-1).to(cuda)
+    cx, cy, cm = Fh.bilinear_corners(vs_dev, Hh, Ww, 2)
+    assert torch.equal(cx.cpu().long(), torch.stack([c[0] for c in corners], -1).reshape(-1, 4))
+    assert torch.equal(cy.cpu().long(), torch.stack([c[1] for c in corners], -1).reshape(-1, 4))
+    assert torch.equal(cm.cpu().bool(), torch.stack([c[3] for c in corners], -1).reshape(-1, 4))
+
+
+def test_deform2d_golden_reference_grid(cuda):
+    """N = 2500 (50 x 50), dim 128: against outputs of the reference itself."""
+    g = Golden("deform2d_ref50")
+    B, C, N = 2, 128, 2500
+    mod = smml.DeformCrossAttention2D(dim=C, dim_head=64, heads=8, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                      offset_groups=8, offset_kernel_size=6)
+    mod = _load(mod, params_for(mod, 42, "deform2d"), cuda)
+    x1 = synth.normal((B, C, N), 42, "deform2d:x1").to(cuda).requires_grad_()
+    x2 = synth.normal((B, C, N), 42, "deform2d:x2").to(cuda).requires_grad_()
+    w_out = synth.normal((B, C, N), 42, "deform2d:wout").to(cuda)
+    w_vg = synth.normal((B * 8, 2, 12, 12), 42, "deform2d:wvg").to(cuda)
+    out, vgrid = mod(x1, x2, return_vgrid=True)
+    loss = (out * w_out).sum() + (vgrid * w_vg).sum()
+    loss.backward()
+    g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    for k, p in mod.named_parameters():
+        if not k.endswith(ZERO_GRADS):
+            g.check("grad:" + k, p.grad, rtol=2e-4, what="d" + k)
+    # integer path on the REFERENCE's vgrid: bit-exact corners / masks
+    vgf = torch.from_numpy(g.array("vgrid_full"))
+    vs = (2.0 * vgf / 11.0 - 1.0)
+    vs_dev = torch.stack((vs[:, 0].reshape(16, 144), vs[:, 1].reshape(16, 144)), dim=-1).to(cuda)
+    cx, cy, cm = Fh.bilinear_corners(vs_dev, 50, 50, 2)
+    assert np.array_equal(cx.cpu().numpy().reshape(16, 144, 4), g.array("corner_x"))
+    assert np.array_equal(cy.cpu().numpy().reshape(16, 144, 4), g.array("corner_y"))
+    assert np.array_equal(cm.cpu().numpy().astype(bool).reshape(16, 144, 4), g.array("corner_mask"))
+
+
+@pytest.mark.parametrize("tag,B,n", [("deform1d_n37", 2, 37), ("deform1d_n40", 2, 40), ("deform1d_n2501", 1, 2501)])
+def test_deform1d_golden(cuda, tag, B, n):
+    g = Golden(tag)
+    C = 128
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    mod = _load(mod, params_for(mod, 42, tag), cuda)
+    x1 = synth.normal((B, C, n), 42, tag + ":x1").to(cuda).requires_grad_()
+    x2 = synth.normal((B, C, n), 42, tag + ":x2").to(cuda).requires_grad_()
+    w_out = synth.normal((B, C, n), 42, tag + ":wout").to(cuda)
+    out, vgrid = mod(x1, x2, return_vgrid=True)
+    w_vg = synth.normal(tuple(vgrid.shape), 42, tag + ":wvg").to(cuda)
+    ((out * w_out).sum() + (vgrid * w_vg).sum()).backward()
+    g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+    for k, p in mod.named_parameters():
+        if not k.endswith(ZERO_GRADS):
+            g.check("grad:" + k, p.grad, rtol=2e-4, what="d" + k)
+
+
+def test_batch_loss_vs_oracle(cuda):
+    B = 4
+    g = Golden("batchloss_b4")
+    omic = synth.normal((B, 50, 16), 42, "bl:omic").to(cuda).requires_grad_()
+    vgrid = synth.normal((B * 8, 2, 3, 3), 42, "bl:vgrid").to(cuda).requires_grad_()
+    out = smml.BatchLoss(B, 1)(omic, vgrid)
+    out.sum().backward()
+    g.check("out", out); g.check("domic", omic.grad); g.check("dvgrid", vgrid.grad)
+    # long contraction (K = N*C as in the model) against the oracle
+    o2 = synth.normal((8, 3000, 128), 1, "bl2:omic"); v2 = synth.normal((64, 2, 12, 12), 1, "bl2:vg")
+    ref = batch_loss(o2, v2, 8)
+    got = smml.BatchLoss(8, 1)(o2.to(cuda), v2.to(cuda))
+    _assert_close("batchloss long-K", got, ref)
+
+
+def test_full_model_golden_reference_grid(cuda):
+    """DeformPathomicNet (two DeformCrossTransMIL branches) + BatchLoss + CE at N = 2500 against the reference."""
+    g = Golden("pathomic_ref50")
+    net = smml.DeformPathomicNet(pathomic_args())
+    net = _load(net, params_for(net, 42, "pathomic"), cuda)
+    B = 2
+    x_path = synth.bag(B, 2500, 1024, 42, "pathomic:bag").to(cuda)
+    x_t = synth.normal((B, 59), 42, "pathomic:tumor").to(cuda)
+    x_i = synth.normal((B, 361), 42, "pathomic:immune").to(cuda)
+    feats, vt, vi, lg, _, _, _ = net(x_path=x_path, x_omic=None, x_omic_tumor=x_t, x_omic_immune=x_i)
+    bl = smml.BatchLoss(B, 1)
+    l_t, l_i = bl(lg[3], lg[4]), bl(lg[5], lg[6])
+    label = torch.tensor([1, 3], device=cuda)
+    loss = torch.nn.functional.cross_entropy(lg[2], label) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
+    loss.backward()
+    g.check("features", feats); g.check("vec_t", vt); g.check("vec_i", vi); g.check("haz", lg[2])
+    g.check("haz_t", lg[0]); g.check("haz_i", lg[1])
+    g.check("vgrid_t", lg[4]); g.check("vgrid_i", lg[6]); g.check("batchloss_t", l_t); g.check("batchloss_i", l_i)
+    g.check("omic_t_row0", lg[3][:, 0])
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
+    assert with_grad == {k[5:] for k in g.keys("grad:")}, "set of parameters receiving a gradient differs"
+    for k, p in net.named_parameters():
+        if p.grad is not None and not k.endswith(ZERO_GRADS):
+            g.check("grad:" + k, p.grad, rtol=1e-3, what="d" + k)
+
+
+def test_mil_branch_larger_grid_vs_oracle(cuda):
+    """One DeformCrossTransMIL branch on a 64 x 64 grid with 512-wide bag features (BASELINE config 3 shape)."""
+    args = pathomic_args(input_path_dim=512, return_vgrid=True)
+    mil = smml.DeformCrossTransMIL(args)
+    params = params_for(mil, 3, "mil64")
+    mil = _load(mil, params, cuda)
+    B, S = 1, 64
+    path = synth.bag(B, S * S, 512, 3, "mil64:bag"); omic = torch.relu(synth.normal((B, 128), 3, "mil64:omic"))
+    pref = {k: v.clone().requires_grad_() for k, v in params.items()}
+    enc_r, log_r, _, vg_r = deform_cross_trans_mil(path, omic, pref, grid_hw=(S, S))
+    (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
+    enc, logits, _, omic_t, vg = mil(path.to(cuda), omic.to(cuda))
+    (enc.sum() + (logits * logits).sum() + vg.pow(2).sum() * 1e-3).backward()
+    _assert_close("encoded", enc, enc_r); _assert_close("logits", logits, log_r); _assert_close("vgrid", vg, vg_r)
+    assert omic_t.shape == (B, S * S, 128) and torch.equal(omic_t[0, 17].cpu(), omic[0])
+    _compare_param_grads(mil, pref, 1e-3, skip=ZERO_GRADS + ("cls_token",))
+
+
+def test_size_independent_properties_full_size(cuda):
+    """N = 10 000 (100 x 100 grid, 625 keys): properties that need no oracle run -
+    (1) attention rows are convex combinations: with v = 1 the core returns exactly-normalised ones;
+    (2) the core is linear in v; (3) permuting bags permutes outputs (whole-bag independence)."""
+    torch.manual_seed(0)
+    B, N, J, H = 2, 10000, 625, 8
+    q = torch.randn(B, N, 512, device=cuda) * 0.3; k = torch.randn(B, J, 512, device=cuda) * 0.3
+    v = torch.randn(B, J, 512, device=cuda); vs = torch.rand(B * 8, J, 2, device=cuda) * 2 - 1
+    mod = smml.DeformCrossAttention2D(dim=128).to(cuda)
+    cp = [t.detach() for t in mod.rel_pos_bias.tensors()]
+    gq = smml.deform_attention._grid_queries_2d(100, 100, cuda)
+    f = lambda vv, qq=q, kk=k, ss=vs: Fh.deform_attention(qq, kk, vv, ss, gq, *cp, heads=H, groups=8, scale=0.125)
+    ones = f(torch.ones_like(v))
+    assert float((ones - 1).abs().max()) < 1e-5
+    o1, o2 = f(v), f(2 * v + 1)
+    assert float((o2 - (2 * o1 + 1)).abs().max()) < 1e-4
+    perm = torch.tensor([1, 0], device=cuda)
+    vs_p = vs.reshape(B, 8, J, 2)[perm].reshape(B * 8, J, 2)
+    o_p = Fh.deform_attention(q[perm], k[perm], v[perm], vs_p, gq, *cp, heads=H, groups=8, scale=0.125)
+    assert torch.equal(o_p, o1[perm])
+
+
+def test_fails_loudly_on_cpu_tensors(cuda):
+    mod = smml.DeformCrossAttention2D(dim=128).eval()
+    with pytest.raises(RuntimeError):
+        mod(torch.randn(1, 128, 144), torch.randn(1, 128, 144))

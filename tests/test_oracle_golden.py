@@ -1,0 +1,172 @@
+"""CPU: pins the oracle (oracle/*.py) against the golden vectors generated from the reference
+(tests/golden/make_golden.py).  Tolerance: 1e-4 relative to each tensor's scale (north_star); the oracle
+actually agrees to ~2e-6."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, params_for, smml, synth
+from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
+from oracle.losses import batch_loss, orthogonal_loss
+from oracle.mil import deform_pathomic_net
+from oracle.nystrom import nystrom_attention, pinv_newton_schulz, ppeg, trans_layer
+
+ZERO_GRADS = ("rel_pos_bias.mlp.2.bias",)   # softmax is shift invariant: this gradient is exactly 0 (noise only)
+
+
+def _req(params):
+    return {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in params.items()}
+
+
+def _check_grads(g, params, prefix="grad:", rtol=1e-4):
+    for key in g.keys(prefix):
+        name = key[len(prefix):]
+        if name.endswith(ZERO_GRADS):
+            continue
+        assert params[name].grad is not None, name
+        g.check(key, params[name].grad, rtol=rtol, what="d" + name)
+
+
+def test_deform2d_reference_grid():
+    g = Golden("deform2d_ref50")
+    B, C, N = 2, 128, 2500
+    mod = smml.DeformCrossAttention2D(dim=C, dim_head=64, heads=8, dropout=0.1, downsample_factor=4, offset_scale=4,
+                                      offset_groups=8, offset_kernel_size=6)
+    p = _req(params_for(mod, 42, "deform2d"))
+    x1 = synth.normal((B, C, N), 42, "deform2d:x1").requires_grad_()
+    x2 = synth.normal((B, C, N), 42, "deform2d:x2").requires_grad_()
+    w_out = synth.normal((B, C, N), 42, "deform2d:wout")
+    w_vg = synth.normal((B * 8, 2, 12, 12), 42, "deform2d:wvg")
+    out, vgrid, aux = deform_cross_attention_2d(x1, x2, p, grid_hw=(50, 50), return_aux=True)
+    loss = (out * w_out).sum() + (vgrid * w_vg).sum()
+    loss.backward()
+    g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    _check_grads(g, p)
+    # integer path: corners / masks computed from the REFERENCE's vgrid must match bit for bit
+    vg = torch.from_numpy(g.array("vgrid_full"))
+    vs = 2.0 * vg / 11.0 - 1.0
+    _, _, corners = sample_positions(vs[:, 0].reshape(16, 144), vs[:, 1].reshape(16, 144), 50, 50)
+    assert np.array_equal(torch.stack([c[0] for c in corners], -1).numpy().astype(np.int32), g.array("corner_x"))
+    assert np.array_equal(torch.stack([c[1] for c in corners], -1).numpy().astype(np.int32), g.array("corner_y"))
+    assert np.array_equal(torch.stack([c[3] for c in corners], -1).numpy(), g.array("corner_mask"))
+
+
+@pytest.mark.parametrize("tag,B,n", [("deform1d_n37", 2, 37), ("deform1d_n40", 2, 40), ("deform1d_n2501", 1, 2501)])
+def test_deform1d(tag, B, n):
+    g = Golden(tag)
+    C = 128
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    p = _req(params_for(mod, 42, tag))
+    x1 = synth.normal((B, C, n), 42, tag + ":x1").requires_grad_()
+    x2 = synth.normal((B, C, n), 42, tag + ":x2").requires_grad_()
+    w_out = synth.normal((B, C, n), 42, tag + ":wout")
+    out, vgrid = deform_cross_attention_1d(x1, x2, p, offset_scale=2.0)
+    w_vg = synth.normal(tuple(vgrid.shape), 42, tag + ":wvg")
+    ((out * w_out).sum() + (vgrid * w_vg).sum()).backward()
+    g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+    _check_grads(g, p)
+
+
+class _NysShapes(torch.nn.Module):
+    def __init__(self, dim, dh, heads=8, k=33):
+        super().__init__()
+        inner = dh * heads
+        self.to_qkv = torch.nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = torch.nn.Sequential(torch.nn.Linear(inner, dim), torch.nn.Dropout(0.))
+        self.res_conv = torch.nn.Conv2d(heads, heads, (k, 1), padding=(k // 2, 0), groups=heads, bias=False)
+
+
+@pytest.mark.parametrize("tag,B,n,dim,dh,m", [("nystrom_n37_m16", 2, 37, 64, 8, 16), ("nystrom_n64_m16", 2, 64, 64, 8, 16),
+                                               ("nystrom_n257_m256", 1, 257, 512, 64, 256)])
+def test_nystrom(tag, B, n, dim, dh, m):
+    g = Golden(tag)
+    p = _req(params_for(_NysShapes(dim, dh), 42, tag))
+    x = synth.normal((B, n, dim), 42, tag + ":x").requires_grad_()
+    w_out = synth.normal((B, n, dim), 42, tag + ":wout")
+    out = nystrom_attention(x, p, heads=8, dim_head=dh, num_landmarks=m)
+    (out * w_out).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    _check_grads(g, p)
+
+
+def test_pinv_and_translayer_and_ppeg():
+    a2 = torch.softmax(synth.normal((2, 3, 16, 16), 42, "pinv:x"), dim=-1)
+    Golden("pinv_m16").check("z", pinv_newton_schulz(a2, 6))
+
+    class TL(torch.nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.norm = torch.nn.LayerNorm(dim)
+            self.attn = _NysShapes(dim, dim // 8)
+    dim = 64
+    g = Golden("translayer_d64")
+    p = _req(params_for(TL(dim), 42, "translayer"))
+    x = synth.normal((2, 37, dim), 42, "translayer:x").requires_grad_()
+    w = synth.normal((2, 37, dim), 42, "translayer:w")
+    out = trans_layer(x, p, dim=dim)
+    (out * w).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    _check_grads(g, p)
+
+    class PP(torch.nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.proj = torch.nn.Conv2d(dim, dim, 7, 1, 3, groups=dim)
+            self.proj1 = torch.nn.Conv2d(dim, dim, 5, 1, 2, groups=dim)
+            self.proj2 = torch.nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+    Golden("ppeg_d64").check("out", ppeg(x.detach(), 6, 6, params_for(PP(dim), 42, "ppeg")))
+
+
+def test_losses():
+    B = 4
+    g = Golden("batchloss_b4")
+    omic = synth.normal((B, 50, 16), 42, "bl:omic").requires_grad_()
+    vgrid = synth.normal((B * 8, 2, 3, 3), 42, "bl:vgrid").requires_grad_()
+    out = batch_loss(omic, vgrid, B)
+    out.sum().backward()
+    g.check("out", out); g.check("domic", omic.grad); g.check("dvgrid", vgrid.grad)
+    g = Golden("orthloss_b4")
+    P, Ph, G, Gh = (synth.normal((B, 256), 42, "ol:" + t).requires_grad_() for t in "abcd")
+    ol = orthogonal_loss(P, Ph, G, Gh)
+    ol.sum().backward()
+    g.check("out", ol); g.check("dP", P.grad); g.check("dPh", Ph.grad); g.check("dG", G.grad); g.check("dGh", Gh.grad)
+
+
+def pathomic_args(**over):
+    a = argparse.Namespace(
+        mode="deformpathomic", act_type="Sigmoid", init_type="max", init_gain=0.02, fusion_type="concat",
+        skip=0, use_bilinear=1, input_size_omic=431, input_size_omic_tumor=59, input_size_omic_immune=361,
+        input_path_dim=1024, path_gate=1, omic_gate=1, path_dim=128, omic_dim=128, path_scale=1, omic_scale=1,
+        mmhid=128, cut_fuse_grad=False, dropout_rate=0.1, return_grad="False", label_dim=4, task_type="diag2021",
+        attn_dim=2, return_vgrid=True, batch_size=2, world_size=1)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_full_model_reference_grid():
+    """DeformPathomicNet + BatchLoss, B = 2, N = 2500 (the only size the reference supports)."""
+    g = Golden("pathomic_ref50")
+    net = smml.DeformPathomicNet(pathomic_args())
+    params = params_for(net, 42, "pathomic")
+    p = _req(params)
+    B = 2
+    x_path = synth.bag(B, 2500, 1024, 42, "pathomic:bag")
+    x_t = synth.normal((B, 59), 42, "pathomic:tumor")
+    x_i = synth.normal((B, 361), 42, "pathomic:immune")
+    feats, vt, vi, lg = deform_pathomic_net(x_path, x_t, x_i, p, grid_hw=(50, 50))
+    label = torch.tensor([1, 3])
+    l_t, l_i = batch_loss(lg[3], lg[4], B), batch_loss(lg[5], lg[6], B)
+    loss = torch.nn.functional.cross_entropy(lg[2], label) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
+    loss.backward()
+    g.check("features", feats); g.check("vec_t", vt); g.check("vec_i", vi); g.check("haz", lg[2])
+    g.check("vgrid_t", lg[4]); g.check("vgrid_i", lg[6]); g.check("batchloss_t", l_t); g.check("batchloss_i", l_i)
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    n_with_grad = sum(1 for k in g.keys("grad:"))
+    assert n_with_grad == int(g.array("n_params_with_grad"))
+    # parameter gradients of the position-bias MLP are sums over 2.9e7 (query, key) pairs with heavy
+    # cancellation (|grad| ~ 2e-3): fp32 summation order alone moves them by ~2e-4 of their scale
+    _check_grads(g, p, rtol=1e-3)
