@@ -22,6 +22,11 @@ from .nystrom import _sub, layer_norm
 Params = Dict[str, torch.Tensor]
 
 
+def _fl(x):
+    """the reference casts inputs with .float(); an fp64 run (noise calibration of the tests) keeps fp64"""
+    return x if x.dtype == torch.float64 else x.float()
+
+
 def linear(x, p: Params, prefix: str):
     return x @ p[prefix + "weight"].t() + p[prefix + "bias"]
 
@@ -48,9 +53,9 @@ def deform_cross_trans_mil(path, omic, p: Params, *, attn_dim: int = 2, grid_hw:
                            q_chunk: int = 512):
     """path [B, N, F_in], omic [B, C] -> (encoded [B, C], logits [B, n_classes], omic_tiled [B, N, C], vgrid)
     (DeformCrossTransMIL.py:97-160)."""
-    path = torch.relu(linear(path.float(), p, "_fc1.0."))                 # :100
+    path = torch.relu(linear(_fl(path), p, "_fc1.0."))                 # :100
     N = path.shape[1]
-    omic_t = omic.float().unsqueeze(1).repeat(1, N, 1)                    # :104 (2500 in the reference)
+    omic_t = _fl(omic).unsqueeze(1).repeat(1, N, 1)                    # :104 (2500 in the reference)
     h = linear(torch.cat((path, omic_t), dim=-1), p, "fusion_layer.fusion_layer.")   # :35-37,110
     if attn_dim == 1:
         cls = p["cls_token"].expand(h.shape[0], -1, -1)

@@ -28,15 +28,24 @@ def _assert_close(name, got, ref, tol=TOL):
     assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
 
 
-def _compare_param_grads(mod, pref, tol, skip=ZERO_GRADS):
+def _calibrated(name, got, ref32, ref64, floor=TOL):
+    """HIP result vs the fp64 oracle; tolerance = max(1e-4, 8 x the fp32 oracle's own distance to fp64):
+    gradients of the position-bias MLP are ReLU-gated sums over 1e6+ pairs with cancellation, which fp32
+    arithmetic itself only determines to a few 1e-4 of their scale (see tests/diag_gpu.py)."""
+    tol = max(floor, 8.0 * rel_err(ref32, ref64))
+    e = rel_err(got, ref64)
+    assert e <= tol, f"{name}: rel err vs fp64 oracle {e:.3e} > {tol:.3e}"
+
+
+def _compare_param_grads(mod, p32, p64, skip=ZERO_GRADS):
     for k, p in mod.named_parameters():
         if k.endswith(skip):
             continue
-        if pref[k].grad is None:
+        if p32[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         assert p.grad is not None, f"missing grad for {k}"
-        _assert_close("d" + k, p.grad, pref[k].grad, tol)
+        _calibrated("d" + k, p.grad, p32[k].grad, p64[k].grad)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -100,19 +109,23 @@ def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     mod = _load(mod, params, cuda)
     x1 = synth.normal((B, C, N), 7, tag + ":x1"); x2 = synth.normal((B, C, N), 7, tag + ":x2")
     w_out = synth.normal((B, C, N), 7, tag + ":wo")
-    # oracle
-    pref = {k: v.clone().requires_grad_() for k, v in params.items()}
-    a, b = x1.clone().requires_grad_(), x2.clone().requires_grad_()
-    o_ref, vg_ref, aux = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), return_aux=True)
-    w_vg = synth.normal(tuple(vg_ref.shape), 7, tag + ":wvg")
-    ((o_ref * w_out).sum() + (vg_ref * w_vg).sum()).backward()
+    # oracle, fp32 (the reference's arithmetic) and fp64 (truth for the tolerance calibration)
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+        o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww))
+        w_vg = synth.normal(tuple(vg_ref.shape), 7, tag + ":wvg")
+        ((o_ref * w_out.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
+        run[dt] = (o_ref, vg_ref, a.grad, b.grad, pref)
+    r32, r64 = run[torch.float32], run[torch.float64]
     # HIP
     ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
     o, vg = mod(ad, bd, return_vgrid=True)
     ((o * w_out.to(cuda)).sum() + (vg * w_vg.to(cuda)).sum()).backward()
-    _assert_close("out", o, o_ref); _assert_close("vgrid", vg, vg_ref)
-    _assert_close("dx1", ad.grad, a.grad); _assert_close("dx2", bd.grad, b.grad)
-    _compare_param_grads(mod, pref, 2e-4)
+    for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
+        _calibrated(name, got, r32[i], r64[i])
+    _compare_param_grads(mod, r32[4], r64[4])
     # integer path: corners of the kernel's own sample positions, bit-exact against the oracle's formula
     th, tw = vg.shape[-2:]
     vgc = vg.detach().cpu()
@@ -144,7 +157,7 @@ def test_deform2d_golden_reference_grid(cuda):
     assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
     for k, p in mod.named_parameters():
         if not k.endswith(ZERO_GRADS):
-            g.check("grad:" + k, p.grad, rtol=2e-4, what="d" + k)
+            g.check("grad:" + k, p.grad, what="d" + k)
     # integer path on the REFERENCE's vgrid: bit-exact corners / masks
     vgf = torch.from_numpy(g.array("vgrid_full"))
     vs = (2.0 * vgf / 11.0 - 1.0)
@@ -170,7 +183,7 @@ def test_deform1d_golden(cuda, tag, B, n):
     g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
     for k, p in mod.named_parameters():
         if not k.endswith(ZERO_GRADS):
-            g.check("grad:" + k, p.grad, rtol=2e-4, what="d" + k)
+            g.check("grad:" + k, p.grad, what="d" + k)
 
 
 def test_batch_loss_vs_oracle(cuda):
@@ -212,7 +225,7 @@ def test_full_model_golden_reference_grid(cuda):
     assert with_grad == {k[5:] for k in g.keys("grad:")}, "set of parameters receiving a gradient differs"
     for k, p in net.named_parameters():
         if p.grad is not None and not k.endswith(ZERO_GRADS):
-            g.check("grad:" + k, p.grad, rtol=1e-3, what="d" + k)
+            g.check("grad:" + k, p.grad, what="d" + k)
 
 
 def test_mil_branch_larger_grid_vs_oracle(cuda):
@@ -223,14 +236,19 @@ def test_mil_branch_larger_grid_vs_oracle(cuda):
     mil = _load(mil, params, cuda)
     B, S = 1, 64
     path = synth.bag(B, S * S, 512, 3, "mil64:bag"); omic = torch.relu(synth.normal((B, 128), 3, "mil64:omic"))
-    pref = {k: v.clone().requires_grad_() for k, v in params.items()}
-    enc_r, log_r, _, vg_r = deform_cross_trans_mil(path, omic, pref, grid_hw=(S, S))
-    (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        enc_r, log_r, _, vg_r = deform_cross_trans_mil(path.to(dt), omic.to(dt), pref, grid_hw=(S, S))
+        (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
+        run[dt] = (enc_r, log_r, vg_r, pref)
+    r32, r64 = run[torch.float32], run[torch.float64]
     enc, logits, _, omic_t, vg = mil(path.to(cuda), omic.to(cuda))
     (enc.sum() + (logits * logits).sum() + vg.pow(2).sum() * 1e-3).backward()
-    _assert_close("encoded", enc, enc_r); _assert_close("logits", logits, log_r); _assert_close("vgrid", vg, vg_r)
+    for name, got, i in (("encoded", enc, 0), ("logits", logits, 1), ("vgrid", vg, 2)):
+        _calibrated(name, got, r32[i], r64[i])
     assert omic_t.shape == (B, S * S, 128) and torch.equal(omic_t[0, 17].cpu(), omic[0])
-    _compare_param_grads(mil, pref, 1e-3, skip=ZERO_GRADS + ("cls_token",))
+    _compare_param_grads(mil, r32[3], r64[3], skip=ZERO_GRADS + ("cls_token",))
 
 
 def test_size_independent_properties_full_size(cuda):

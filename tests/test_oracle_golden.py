@@ -167,6 +167,6 @@ def test_full_model_reference_grid():
     assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
     n_with_grad = sum(1 for k in g.keys("grad:"))
     assert n_with_grad == int(g.array("n_params_with_grad"))
-    # parameter gradients of the position-bias MLP are sums over 2.9e7 (query, key) pairs with heavy
-    # cancellation (|grad| ~ 2e-3): fp32 summation order alone moves them by ~2e-4 of their scale
-    _check_grads(g, p, rtol=1e-3)
+    # ill-conditioned gradients (position-bias MLP: ReLU-gated sums over 2.9e7 pairs) carry their own fp32
+    # noise in the fixture; Golden.check widens the tolerance to 8 x that noise
+    _check_grads(g, p)
