@@ -23,7 +23,28 @@
 // f32 MFMA rate (157.3 TFLOP/s peak): roofline "mfma".
 #include "smml_common.h"
 
+// tuning knobs (defaults = the configuration measured fastest on MI355X; tests/microbench sweeps them)
+#ifndef SMML_FWD_WPS
+#define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
+#endif
+#ifndef SMML_BWD_WPS
+#define SMML_BWD_WPS 2      // same for the position-bias backward kernel
+#endif
+#ifndef SMML_FAST_MATH
+#define SMML_FAST_MATH 0    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
+#endif
+
 namespace {
+
+#if SMML_FAST_MATH
+__device__ __forceinline__ float slog1p(float d) { return copysignf(__logf(fabsf(d) + 1.0f), d); }
+__device__ __forceinline__ float sexp(float x) { return __expf(x); }
+__device__ __forceinline__ float srcp(float x) { return __frcp_rn(x); }
+#else
+__device__ __forceinline__ float slog1p(float d) { return signed_log1p(d); }
+__device__ __forceinline__ float sexp(float x) { return expf(x); }
+__device__ __forceinline__ float srcp(float x) { return 1.0f / x; }
+#endif
 
 constexpr int DH = 64;       // head dim (fixed: dim_head = 64 in both reference modules)
 constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
@@ -44,7 +65,7 @@ struct CpbParams {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int PD>
-__global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
+__global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
     float* __restrict__ LSE, float* __restrict__ LT, int N, int J, int H, int G, int NST, float scale) {
@@ -52,6 +73,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
   __shared__ float biasT[WAVES][KT][QT];     // per-wave bias tile [key][query]
+  __shared__ float4 tabB[CH];                // {w1x, w1y, b1, -} per hidden channel
+  __shared__ float Qs[WAVES][DH][QT];        // per-wave scaled Q tile, d-major
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -61,33 +84,40 @@ __global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
 
-  // Q row of this lane's query: d = 32*hf + s, pre-multiplied by the softmax scale
-  float qreg[32];
+  // Q tile of this wave, pre-multiplied by the softmax scale, parked in LDS d-major (B operand of S^T):
+  // lane (query c, half hf) owns d = 32 hf .. 32 hf + 31
   {
     const float4* qp = reinterpret_cast<const float4*>(Q + ((size_t)b * N + qi) * HD + h * DH + hf * 32);
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4) {
       const float4 t = qp[s4];
-      qreg[4 * s4 + 0] = t.x * scale; qreg[4 * s4 + 1] = t.y * scale;
-      qreg[4 * s4 + 2] = t.z * scale; qreg[4 * s4 + 3] = t.w * scale;
+      Qs[wave][32 * hf + 4 * s4 + 0][c] = t.x * scale; Qs[wave][32 * hf + 4 * s4 + 1][c] = t.y * scale;
+      Qs[wave][32 * hf + 4 * s4 + 2][c] = t.z * scale; Qs[wave][32 * hf + 4 * s4 + 3][c] = t.w * scale;
     }
   }
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
 
-  // CPB constants in the operand layouts they are consumed in
-  float w2a[16], w1x[16], w1y[16], b1v[16], b2v[16], w3v[16];
+  // CPB constants: W2 (A operand, k-step layout), b2 / w3 (accumulator layout) in VGPRs; the layer-1
+  // weights {w1x, w1y, b1} of channel 16 hf + s are broadcast-read from an LDS table
+  float w2a[16], w3v[16];
+  floatx16 b2acc;                               // b2 in accumulator layout: the chain's initial C operand
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const int ch = 16 * hf + s;                 // layer-2 input channel of k-step s
-    w2a[s] = cp.w2[c * CH + ch];                // A[i = out = c][k = in = ch]
-    w1x[s] = cp.w1[ch * PD];
-    w1y[s] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
-    b1v[s] = cp.b1[ch];
+    w2a[s] = cp.w2[c * CH + 16 * hf + s];       // A[i = out = c][k = in = 16 hf + s]
     const int oc = acc_row(s, hf);              // output channel held in accumulator register s
-    b2v[s] = cp.b2[oc];
+    b2acc[s] = cp.b2[oc];
     w3v[s] = cp.w3[oi * CH + oc];
   }
+  if (tid < 32) {
+    float4 t;
+    t.x = cp.w1[tid * PD];
+    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
+    t.z = cp.b1[tid];
+    t.w = 0.f;
+    tabB[tid] = t;
+  }
+  const float4* tb = tabB + 16 * hf;
   const float b3 = cp.b3[oi];
 
   floatx16 oacc0 = {0}, oacc1 = {0};
@@ -123,25 +153,29 @@ __global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
     // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
 #pragma unroll
-    for (int st = 0; st < 32; ++st) s = mfma32(Ks[32 * hf + st][c], qreg[st], s);
+    for (int st = 0; st < 32; ++st) s = mfma32(Ks[32 * hf + st][c], Qs[wave][32 * hf + st][c], s);
 
-    // continuous position bias: one MFMA chain per key
+    // continuous position bias: one 16-MFMA chain per key.  On gfx950 v_mfma_f32_32x32x2_f32 runs at the fp32
+    // vector rate and does NOT overlap VALU work of the same SIMD (tests/microbench/mfma_probe.hip: every
+    // VALU instruction between two of these MFMAs adds its full issue time), so the loop is written for the
+    // fewest vector instructions: b2 rides in as the chain's initial accumulator, no register copies.
     const int nk = min(KT, J - j0);
     for (int jj = 0; jj < nk; ++jj) {
-      const float p0 = signed_log1p(gq0 - vsl[jj][0]);
-      const float p1 = (PD == 2) ? signed_log1p(gq1 - vsl[jj][1]) : 0.f;
-      floatx16 d = {0};
+      const float p0 = slog1p(gq0 - vsl[jj][0]);
+      const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
+      floatx16 d = b2acc;
 #pragma unroll
       for (int sp = 0; sp < 16; ++sp) {
-        float hv = fmaf(w1x[sp], p0, b1v[sp]);
-        if (PD == 2) hv = fmaf(w1y[sp], p1, hv);
+        const float4 t = tb[sp];
+        float hv = fmaf(t.x, p0, t.z);
+        if (PD == 2) hv = fmaf(t.y, p1, hv);
         d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
       }
-      float t = 0.f;
+      float t3 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t = fmaf(fmaxf(d[r] + b2v[r], 0.f), w3v[r], t);
-      t = xhalf_sum(t) + b3;
-      if (hf == 0) biasT[wave][jj][c] = t;
+      for (int r = 0; r < 16; ++r) t3 = fmaf(fmaxf(d[r], 0.f), w3v[r], t3);
+      t3 = xhalf_sum(t3) + b3;
+      if (hf == 0) biasT[wave][jj][c] = t3;
     }
     wave_lds_fence();
 
@@ -163,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_fwd_kernel(
     }
     tmax = xhalf_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = sexp(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = expf(s[r] - m_new);
+      const float p = sexp(s[r] - m_new);
       s[r] = p;
       psum += p;
     }
@@ -413,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
 
 template <int PD>
-__global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
+__global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
     float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -474,16 +508,23 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
   __syncthreads();
 
+  // next key's operands are fetched one iteration ahead (d bias streams from HBM, used once)
+  float vx_n = VSb[0];
+  float vy_n = (PD == 2) ? VSb[1] : 0.f;
+  float db_n = qvalid ? dLTb[q0 + c] : 0.f;
   for (int j = 0; j < J; ++j) {
-    const float vx = VSb[(size_t)j * PD];
-    const float vy = (PD == 2) ? VSb[(size_t)j * PD + 1] : 0.f;
-    const float dbias = qvalid ? dLTb[(size_t)j * NST + q0 + c] : 0.f;
+    const float vx = vx_n, vy = vy_n, dbias = db_n;
+    if (j + 1 < J) {
+      vx_n = VSb[(size_t)(j + 1) * PD];
+      if (PD == 2) vy_n = VSb[(size_t)(j + 1) * PD + 1];
+      db_n = qvalid ? dLTb[(size_t)(j + 1) * NST + q0 + c] : 0.f;
+    }
     const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = signed_log1p(d0);
-    const float p1 = (PD == 2) ? signed_log1p(d1) : 0.f;
+    const float p0 = slog1p(d0);
+    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
     if (hf == 0) { pl[c * 2] = p0; pl[c * 2 + 1] = p1; }
 
-    // forward recompute: D = W2 . h1
+    // phase 1 - forward recompute: D = W2 . h1
     floatx16 d = {0};
 #pragma unroll
     for (int sp = 0; sp < 16; ++sp) {
@@ -492,60 +533,52 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       if (PD == 2) hv = fmaf(t.y, p1, hv);
       d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
     }
-    // layer 3 backward: dD = dbias * w3 * [h2 > 0]
-    floatx16 dd;
+    // phase 2 - layer-3 backward slice r feeds MFMA r of dh1[in, query] = W2^T . dD straight away
+    // (the sum runs over the accumulator-row index: register r is the B operand of k-step r)
+    floatx16 dh = {0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float h2 = fmaxf(d[r] + tabA[r].w, 0.f);
       aw3[r] = fmaf(dbias, h2, aw3[r]);
       const float g2 = (h2 > 0.f) ? dbias * tab3[r] : 0.f;
       ab2[r] += g2;
-      dd[r] = g2;
       dDl[acc_row(r, hf) * 33 + c] = g2;
+      dh = mfma32(w2t[r], g2, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
-
-    // dh1[in, query] = W2^T . dD   (sum over the accumulator-row index: registers are the B operand)
-    floatx16 dh = {0};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dh = mfma32(w2t[r], dd[r], dh);
-
-    // layer 1 backward in accumulator layout (channel = acc_row(r, hf))
+    asm volatile("" ::: "memory");     // LDS of one wave is in order; only the compiler must not reorder
+    // phase 3 - dW2[out, in] += sum_query dD[out, query] h1[in, query] on the matrix cores
+    //   (A[i = out = c][k = query = 16 hf + s] from LDS, B[k = query][j = in = c] recomputed),
+    //   interleaved with the layer-1 backward of accumulator slice s
     float dp0 = 0.f, dp1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 t = tabA[r];
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int qq = 16 * hf + s2;
+      float hv = fmaf(w1xc, pl[qq * 2], b1c);
+      if (PD == 2) hv = fmaf(w1yc, pl[qq * 2 + 1], hv);
+      e = mfma32(dDl[c * 33 + qq], fmaxf(hv, 0.f), e);
+      const float4 t = tabA[s2];
       float pre = fmaf(t.x, p0, t.z);
       if (PD == 2) pre = fmaf(t.y, p1, pre);
-      const float g1 = (pre > 0.f) ? dh[r] : 0.f;
-      ab1[r] += g1;
-      aw1x[r] = fmaf(g1, p0, aw1x[r]);
+      const float g1 = (pre > 0.f) ? dh[s2] : 0.f;
+      ab1[s2] += g1;
+      aw1x[s2] = fmaf(g1, p0, aw1x[s2]);
       dp0 = fmaf(g1, t.x, dp0);
       if (PD == 2) {
-        aw1y[r] = fmaf(g1, p1, aw1y[r]);
+        aw1y[s2] = fmaf(g1, p1, aw1y[s2]);
         dp1 = fmaf(g1, t.y, dp1);
       }
     }
     // d vs[j] = - sum_query dp / (|d| + 1)
     {
-      float t0 = wave_sum(-dp0 / (fabsf(d0) + 1.f));
+      float t0 = wave_sum(-dp0 * srcp(fabsf(d0) + 1.f));
       if (lane == 0) atomicAdd(&dvs[2 * j], t0);
       if (PD == 2) {
-        float t1 = wave_sum(-dp1 / (fabsf(d1) + 1.f));
+        float t1 = wave_sum(-dp1 * srcp(fabsf(d1) + 1.f));
         if (lane == 0) atomicAdd(&dvs[2 * j + 1], t1);
       }
     }
-    wave_lds_fence();
-    // dW2[out, in] += sum_query dD[out, query] h1[in, query]:
-    //   A[i = out = c][k = query = 16 hf + s] from LDS, B[k = query][j = in = c] recomputed
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int qq = 16 * hf + s;
-      float hv = fmaf(w1xc, pl[qq * 2], b1c);
-      if (PD == 2) hv = fmaf(w1yc, pl[qq * 2 + 1], hv);
-      e = mfma32(dDl[c * 33 + qq], fmaxf(hv, 0.f), e);
-    }
-    wave_lds_fence();
+    asm volatile("" ::: "memory");
   }
 
   // ---- workgroup reduction of the per-lane partials -> slab[wg] ----

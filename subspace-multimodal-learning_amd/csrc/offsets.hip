@@ -182,14 +182,28 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
       }
     }
   }
+  // weight-gradient partials: sum the workgroup's waves in LDS, then ONE contiguous row of float atomics per
+  // workgroup (per-lane atomics at a 144-B stride from every wave ran an order of magnitude slower)
+  __shared__ float red[128 * (KH * KW + 3)];
+  constexpr int KK = KH * KW;
+  const int nred = dg * (KK + 1 + 2);
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
     const int ch = lane + 64 * u;
-    atomicAdd(&db0[ch], ab0[u]);
-    atomicAdd(&dw2[ch], aw2[u][0]);
-    if (PD == 2) atomicAdd(&dw2[dg + ch], aw2[u][1]);
 #pragma unroll
-    for (int t = 0; t < KH * KW; ++t) atomicAdd(&dw0[ch * KH * KW + t], aw0[u][t]);
+    for (int t = 0; t < KK; ++t) atomicAdd(&red[ch * KK + t], aw0[u][t]);
+    atomicAdd(&red[dg * KK + ch], ab0[u]);
+    atomicAdd(&red[dg * (KK + 1) + ch], aw2[u][0]);
+    if (PD == 2) atomicAdd(&red[dg * (KK + 2) + ch], aw2[u][1]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) {
+    const float v = red[i];
+    if (i < dg * KK) atomicAdd(&dw0[i], v);
+    else if (i < dg * (KK + 1)) atomicAdd(&db0[i - dg * KK], v);
+    else if (i < dg * (KK + 1 + PD)) atomicAdd(&dw2[i - dg * (KK + 1)], v);
   }
 }
 
@@ -331,7 +345,7 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
   if (rc) return rc;
   const int pw = (ks - r) / 2;
   const int npts = B * G * th * tw;
-  const int nblk = min((npts + 3) / 4, 2048);
+  const int nblk = min((npts + 3) / 4, 512);
   dim3 grid(nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (posdim == 2 && dg == 64)
