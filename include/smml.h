@@ -35,11 +35,12 @@ int smml_event_elapsed_ms(void* start, void* stop, float* ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Strided-batched fp32 GEMM on the f32 matrix cores (exact fp32):
- *   C[b0,b1](m,n) (+)= act(alpha * sum_k A[b0,b1](m,k) B[b0,b1](k,n) + bias) + residual
+ *   C[b0,b1](m,n) (+)= act(alpha * sum_k A[b0,b1](m,k) B[b0,b1](k,n) + bias) + beta * residual
  * A(m,k) at A + b0*sa0 + b1*sa1 + m*sam + k*sak;  B(k,n) at B + b0*sb0 + b1*sb1 + k*sbk + n*sbn;
  * C(m,n) at C + b0*sc0 + b1*sc1 + m*ldc + n;  residual shares C's batch offsets with row stride ldr.
  * bias_mode 0 none | 1 bias[n] | 2 bias[(m / rows_per_bias) * bias_ld + n];  act 0 none | 1 relu | 2 tanh.
- * splitk > 1: partial products are atomically added into C (caller zeroes C; no act / residual).
+ * splitk > 1 or accumulate != 0: products are atomically added into C (caller zeroes C or keeps a running
+ * sum there; no act / residual); batch strides of 0 on C fold a batch dimension into one output.
  * Replaces nn.Linear / 1x1 nn.Conv sites of the path: models/DeformCrossTransMIL.py:35-37,83,93-95,
  * 196; models/DeformableAttention2D.py:218-221; models/DeformableAttention1D.py:150-153;
  * models/NystromAttention.py:60-65,86,122-140 - and their backward products. */
@@ -48,7 +49,7 @@ int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   long long ldc, long long ldr, int nb0, int nb1, long long sa0, long long sa1,
                   long long sb0, long long sb1, long long sc0, long long sc1, long long sbias0,
                   long long sbias1, int bias_mode, int rows_per_bias, long long bias_ld, int act,
-                  int splitk, float alpha, void* stream);
+                  int splitk, int accumulate, float alpha, float beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.
@@ -129,6 +130,30 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, void* ev_start, void* ev_stop, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Nystrom landmark self-attention, HBM-bound pieces (the contractions of models/NystromAttention.py:86,
+ * 122-140 and the pinv iteration :20-35 run through smml_gemm_f32 with alpha / beta epilogues).
+ * Row softmax over the last dim L of x [rows, L] (:137) and its backward dx = y (dy - sum(dy y)). */
+int smml_softmax_fwd_f32(const float* x, float* y, long long rows, int L, void* stream);
+int smml_softmax_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream);
+/* dst[b, r, c] = scale * src[b, c]: backward of the landmark segment mean (:102-118; the forward is
+ * smml_colsum_f32 over [B*h*m, l, d] with scale 1/l). */
+int smml_tile_rows_f32(const float* src, float* dst, long long nb, int R, int C, float scale, void* stream);
+/* depthwise residual convolution along the tokens (:72,144-145): v [B, H, n, D], w [H, KW] ->
+ * out_merged [B, n, H*D] (heads merged, the layout the output projection consumes). */
+int smml_resconv_fwd_f32(const float* v, const float* w, float* out_merged, int B, int H, int n, int D, int KW,
+                         void* stream);
+/* dv [B, H, n, D] overwritten, dw [H, KW] accumulated into */
+int smml_resconv_bwd_f32(const float* dout_merged, const float* v, const float* w, float* dv, float* dw, int B, int H,
+                         int n, int D, int KW, void* stream);
+/* PPEG (models/mil.py:192-206): depthwise 7x7 + 5x5 + 3x3 + identity as ONE merged 7x7 depthwise pass on
+ * channel-last maps x [B, H, W, C]; wm [C, 49]; flip = 1 applies the rotated kernel (data gradient). */
+int smml_dwconv7_fwd_f32(const float* x, const float* wm, const float* bias, float* y, int B, int H, int W, int C, int flip,
+                         void* stream);
+/* dwm [C, 49], db [C] accumulated into */
+int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, float* db, int B, int H, int W, int C,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,12 +11,13 @@ from ._capi import LIB_PATH, SIGNATURES, lib  # noqa: F401
 from . import functional  # noqa: F401
 from .deform_attention import CPB, DeformCrossAttention1D, DeformCrossAttention2D, Scale  # noqa: F401
 from .deform_cross_trans_mil import DeformCrossTransLayer, DeformCrossTransMIL, FusionNet, Pooler  # noqa: F401
+from .nystrom_attention import NystromAttention, PPEG, TransLayer, TransMIL, moore_penrose_iter_pinv  # noqa: F401
 from .pathomic import DeformPathomicNet, MaxNet, define_net  # noqa: F401
 from .losses import BatchLoss, GatherLayer, OrthogonalLoss  # noqa: F401
 from .data_parallel import BagDataParallel  # noqa: F401
 
 __all__ = [
     "CPB", "Scale", "DeformCrossAttention1D", "DeformCrossAttention2D", "FusionNet", "DeformCrossTransLayer",
-    "DeformCrossTransMIL", "Pooler", "MaxNet", "DeformPathomicNet", "define_net", "BatchLoss", "GatherLayer",
+    "DeformCrossTransMIL", "Pooler", "NystromAttention", "TransLayer", "PPEG", "TransMIL", "moore_penrose_iter_pinv", "MaxNet", "DeformPathomicNet", "define_net", "BatchLoss", "GatherLayer",
     "OrthogonalLoss", "BagDataParallel", "functional", "synth", "lib",
 ]

@@ -22,7 +22,7 @@ SIGNATURES = {
     "smml_abi_version": (_i, []),
     "smml_device_check": (_i, [_i]),
     "smml_gemm_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _ll, _ll, _ll, _ll,
-                           _ll, _ll, _ll, _ll, _i, _i, _ll, _i, _i, _fl, _f]),
+                           _ll, _ll, _ll, _ll, _i, _i, _ll, _i, _i, _i, _fl, _fl, _f]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),
     "smml_layernorm_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _ll, _i, _ll, _fl, _i, _f]),
     "smml_colsum_f32": (_i, [_f, _f, _i, _ll, _i, _fl, _f]),
@@ -37,6 +37,13 @@ SIGNATURES = {
     "smml_deform_attn_fwd_f32": (_i, [_f] * 14 + [_i, _i, _i, _i, _i, _i, _fl, _f, _f, _f]),
     "smml_deform_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_deform_attn_bwd_f32": (_i, [_f] * 26 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _f]),
+    "smml_softmax_fwd_f32": (_i, [_f, _f, _ll, _i, _f]),
+    "smml_softmax_bwd_f32": (_i, [_f, _f, _f, _ll, _i, _f]),
+    "smml_tile_rows_f32": (_i, [_f, _f, _ll, _i, _i, _fl, _f]),
+    "smml_resconv_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_resconv_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_dwconv7_fwd_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_dwconv7_bwd_weight_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "smml_event_create": (C.c_void_p, []),
     "smml_event_destroy": (_i, [_f]),
     "smml_event_record": (_i, [_f, _f]),

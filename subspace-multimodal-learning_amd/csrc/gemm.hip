@@ -1,5 +1,5 @@
 // Strided-batched fp32 GEMM on the gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):
-//   C[b0,b1][m,n] (+)= act(alpha * sum_k A[b0,b1](m,k) * B[b0,b1](k,n) + bias) + residual
+//   C[b0,b1][m,n] (+)= act(alpha * sum_k A[b0,b1](m,k) * B[b0,b1](k,n) + bias) + beta * residual
 // Arbitrary element strides on A and B cover the NN / NT / TN products needed by the linear layers of
 // the path, forward and backward:
 //   _fc1, fusion_layer, to_q/to_k/to_v (grouped 1x1 convs = batch over groups), to_out, pooler.dense,
@@ -24,7 +24,8 @@ struct GemmArgs {
   int nb0, nb1;
   long long sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1;
   int bias_mode, rows_per_bias; long long bias_ld;
-  int act, splitk; float alpha;
+  int act, splitk; float alpha, beta;
+  int atomic;    // accumulate into C with float atomics (split-K, or batch dims folded onto one C)
   int swap_xy;   // column tiles on grid.x (wide outputs: > 65535 column tiles)
 };
 
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       const int m = m0 + wave * 32 + acc_row(r, hf);
       if (m >= g.M) continue;
       float v = g.alpha * (t == 0 ? acc0[r] : acc1[r]);
-      if (g.splitk > 1) {
+      if (g.atomic) {
         if (bias && ks == 0) v += (g.bias_mode == 2) ? bias[(m / g.rows_per_bias) * g.bias_ld + n] : bias[n];
         atomicAdd(&C[m * g.ldc + n], v);
       } else {
         if (bias) v += (g.bias_mode == 2) ? bias[(m / g.rows_per_bias) * g.bias_ld + n] : bias[n];
         v = apply_act(v, g.act);
-        if (res) v += res[m * g.ldr + n];
+        if (res) v = fmaf(g.beta, res[m * g.ldr + n], v);
         C[m * g.ldc + n] = v;
       }
     }
@@ -133,11 +134,12 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
                              long long ldc, long long ldr, int nb0, int nb1, long long sa0, long long sa1,
                              long long sb0, long long sb1, long long sc0, long long sc1, long long sbias0,
                              long long sbias1, int bias_mode, int rows_per_bias, long long bias_ld, int act,
-                             int splitk, float alpha, void* stream) {
+                             int splitk, int accumulate, float alpha, float beta, void* stream) {
   SMML_REQUIRE(A && B && C, "smml_gemm_f32: null operand");
   SMML_REQUIRE(M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0, "smml_gemm_f32: non-positive size (M=%d N=%d K=%d)", M, N, K);
   SMML_REQUIRE(splitk >= 1, "smml_gemm_f32: splitk must be >= 1");
-  SMML_REQUIRE(!(splitk > 1 && (act != 0 || residual)), "smml_gemm_f32: split-K excludes activation/residual");
+  const int atomic = (splitk > 1 || accumulate) ? 1 : 0;
+  SMML_REQUIRE(!(atomic && (act != 0 || residual)), "smml_gemm_f32: split-K / accumulate excludes activation/residual");
   SMML_REQUIRE(bias_mode >= 0 && bias_mode <= 2, "smml_gemm_f32: bad bias_mode %d", bias_mode);
   SMML_REQUIRE(bias_mode != 2 || rows_per_bias > 0, "smml_gemm_f32: rows_per_bias must be positive");
   SMML_REQUIRE(act >= 0 && act <= 2, "smml_gemm_f32: bad activation %d", act);
@@ -148,7 +150,7 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
                "smml_gemm_f32: grid too large (batch*splitk=%lld, row tiles=%lld, col tiles=%lld)", gz, gx, gy);
   GemmArgs g{A, B, C, bias_mode ? bias : nullptr, residual, M, N, K, sam, sak, sbk, sbn, ldc, ldr, nb0, nb1,
              sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1, bias_mode, rows_per_bias > 0 ? rows_per_bias : 1,
-             bias_ld, act, splitk, alpha, swap_xy};
+             bias_ld, act, splitk, alpha, beta, atomic, swap_xy};
   SMML_REQUIRE(!bias_mode || bias, "smml_gemm_f32: bias_mode set but bias is null");
   dim3 grid((unsigned)(swap_xy ? gy : gx), (unsigned)(swap_xy ? gx : gy), (unsigned)gz);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);

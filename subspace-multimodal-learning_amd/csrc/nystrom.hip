@@ -1,0 +1,336 @@
+// HBM-bound pieces of the Nystrom landmark self-attention block for gfx950 (the dense contractions run in
+// gemm.hip on the matrix cores):
+//   row softmax forward / backward           models/NystromAttention.py:137 (attn1, attn2, attn3; attn3's rows are n' long)
+//   landmark segment means (+ backward tile) :102-118   (forward = colsum_kernel over [B*h*m, l, d]; backward = tile_rows)
+//   depthwise residual conv along tokens     :72,144-145 (33 taps, per head, no bias), forward / data / weight gradients
+//   PPEG depthwise 7x7 + 5x5 + 3x3 + identity models/mil.py:192-206 as ONE merged 7x7 depthwise pass, channel-last
+// Layouts: scores [rows, L]; v [B, h, n', d]; conv output merged [B, n', h*d]; PPEG maps [B, H, W, C].
+#include "smml_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// one 256-thread block per row; rows of any length (three passes, the row stays L2/MALL resident)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int L) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* xr = x + row * L;
+  float* yr = y + row * L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int i = tid; i < L; i += 256) m = fmaxf(m, xr[i]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < L; i += 256) s += expf(xr[i] - m);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = tid; i < L; i += 256) yr[i] = expf(xr[i] - m) * inv;
+}
+
+// dx = y * (dy - sum(dy * y))
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int L) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* yr = y + row * L;
+  const float* dr = dy + row * L;
+  float* xr = dx + row * L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int i = tid; i < L; i += 256) s = fmaf(yr[i], dr[i], s);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  for (int i = tid; i < L; i += 256) xr[i] = yr[i] * (dr[i] - dot);
+}
+
+// short rows (L <= 1024): one wave per row, the row lives in registers
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               long long rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * L;
+  float v[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < L) ? xr[c] : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+  const float inv = 1.f / wave_sum(s);
+  float* yr = y + row * L;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < L) yr[c] = v[i] * inv;
+  }
+}
+
+// dst[b, r, c] = scale * src[b, c]  (backward of a mean over r)
+__global__ void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long nb, int R, int C,
+                                 float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = nb * R * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long b = i / ((long long)R * C);
+  dst[i] = src[b * C + c] * scale;
+}
+
+// out[b, t, h*D + d] (+)= sum_k w[h, k] * v[b, h, t + k - KW/2, d]     (zero padding), float4 over d
+__global__ __launch_bounds__(256) void resconv_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w,
+                                                          float* __restrict__ out, int B, int Hh, int n, int D, int KW) {
+  const int d4n = D >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * Hh * n * d4n;
+  if (idx >= total) return;
+  const int d4 = (int)(idx % d4n);
+  const int t = (int)((idx / d4n) % n);
+  const int h = (int)((idx / ((long long)d4n * n)) % Hh);
+  const int b = (int)(idx / ((long long)d4n * n * Hh));
+  const float* vb = v + (((long long)b * Hh + h) * n) * D + d4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int half = KW / 2;
+  for (int k = 0; k < KW; ++k) {
+    const int tt = t + k - half;
+    if (tt < 0 || tt >= n) continue;
+    const float wk = w[h * KW + k];
+    const float4 x = *reinterpret_cast<const float4*>(vb + (long long)tt * D);
+    acc.x = fmaf(wk, x.x, acc.x); acc.y = fmaf(wk, x.y, acc.y); acc.z = fmaf(wk, x.z, acc.z); acc.w = fmaf(wk, x.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(out + ((long long)b * n + t) * (Hh * D) + h * D + d4 * 4) = acc;
+}
+
+// dv[b, h, t, d] = sum_k w[h, k] * dout[b, t - k + KW/2, h*D + d]
+__global__ __launch_bounds__(256) void resconv_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                               float* __restrict__ dv, int B, int Hh, int n, int D, int KW) {
+  const int d4n = D >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * Hh * n * d4n;
+  if (idx >= total) return;
+  const int d4 = (int)(idx % d4n);
+  const int t = (int)((idx / d4n) % n);
+  const int h = (int)((idx / ((long long)d4n * n)) % Hh);
+  const int b = (int)(idx / ((long long)d4n * n * Hh));
+  const float* db = dout + ((long long)b * n) * (Hh * D) + h * D + d4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int half = KW / 2;
+  for (int k = 0; k < KW; ++k) {
+    const int tt = t - k + half;
+    if (tt < 0 || tt >= n) continue;
+    const float wk = w[h * KW + k];
+    const float4 x = *reinterpret_cast<const float4*>(db + (long long)tt * (Hh * D));
+    acc.x = fmaf(wk, x.x, acc.x); acc.y = fmaf(wk, x.y, acc.y); acc.z = fmaf(wk, x.z, acc.z); acc.w = fmaf(wk, x.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(dv + (((long long)b * Hh + h) * n + t) * D + d4 * 4) = acc;
+}
+
+// dw[h, k] += sum_{b, t, d} dout[b, t, h*D + d] * v[b, h, t + k - KW/2, d]; one block per (h, b, chunk of t)
+__global__ __launch_bounds__(256) void resconv_bwd_weight_kernel(const float* __restrict__ dout, const float* __restrict__ v,
+                                                                 float* __restrict__ dw, int B, int Hh, int n, int D, int KW,
+                                                                 int tchunk) {
+  __shared__ float red[64];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * tchunk, t1 = min(n, t0 + tchunk);
+  const int tid = threadIdx.x;
+  const int half = KW / 2;
+  if (tid < 64) red[tid] = 0.f;
+  __syncthreads();
+  const float* vb = v + (((long long)b * Hh + h) * n) * D;
+  const float* db = dout + ((long long)b * n) * (Hh * D) + h * D;
+  // thread -> (tap k = tid % KWp, lane group): each thread owns one tap and strides over (t, d)
+  for (int k = tid >> 3; k < KW; k += 32) {
+    float s = 0.f;
+    const int sub = tid & 7;            // 8 threads per tap split d
+    for (int t = t0; t < t1; ++t) {
+      const int tt = t + k - half;
+      if (tt < 0 || tt >= n) continue;
+      for (int d = sub; d < D; d += 8) s = fmaf(db[(long long)t * (Hh * D) + d], vb[(long long)tt * D + d], s);
+    }
+    atomicAdd(&red[k], s);
+  }
+  __syncthreads();
+  if (tid < KW) atomicAdd(&dw[h * KW + tid], red[tid]);
+}
+
+// PPEG: y[b, y, x, c] = bias[c] + sum_{ky,kx} wm[c, ky, kx] * x[b, y+ky-3, x+kx-3, c]  (wm = merged 7x7 incl. identity)
+__global__ __launch_bounds__(256) void dw7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wm,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                      int W, int C, int flip) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * H * W * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int px = (int)((idx / C) % W);
+  const int py = (int)((idx / ((long long)C * W)) % H);
+  const int b = (int)(idx / ((long long)C * W * H));
+  float acc = bias ? bias[c] : 0.f;
+  const float* xb = x + (long long)b * H * W * C + c;
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    const int yy = py + ky - 3;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int xx = px + kx - 3;
+      if (xx < 0 || xx >= W) continue;
+      const int wi = flip ? (6 - ky) * 7 + (6 - kx) : ky * 7 + kx;
+      acc = fmaf(wm[c * 49 + wi], xb[((long long)yy * W + xx) * C], acc);
+    }
+  }
+  y[idx] = acc;
+}
+
+// dwm[c, ky, kx] += sum_{b,y,x} dy[b,y,x,c] * x[b, y+ky-3, x+kx-3, c]; db[c] += sum dy
+// block = 64 channels x 4 pixel lanes, grid-stride over pixels; 49 + 1 register accumulators per thread
+__global__ __launch_bounds__(256) void dw7_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dwm, float* __restrict__ db, int B, int H,
+                                                             int W, int C) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  float acc[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) acc[i] = 0.f;
+  float ab = 0.f;
+  const long long npix = (long long)B * H * W;
+  if (c < C) {
+    for (long long p = (long long)blockIdx.x * 4 + pl; p < npix; p += (long long)gridDim.x * 4) {
+      const int px = (int)(p % W), py = (int)((p / W) % H);
+      const long long b = p / ((long long)W * H);
+      const float g = dy[p * C + c];
+      ab += g;
+      const float* xb = x + b * H * W * C + c;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int yy = py + ky - 3;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const int xx = px + kx - 3;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * 7 + kx] = fmaf(g, xb[((long long)yy * W + xx) * C], acc[ky * 7 + kx]);
+        }
+      }
+    }
+  }
+  __shared__ float red[64 * 50];
+  for (int i = threadIdx.x; i < 64 * 50; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int cl = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 49; ++i) atomicAdd(&red[cl * 50 + i], acc[i]);
+  atomicAdd(&red[cl * 50 + 49], ab);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 50; i += 256) {
+    const int cc = blockIdx.y * 64 + i / 50, k = i % 50;
+    if (cc < C) {
+      if (k < 49) atomicAdd(&dwm[cc * 49 + k], red[i]);
+      else atomicAdd(&db[cc], red[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int smml_softmax_fwd_f32(const float* x, float* y, long long rows, int L, void* stream) {
+  SMML_REQUIRE(x && y && rows > 0 && L > 0, "smml_softmax_fwd_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (L <= 256) {
+    hipLaunchKernelGGL(softmax_fwd_wave_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, y, rows, L);
+  } else if (L <= 1024) {
+    hipLaunchKernelGGL(softmax_fwd_wave_kernel<16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, y, rows, L);
+  } else {
+    SMML_REQUIRE(rows <= 2147483647LL, "smml_softmax_fwd_f32: too many rows");
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, y, L);
+  }
+  SMML_LAUNCH_CHECK("smml_softmax_fwd_f32");
+  return SMML_OK;
+}
+
+int smml_softmax_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, void* stream) {
+  SMML_REQUIRE(y && dy && dx && rows > 0 && L > 0 && rows <= 2147483647LL, "smml_softmax_bwd_f32: bad argument");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, L);
+  SMML_LAUNCH_CHECK("smml_softmax_bwd_f32");
+  return SMML_OK;
+}
+
+int smml_tile_rows_f32(const float* src, float* dst, long long nb, int R, int C, float scale, void* stream) {
+  SMML_REQUIRE(src && dst && nb > 0 && R > 0 && C > 0, "smml_tile_rows_f32: bad argument");
+  const long long total = nb * R * C;
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, nb,
+                     R, C, scale);
+  SMML_LAUNCH_CHECK("smml_tile_rows_f32");
+  return SMML_OK;
+}
+
+int smml_resconv_fwd_f32(const float* v, const float* w, float* out_merged, int B, int H, int n, int D, int KW,
+                         void* stream) {
+  SMML_REQUIRE(v && w && out_merged && B > 0 && H > 0 && n > 0 && D > 0 && D % 4 == 0 && KW > 0 && KW % 2 == 1,
+               "smml_resconv_fwd_f32: bad argument (D %% 4 == 0, odd kernel)");
+  const long long total = (long long)B * H * n * (D / 4);
+  hipLaunchKernelGGL(resconv_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, w,
+                     out_merged, B, H, n, D, KW);
+  SMML_LAUNCH_CHECK("smml_resconv_fwd_f32");
+  return SMML_OK;
+}
+
+// dv overwritten; dw accumulated into
+int smml_resconv_bwd_f32(const float* dout_merged, const float* v, const float* w, float* dv, float* dw, int B, int H,
+                         int n, int D, int KW, void* stream) {
+  SMML_REQUIRE(dout_merged && v && w && dv && dw && D % 4 == 0 && KW % 2 == 1 && KW <= 64,
+               "smml_resconv_bwd_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)B * H * n * (D / 4);
+  hipLaunchKernelGGL(resconv_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout_merged, w, dv, B,
+                     H, n, D, KW);
+  SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/data");
+  const int tchunk = 64;
+  hipLaunchKernelGGL(resconv_bwd_weight_kernel, dim3((n + tchunk - 1) / tchunk, H, B), dim3(256), 0, st, dout_merged, v, dw,
+                     B, H, n, D, KW, tchunk);
+  SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/weight");
+  return SMML_OK;
+}
+
+// merged depthwise 7x7 on channel-last maps; flip = 1 applies the 180-degree rotated kernel (data gradient)
+int smml_dwconv7_fwd_f32(const float* x, const float* wm, const float* bias, float* y, int B, int H, int W, int C, int flip,
+                         void* stream) {
+  SMML_REQUIRE(x && wm && y && B > 0 && H > 0 && W > 0 && C > 0, "smml_dwconv7_fwd_f32: bad argument");
+  const long long total = (long long)B * H * W * C;
+  hipLaunchKernelGGL(dw7_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, wm, bias, y,
+                     B, H, W, C, flip);
+  SMML_LAUNCH_CHECK("smml_dwconv7_fwd_f32");
+  return SMML_OK;
+}
+
+// dwm [C, 49] and db [C] accumulated into
+int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, float* db, int B, int H, int W, int C,
+                                void* stream) {
+  SMML_REQUIRE(x && dy && dwm && db && B > 0 && H > 0 && W > 0 && C > 0, "smml_dwconv7_bwd_weight_f32: bad argument");
+  const long long npix = (long long)B * H * W;
+  const int gx = (int)((npix + 3) / 4 < 256 ? (npix + 3) / 4 : 256);
+  hipLaunchKernelGGL(dw7_bwd_weight_kernel, dim3(gx, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, dy, dwm, db, B, H,
+                     W, C);
+  SMML_LAUNCH_CHECK("smml_dwconv7_bwd_weight_f32");
+  return SMML_OK;
+}
+
+}  // extern "C"

@@ -63,11 +63,11 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 def _gemm(A, B, C, *, M, N, K, sam, sak, sbk, sbn, ldc, bias=None, bias_mode=0, rows_per_bias=1, bias_ld=0,
           residual=None, ldr=0, act=ACT_NONE, splitk=1, alpha=1.0, nb0=1, nb1=1, sa0=0, sa1=0, sb0=0, sb1=0,
-          sc0=0, sc1=0, sbias0=0, sbias1=0):
+          sc0=0, sc1=0, sbias0=0, sbias1=0, beta=1.0, accumulate=0):
     capi.check(capi.lib().smml_gemm_f32(
         capi.fptr(A), capi.fptr(B), capi.fptr(C), capi.fptr(bias), capi.fptr(residual), M, N, K,
         sam, sak, sbk, sbn, ldc, ldr, nb0, nb1, sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1,
-        bias_mode, rows_per_bias, bias_ld, act, splitk, float(alpha), capi.stream()), "gemm")
+        bias_mode, rows_per_bias, bias_ld, act, splitk, accumulate, float(alpha), float(beta), capi.stream()), "gemm")
 
 
 def _splitk_for(out_rows: int, out_cols: int, k: int, batches: int = 1) -> int:
@@ -450,3 +450,204 @@ class _Gram(torch.autograd.Function):
 
 def gram(x):
     return _Gram.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# generic batched product on the matrix cores: C = alpha * op(A) @ op(B) + beta * R
+# (Nystrom sims / landmark products / pinv iteration, co-attention)
+# ------------------------------------------------------------------------------------------------
+def _op_view(T, trans):
+    """(rows, cols, row stride, col stride, batch strides) of op(T) for a contiguous [t0, t1, r, c] tensor."""
+    t0, t1, r, c = T.shape
+    s0 = t1 * r * c if t0 > 1 else 0
+    s1 = r * c if t1 > 1 else 0
+    return (c, r, 1, c, s0, s1) if trans else (r, c, c, 1, s0, s1)
+
+
+class _MatMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, R, ta, tb, alpha, beta, merged):
+        A, B = _c(A), _c(B)
+        M, K, sam, sak, sa0, sa1 = _op_view(A, ta)
+        K2, N, sbk, sbn, sb0, sb1 = _op_view(B, tb)
+        if K != K2:
+            raise RuntimeError(f"matmul4: inner dimensions differ ({K} vs {K2})")
+        nb0, nb1 = max(A.shape[0], B.shape[0]), max(A.shape[1], B.shape[1])
+        if merged:
+            Cm = torch.empty(nb0, M, nb1 * N, device=A.device, dtype=torch.float32)
+            ldc, sc0, sc1 = nb1 * N, M * nb1 * N, N
+        else:
+            Cm = torch.empty(nb0, nb1, M, N, device=A.device, dtype=torch.float32)
+            ldc, sc0, sc1 = N, nb1 * M * N, M * N
+        Rc = None
+        if R is not None:
+            Rc = _c(R)
+            if Rc.shape != Cm.shape:
+                raise RuntimeError("matmul4: residual must have the output's shape")
+        _gemm(A, B, Cm, M=M, N=N, K=K, sam=sam, sak=sak, sbk=sbk, sbn=sbn, ldc=ldc, residual=Rc, ldr=ldc, nb0=nb0,
+              nb1=nb1, sa0=sa0, sa1=sa1, sb0=sb0, sb1=sb1, sc0=sc0, sc1=sc1, alpha=alpha, beta=beta)
+        ctx.cfg = (ta, tb, float(alpha), float(beta), merged, nb0, nb1, M, N, K, R is not None)
+        ctx.save_for_backward(A, B)
+        return Cm
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        ta, tb, alpha, beta, merged, nb0, nb1, M, N, K, has_r = ctx.cfg
+        dC = _c(dC)
+        if merged:
+            ldc, sc0, sc1 = nb1 * N, M * nb1 * N, N
+        else:
+            ldc, sc0, sc1 = N, nb1 * M * N, M * N
+        _, _, a_sr, a_sc, sa0, sa1 = _op_view(A, ta)       # strides of op(A)[m, k]
+        _, _, b_sr, b_sc, sb0, sb1 = _op_view(B, tb)       # strides of op(B)[k, n]
+        dA = dB = dR = None
+
+        def run(out, Mx, Nx, Kx, Xa, xa, Xb, xb, ld_out, bcast):
+            nb = nb0 * nb1
+            splitk = _splitk_for(Mx, Nx, Kx, nb)
+            acc = 1 if (bcast or splitk > 1) else 0
+            _gemm(Xa, Xb, out, M=Mx, N=Nx, K=Kx, sam=xa[0], sak=xa[1], sbk=xb[0], sbn=xb[1], ldc=ld_out, nb0=nb0, nb1=nb1,
+                  sa0=xa[2], sa1=xa[3], sb0=xb[2], sb1=xb[3],
+                  sc0=(out.shape[1] * out.shape[2] * out.shape[3] if out.shape[0] > 1 else 0),
+                  sc1=(out.shape[2] * out.shape[3] if out.shape[1] > 1 else 0), alpha=alpha, splitk=splitk,
+                  accumulate=acc)
+
+        if ctx.needs_input_grad[0]:
+            bcast = (A.shape[0] < nb0) or (A.shape[1] < nb1)
+            dA = torch.zeros_like(A)
+            if not ta:   # dA[m, k] = sum_n dC[m, n] opB[k, n]
+                run(dA, M, K, N, dC, (ldc, 1, sc0, sc1), B, (b_sc, b_sr, sb0, sb1), A.shape[3], bcast)
+            else:        # A stored [K, M]: dA[k, m] = sum_n opB[k, n] dC[m, n]
+                run(dA, K, M, N, B, (b_sr, b_sc, sb0, sb1), dC, (1, ldc, sc0, sc1), A.shape[3], bcast)
+        if ctx.needs_input_grad[1]:
+            bcast = (B.shape[0] < nb0) or (B.shape[1] < nb1)
+            dB = torch.zeros_like(B)
+            if not tb:   # B stored [K, N]: dB[k, n] = sum_m opA[m, k] dC[m, n]
+                run(dB, K, N, M, A, (a_sc, a_sr, sa0, sa1), dC, (ldc, 1, sc0, sc1), B.shape[3], bcast)
+            else:        # B stored [N, K]: dB[n, k] = sum_m dC[m, n] opA[m, k]
+                run(dB, N, K, M, dC, (1, ldc, sc0, sc1), A, (a_sr, a_sc, sa0, sa1), B.shape[3], bcast)
+        if has_r and ctx.needs_input_grad[2]:
+            dR = dC * beta if beta != 1.0 else dC
+        return dA, dB, dR, None, None, None, None, None
+
+
+def matmul4(A, B, R=None, *, ta=False, tb=False, alpha=1.0, beta=1.0, merged=False):
+    """alpha * op(A) @ op(B) + beta * R for [nb0, nb1, rows, cols] tensors (size-1 batch dims broadcast);
+    merged=True lays the result out as [nb0, M, nb1 * N] (heads merged)."""
+    return _MatMul.apply(A, B, R, ta, tb, alpha, beta, merged)
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        L = x.shape[-1]
+        y = torch.empty_like(x)
+        capi.check(capi.lib().smml_softmax_fwd_f32(capi.fptr(x), capi.fptr(y), x.numel() // L, L, capi.stream()), "softmax_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        L = y.shape[-1]
+        dx = torch.empty_like(y)
+        capi.check(capi.lib().smml_softmax_bwd_f32(capi.fptr(y), capi.fptr(_c(dy)), capi.fptr(dx), y.numel() // L, L,
+                                                   capi.stream()), "softmax_bwd")
+        return dx
+
+
+def softmax_rows(x):
+    return _SoftmaxRows.apply(x)
+
+
+class _SegmentMean(torch.autograd.Function):
+    """x [..., n, d] -> mean over l consecutive tokens -> [..., n / l, d]."""
+
+    @staticmethod
+    def forward(ctx, x, l):
+        x = _c(x)
+        n, d = x.shape[-2:]
+        lead = x.numel() // (n * d)
+        m = n // l
+        ctx.l = l
+        ctx.shape = x.shape
+        return colsum(x.view(lead * m, l, d), 1.0 / l).view(*x.shape[:-2], m, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        d = dy.shape[-1]
+        nb = dy.numel() // d
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_tile_rows_f32(capi.fptr(dy), capi.fptr(dx), nb, ctx.l, d, 1.0 / ctx.l, capi.stream()),
+                   "tile_rows")
+        return dx, None
+
+
+def segment_mean(x, l: int):
+    return _SegmentMean.apply(x, l)
+
+
+class _ResConv(torch.autograd.Function):
+    """Depthwise convolution along the tokens, per head: v [B, h, n, d], w [h, KW] -> [B, n, h*d] (heads merged)."""
+
+    @staticmethod
+    def forward(ctx, v, w):
+        v = _c(v)
+        w2 = _c(w).reshape(w.shape[0], -1)
+        B, H, n, D = v.shape
+        out = torch.empty(B, n, H * D, device=v.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_resconv_fwd_f32(capi.fptr(v), capi.fptr(w2), capi.fptr(out), B, H, n, D, w2.shape[1],
+                                                   capi.stream()), "resconv_fwd")
+        ctx.wshape = w.shape
+        ctx.save_for_backward(v, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, w2 = ctx.saved_tensors
+        B, H, n, D = v.shape
+        dv = torch.empty_like(v)
+        dw = torch.zeros_like(w2)
+        capi.check(capi.lib().smml_resconv_bwd_f32(capi.fptr(_c(dout)), capi.fptr(v), capi.fptr(w2), capi.fptr(dv),
+                                                   capi.fptr(dw), B, H, n, D, w2.shape[1], capi.stream()), "resconv_bwd")
+        return dv, dw.reshape(ctx.wshape)
+
+
+def resconv(v, w):
+    return _ResConv.apply(v, w)
+
+
+class _DwConv7(torch.autograd.Function):
+    """Depthwise 7x7 convolution (padding 3) on channel-last maps x [B, H, W, C] with weights wm [C, 49], bias [C]."""
+
+    @staticmethod
+    def forward(ctx, x, wm, bias):
+        x, wm, bias = _c(x), _c(wm), _c(bias)
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        capi.check(capi.lib().smml_dwconv7_fwd_f32(capi.fptr(x), capi.fptr(wm), capi.fptr(bias), capi.fptr(y), B, H, W, Cc, 0,
+                                                   capi.stream()), "dwconv7_fwd")
+        ctx.save_for_backward(x, wm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        L = capi.lib()
+        capi.check(L.smml_dwconv7_fwd_f32(capi.fptr(dy), capi.fptr(wm), None, capi.fptr(dx), B, H, W, Cc, 1, capi.stream()),
+                   "dwconv7_bwd_data")
+        dwm = torch.zeros_like(wm)
+        db = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+        capi.check(L.smml_dwconv7_bwd_weight_f32(capi.fptr(x), capi.fptr(dy), capi.fptr(dwm), capi.fptr(db), B, H, W, Cc,
+                                                 capi.stream()), "dwconv7_bwd_weight")
+        return dx, dwm, db
+
+
+def dwconv7(x, wm, bias):
+    return _DwConv7.apply(x, wm, bias)

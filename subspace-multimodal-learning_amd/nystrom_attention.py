@@ -1,0 +1,155 @@
+"""Host-side mirror of the Nystrom landmark self-attention block on the HIP kernels.
+
+  NystromAttention  models/NystromAttention.py:39-157 (dup models/cmta_utils.py:166-281; the pip package
+                    `nystrom_attention` imported at models/mil.py:24 states the same algorithm)
+  TransLayer        models/mil.py:171-189   (dup cmta_utils.py:858-874)
+  PPEG              models/mil.py:192-206   (dup cmta_utils.py:877-891)
+  TransMIL          models/mil.py:209-259
+
+Same constructors, forward signatures and parameter names.  Every contraction (qkv projection, the three
+similarity products, the six Newton-Schulz iterations of the pseudo-inverse written as alpha/beta GEMM
+epilogues, (attn1 z)(attn3 v), output projection) runs on the matrix cores through smml_gemm_f32; softmax,
+landmark means, the 33-tap residual convolution and PPEG's merged 7x7 depthwise pass are HBM-bound kernels.
+Kept as in the reference: zero padding in FRONT of the sequence (:82), the batch-global max in the
+pseudo-inverse initialisation (:26).  Not built: the `mask` argument (no caller in the reference passes it)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as Fh
+
+
+def moore_penrose_iter_pinv(x, iters=6):
+    """x [B, h, m, m] -> Newton-Schulz pseudo-inverse (NystromAttention.py:20-35).
+    z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz))) evaluated as four GEMMs per iteration:
+    xz; a = 7 xz - xz xz; b = 15 xz - xz a; z = 3.25 z - 0.25 z b."""
+    ax = x.abs()
+    z = (x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())).contiguous()
+    for _ in range(iters):
+        xz = Fh.matmul4(x, z)
+        a = Fh.matmul4(xz, xz, xz, alpha=-1.0, beta=7.0)
+        b = Fh.matmul4(xz, a, xz, alpha=-1.0, beta=15.0)
+        z = Fh.matmul4(z, b, z, alpha=-0.25, beta=3.25)
+    return z
+
+
+class NystromAttention(nn.Module):
+    def __init__(self, dim, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True,
+                 residual_conv_kernel=33, eps=1e-8, dropout=0.):
+        super().__init__()
+        self.eps = eps
+        inner_dim = heads * dim_head
+        self.num_landmarks = num_landmarks
+        self.pinv_iterations = pinv_iterations
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+        self.residual = residual
+        if residual:
+            kernel_size = residual_conv_kernel
+            padding = residual_conv_kernel // 2
+            self.res_conv = nn.Conv2d(heads, heads, (kernel_size, 1), padding=(padding, 0), groups=heads, bias=False)
+
+    def forward(self, x, mask=None, return_attn=False):
+        if mask is not None:
+            raise NotImplementedError("the mask argument is not built on the HIP path (no caller in the reference uses it)")
+        b, n, dim = x.shape
+        h, m, d = self.heads, self.num_landmarks, self.dim_head
+        pad = (m - n % m) % m
+        if pad:
+            x = F.pad(x, (0, 0, pad, 0), value=0)              # zero rows in FRONT (:82)
+        npad = n + pad
+        l = math.ceil(n / m)
+        x4 = x.reshape(b, 1, npad, dim)
+        wq, wk, wv = (w.reshape(1, h, d, dim) for w in self.to_qkv.weight.chunk(3, dim=0))
+        q = Fh.matmul4(x4, wq, tb=True, alpha=self.scale)      # [b, h, n', d], already scaled (:98)
+        k = Fh.matmul4(x4, wk, tb=True)
+        v = Fh.matmul4(x4, wv, tb=True)
+        ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)  # landmarks (:102-118)
+        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True))       # [b, h, n', m]
+        a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True))      # [b, h, m, m]
+        a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True))       # [b, h, m, n']
+        z = moore_penrose_iter_pinv(a2, self.pinv_iterations)
+        left = Fh.matmul4(a1, z)                               # [b, h, n', m]
+        right = Fh.matmul4(a3, v)                              # [b, h, m, d]
+        res = Fh.resconv(v, self.res_conv.weight) if self.residual else None
+        out = Fh.matmul4(left, right, res, merged=True)        # [b, n', h*d]  (:140,144-146)
+        out = Fh.linear(out, self.to_out[0].weight, self.to_out[0].bias)
+        out = self.to_out[1](out)
+        out = out[:, -n:]
+        if return_attn:
+            attn = Fh.matmul4(left, a3)
+            return out, attn
+        return out
+
+
+class TransLayer(nn.Module):
+    def __init__(self, norm_layer=nn.LayerNorm, dim=512):
+        super().__init__()
+        self.norm = norm_layer(dim)
+        self.attn = NystromAttention(dim=dim, dim_head=dim // 8, heads=8, num_landmarks=dim // 2, pinv_iterations=6,
+                                     residual=True, dropout=0.1)
+
+    def forward(self, x):
+        return x + self.attn(Fh.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps))
+
+
+class PPEG(nn.Module):
+    def __init__(self, dim=512):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, 7, 1, 7 // 2, groups=dim)
+        self.proj1 = nn.Conv2d(dim, dim, 5, 1, 5 // 2, groups=dim)
+        self.proj2 = nn.Conv2d(dim, dim, 3, 1, 3 // 2, groups=dim)
+
+    def merged_kernel(self):
+        """7x7 + zero-padded 5x5 + zero-padded 3x3 + identity -> one [C, 49] depthwise kernel and one bias."""
+        w = self.proj.weight + F.pad(self.proj1.weight, (1, 1, 1, 1)) + F.pad(self.proj2.weight, (2, 2, 2, 2))
+        C = w.shape[0]
+        ident = torch.zeros(1, 1, 7, 7, device=w.device, dtype=w.dtype)
+        ident[0, 0, 3, 3] = 1.0
+        return (w + ident).reshape(C, 49), self.proj.bias + self.proj1.bias + self.proj2.bias
+
+    def forward(self, x, H, W):
+        B, _, C = x.shape
+        cls_token, feat_token = x[:, :1], x[:, 1:]
+        wm, bias = self.merged_kernel()
+        y = Fh.dwconv7(feat_token.reshape(B, H, W, C), wm, bias)     # token-major = channel-last map
+        return torch.cat((cls_token, y.reshape(B, H * W, C)), dim=1)
+
+
+class TransMIL(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.pos_layer = PPEG(dim=512)
+        self._fc1 = nn.Sequential(nn.Linear(int(getattr(args, "input_path_dim", 1024) or 1024), 512), nn.ReLU())
+        self.cls_token = nn.Parameter(torch.randn(1, 1, 512))
+        self.n_classes = self.args.label_dim
+        self.layer1 = TransLayer(dim=512)
+        self.layer2 = TransLayer(dim=512)
+        self.norm = nn.LayerNorm(512)
+        self._fc2 = nn.Linear(512, self.n_classes)
+        self.multimodal_projection = nn.Linear(512, self.args.path_dim)
+
+    def forward(self, x):
+        h = Fh.linear(x.float(), self._fc1[0].weight, self._fc1[0].bias, act=Fh.ACT_RELU)
+        Hn = h.shape[1]
+        _H = _W = int(np.ceil(np.sqrt(Hn)))
+        add_length = _H * _W - Hn
+        h = torch.cat([h, h[:, :add_length, :]], dim=1)                 # wrap-pad to a square (:232-235)
+        B = h.shape[0]
+        h = torch.cat((self.cls_token.expand(B, -1, -1).to(h.device), h), dim=1)
+        h = self.layer1(h)
+        h = self.pos_layer(h, _H, _W)
+        h = self.layer2(h)
+        h = Fh.layer_norm(h[:, :1], self.norm.weight, self.norm.bias, self.norm.eps)[:, 0]
+        logits = Fh.linear(h, self._fc2.weight, self._fc2.bias)
+        encoded = Fh.linear(h, self.multimodal_projection.weight, self.multimodal_projection.bias)
+        return encoded, logits, None

@@ -45,7 +45,7 @@ def test_argument_counts_match_header():
 def test_error_channel_without_gpu():
     L = smml.lib()
     rc = L.smml_gemm_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1,
-                         0, 0, 1, 1.0, None)
+                         0, 0, 1, 0, 1.0, 1.0, None)
     assert rc < 0 and b"null" in L.smml_last_error()
     assert L.smml_offsets_out_len(50, 6, 4) == 12 and L.smml_offsets_out_len(100, 6, 4) == 25
     assert L.smml_offsets_out_len(2501, 6, 4) == 625 and L.smml_deform_attn_nst(2500) == 2528

@@ -1,0 +1,142 @@
+"""GPU parity of the Nystrom block (a1-a3): HIP kernels vs golden vectors generated from the reference and vs
+the CPU oracle (fp64-calibrated tolerance, see test_gpu_parity._calibrated)."""
+import argparse
+
+import pytest
+import torch
+
+from helpers import Golden, params_for, rel_err, smml, synth
+from oracle.nystrom import nystrom_attention, pinv_newton_schulz, ppeg, trans_layer, trans_mil
+from test_gpu_parity import _assert_close, _calibrated, _load
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+
+
+def test_matmul4_autograd_all_layouts(cuda):
+    torch.manual_seed(0)
+    for ta in (False, True):
+        for tb in (False, True):
+            for bcast in (False, True):
+                A = torch.randn(2, 1 if bcast else 3, *((13, 70) if ta else (70, 13)))
+                B = torch.randn(1 if bcast else 2, 3, *((40, 13) if tb else (13, 40)))
+                R = torch.randn(2, 3, 70, 40)
+                W = torch.randn(2, 3, 70, 40)
+                def f(a, b, r, mm):
+                    return mm(a, b, r)
+                ref_in = [t.clone().requires_grad_() for t in (A, B, R)]
+                oa = ref_in[0].transpose(-1, -2) if ta else ref_in[0]
+                ob = ref_in[1].transpose(-1, -2) if tb else ref_in[1]
+                ref = -0.5 * (oa @ ob) + 3.0 * ref_in[2]
+                (ref * W).sum().backward()
+                dev_in = [t.clone().to(cuda).requires_grad_() for t in (A, B, R)]
+                got = Fh.matmul4(dev_in[0], dev_in[1], dev_in[2], ta=ta, tb=tb, alpha=-0.5, beta=3.0)
+                (got * W.to(cuda)).sum().backward()
+                _assert_close(f"C ta={ta} tb={tb} bc={bcast}", got, ref, 1e-5)
+                for n, g, r in zip("ABR", dev_in, ref_in):
+                    _assert_close(f"d{n} ta={ta} tb={tb} bc={bcast}", g.grad, r.grad, 1e-5)
+    # merged-heads output
+    A = torch.randn(2, 4, 50, 16); B = torch.randn(2, 4, 16, 8); R = torch.randn(2, 50, 32)
+    ref = (A @ B).permute(0, 2, 1, 3).reshape(2, 50, 32) + R
+    got = Fh.matmul4(A.to(cuda), B.to(cuda), R.to(cuda), merged=True)
+    _assert_close("merged", got, ref, 1e-5)
+
+
+def test_softmax_segment_mean_resconv(cuda):
+    torch.manual_seed(1)
+    for L in (16, 300, 5000):
+        x = torch.randn(7, L) * 3
+        w = torch.randn(7, L)
+        xr = x.clone().requires_grad_(); (torch.softmax(xr, -1) * w).sum().backward()
+        xd = x.clone().to(cuda).requires_grad_(); y = Fh.softmax_rows(xd); (y * w.to(cuda)).sum().backward()
+        _assert_close(f"softmax L={L}", y, torch.softmax(x, -1), 1e-5); _assert_close(f"dsoftmax L={L}", xd.grad, xr.grad, 1e-5)
+    x = torch.randn(2, 3, 40, 8); w = torch.randn(2, 3, 8, 8)
+    xr = x.clone().requires_grad_(); (xr.reshape(2, 3, 8, 5, 8).mean(3) * w).sum().backward()
+    xd = x.clone().to(cuda).requires_grad_(); y = Fh.segment_mean(xd, 5); (y * w.to(cuda)).sum().backward()
+    _assert_close("segment_mean", y, x.reshape(2, 3, 8, 5, 8).mean(3), 1e-5); _assert_close("dsegment_mean", xd.grad, xr.grad, 1e-5)
+    v = torch.randn(2, 4, 50, 8); k = torch.randn(4, 1, 33, 1); wo = torch.randn(2, 50, 32)
+    vr, kr = v.clone().requires_grad_(), k.clone().requires_grad_()
+    ref = torch.nn.functional.conv2d(vr, kr, padding=(16, 0), groups=4).permute(0, 2, 1, 3).reshape(2, 50, 32)
+    (ref * wo).sum().backward()
+    vd, kd = v.clone().to(cuda).requires_grad_(), k.clone().to(cuda).requires_grad_()
+    got = Fh.resconv(vd, kd); (got * wo.to(cuda)).sum().backward()
+    _assert_close("resconv", got, ref, 1e-5); _assert_close("dv", vd.grad, vr.grad, 1e-5); _assert_close("dw", kd.grad, kr.grad, 1e-5)
+
+
+@pytest.mark.parametrize("tag,B,n,dim,dh,m", [("nystrom_n37_m16", 2, 37, 64, 8, 16), ("nystrom_n64_m16", 2, 64, 64, 8, 16),
+                                               ("nystrom_n257_m256", 1, 257, 512, 64, 256)])
+def test_nystrom_golden(cuda, tag, B, n, dim, dh, m):
+    g = Golden(tag)
+    mod = smml.NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, pinv_iterations=6, residual=True, dropout=0.1)
+    mod = _load(mod, params_for(mod, 42, tag), cuda)
+    x = synth.normal((B, n, dim), 42, tag + ":x").to(cuda).requires_grad_()
+    w_out = synth.normal((B, n, dim), 42, tag + ":wout").to(cuda)
+    out = mod(x)
+    (out * w_out).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    for k, p in mod.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
+def test_pinv_translayer_ppeg_golden(cuda):
+    a2 = torch.softmax(synth.normal((2, 3, 16, 16), 42, "pinv:x"), dim=-1)
+    Golden("pinv_m16").check("z", smml.moore_penrose_iter_pinv(a2.to(cuda), 6))
+    dim = 64
+    g = Golden("translayer_d64")
+    tl = smml.TransLayer(dim=dim)
+    tl = _load(tl, params_for(tl, 42, "translayer"), cuda)
+    x = synth.normal((2, 37, dim), 42, "translayer:x").to(cuda).requires_grad_()
+    w = synth.normal((2, 37, dim), 42, "translayer:w").to(cuda)
+    out = tl(x); (out * w).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    for k, p in tl.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+    pp = smml.PPEG(dim=dim)
+    pp = _load(pp, params_for(pp, 42, "ppeg"), cuda)
+    Golden("ppeg_d64").check("out", pp(x.detach(), 6, 6))
+    # PPEG gradients vs the oracle
+    xp = synth.normal((2, 37, dim), 5, "ppeg:x"); wp = synth.normal((2, 37, dim), 5, "ppeg:w")
+    pr = {k: v.detach().cpu().clone().requires_grad_() for k, v in pp.state_dict().items()}
+    xr = xp.clone().requires_grad_(); (ppeg(xr, 6, 6, pr) * wp).sum().backward()
+    xd = xp.clone().to(cuda).requires_grad_(); pp.zero_grad(); (pp(xd, 6, 6) * wp.to(cuda)).sum().backward()
+    _assert_close("ppeg dx", xd.grad, xr.grad, 1e-5)
+    for k, p in pp.named_parameters():
+        _assert_close("ppeg d" + k, p.grad, pr[k].grad, 2e-5)
+
+
+def test_transmil_vs_oracle(cuda):
+    """Single-modality Nystrom MIL (BASELINE config 1 shape family): 60 instances x 1024 -> 8x8 wrap-padded grid + cls."""
+    args = argparse.Namespace(label_dim=4, path_dim=128, input_path_dim=1024)
+    net = smml.TransMIL(args)
+    params = params_for(net, 9, "transmil")
+    net = _load(net, params, cuda)
+    x = synth.bag(1, 60, 1024, 9, "transmil:bag")
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        enc, logits = trans_mil(x.to(dt), pref)
+        (enc.sum() + logits.pow(2).sum()).backward()
+        run[dt] = (enc, logits, pref)
+    enc, logits, _ = net(x.to(cuda))
+    (enc.sum() + logits.pow(2).sum()).backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    _calibrated("encoded", enc, r32[0], r64[0]); _calibrated("logits", logits, r32[1], r64[1])
+    for k, p in net.named_parameters():
+        if r32[2][k].grad is None:
+            continue
+        _calibrated("d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
+
+
+def test_nystrom_long_bag_self_consistency(cuda):
+    """n = 10 000 x 512, m = 256 (front padding to 10 240, l = 40): rows of a1 z a3 sum to ~1 is NOT guaranteed by
+    the approximation, but linearity in v is: out(v-weights scaled) relation via to_qkv's v block; and bag independence
+    does not hold (batch-global pinv max) - so check finite values, shape, and equality of two identical bags."""
+    torch.manual_seed(0)
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(cuda).eval()
+    x1 = torch.randn(1, 10000, 512, device=cuda) * 0.5
+    x = torch.cat((x1, x1), 0).requires_grad_()
+    out = mod(x)
+    assert out.shape == (2, 10000, 512) and torch.isfinite(out).all()
+    assert torch.equal(out[0], out[1])
+    out.pow(2).mean().backward()
+    assert torch.isfinite(x.grad).all() and float((x.grad[0] - x.grad[1]).abs().max()) <= 1e-6 * float(x.grad.abs().max())
