@@ -50,6 +50,9 @@ int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
                   long long sb0, long long sb1, long long sc0, long long sc1, long long sbias0,
                   long long sbias1, int bias_mode, int rows_per_bias, long long bias_ld, int act,
                   int splitk, int accumulate, float alpha, float beta, void* stream);
+/* test hook: 1 routes every product through the generic (any stride / any K) kernel instead of the tiled
+ * fast path (K % 16 == 0, 16-byte aligned operands with a unit stride on k or on the row index). */
+void smml_gemm_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.

@@ -127,7 +127,159 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path: 128 x BN x 16 tile, 2 x 2 waves (64 x BN/2 per wave), float4 global loads staged through
+// registers one K-tile ahead (issue early, write to LDS after the barrier), 16-byte LDS fragment reads when the
+// operand is k-contiguous.  v_mfma_f32_32x32x2_f32 shares the SIMD's fp32 ALUs with ordinary VALU work
+// (tests/microbench/mfma_probe.hip), so the inner loop is built for few vector / LDS instructions per MFMA:
+// per K-tile a wave issues 8 x (BN/32) MFMAs against <= 8 fragment reads.
+// Requirements (checked on the host): K % 16 == 0, 16-byte aligned operands with the unit stride on k or on
+// the row index and all other strides multiples of 4 elements.
+// ------------------------------------------------------------------------------------------------
+template <int BN_, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
+  constexpr int FBM = 128, FBK = 16, NI = BN_ / 64;          // NI 32-column blocks per wave
+  constexpr int A_LD = A_KC ? (FBK + 4) : (FBM + 4);
+  constexpr int B_LD = B_KC ? (FBK + 4) : (BN_ + 4);
+  __shared__ __attribute__((aligned(16))) float As[(A_KC ? FBM : FBK) * A_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[(B_KC ? BN_ : FBK) * B_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int zb = blockIdx.z / g.splitk, ks = blockIdx.z - zb * g.splitk;
+  const int b0 = zb / g.nb1, b1 = zb - b0 * g.nb1;
+  const float* A = g.A + b0 * g.sa0 + b1 * g.sa1;
+  const float* B = g.B + b0 * g.sb0 + b1 * g.sb1;
+  float* C = g.C + b0 * g.sc0 + b1 * g.sc1;
+  const int m0 = (g.swap_xy ? blockIdx.y : blockIdx.x) * FBM, n0 = (g.swap_xy ? blockIdx.x : blockIdx.y) * BN_;
+  const int ktiles = g.K / FBK;
+  const int tps = (ktiles + g.splitk - 1) / g.splitk;
+  const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
+
+  // staging maps (2 float4 of A, NI float4 of B per thread)
+  float4 ra[2], rb[NI];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * FBK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KC) {
+        const int row = (tid >> 2) + 64 * i, kq = tid & 3;
+        const long long gm = min(m0 + row, g.M - 1);
+        ra[i] = *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq);
+      } else {
+        const int k = (tid >> 5) + 8 * i, mq = tid & 31;
+        const int gm = m0 + 4 * mq;
+        const float* p = A + (long long)(k0 + k) * g.sak;
+        if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
+        else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (B_KC) {
+        const int row = (tid >> 2) + 64 * i, kq = tid & 3;
+        const long long gn = min(n0 + row, g.N - 1);
+        rb[i] = *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq);
+      } else {
+        constexpr int NQ = BN_ / 4;                            // float4 per k-row
+        const int idx = tid + 256 * i, k = idx / NQ, nq = idx - k * NQ;
+        const int gn = n0 + 4 * nq;
+        const float* p = B + (long long)(k0 + k) * g.sbk;
+        if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
+        else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KC) { const int row = (tid >> 2) + 64 * i, kq = tid & 3; *reinterpret_cast<float4*>(&As[row * A_LD + 4 * kq]) = ra[i]; }
+      else { const int k = (tid >> 5) + 8 * i, mq = tid & 31; *reinterpret_cast<float4*>(&As[k * A_LD + 4 * mq]) = ra[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (B_KC) { const int row = (tid >> 2) + 64 * i, kq = tid & 3; *reinterpret_cast<float4*>(&Bs[row * B_LD + 4 * kq]) = rb[i]; }
+      else { constexpr int NQ = BN_ / 4; const int idx = tid + 256 * i, k = idx / NQ, nq = idx - k * NQ;
+             *reinterpret_cast<float4*>(&Bs[k * B_LD + 4 * nq]) = rb[i]; }
+    }
+  };
+
+  floatx16 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = floatx16{0};
+
+  if (kt0 < kt1) load_tile(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    __syncthreads();                 // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt1) load_tile(kt + 1);   // in flight during the MFMAs below
+    float af[2][8], bf[NI][8];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int row = wm * 64 + mi * 32 + c;
+      if (A_KC) {
+        const float4 x = *reinterpret_cast<const float4*>(&As[row * A_LD + 8 * hf]);
+        const float4 y = *reinterpret_cast<const float4*>(&As[row * A_LD + 8 * hf + 4]);
+        af[mi][0] = x.x; af[mi][1] = x.y; af[mi][2] = x.z; af[mi][3] = x.w;
+        af[mi][4] = y.x; af[mi][5] = y.y; af[mi][6] = y.z; af[mi][7] = y.w;
+      } else {
+#pragma unroll
+        for (int st = 0; st < 8; ++st) af[mi][st] = As[(8 * hf + st) * A_LD + row];
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = wn * (BN_ / 2) + ni * 32 + c;
+      if (B_KC) {
+        const float4 x = *reinterpret_cast<const float4*>(&Bs[col * B_LD + 8 * hf]);
+        const float4 y = *reinterpret_cast<const float4*>(&Bs[col * B_LD + 8 * hf + 4]);
+        bf[ni][0] = x.x; bf[ni][1] = x.y; bf[ni][2] = x.z; bf[ni][3] = x.w;
+        bf[ni][4] = y.x; bf[ni][5] = y.y; bf[ni][6] = y.z; bf[ni][7] = y.w;
+      } else {
+#pragma unroll
+        for (int st = 0; st < 8; ++st) bf[ni][st] = Bs[(8 * hf + st) * B_LD + col];
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(af[mi][st], bf[ni][st], acc[mi][ni]);
+  }
+
+  const float* bias = g.bias ? g.bias + b0 * g.sbias0 + b1 * g.sbias1 : nullptr;
+  const float* res = g.residual ? g.residual + b0 * g.sc0 + b1 * g.sc1 : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (BN_ / 2) + ni * 32 + c;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + acc_row(r, hf);
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[mi][ni][r];
+        if (g.atomic) {
+          if (bias && ks == 0) v += (g.bias_mode == 2) ? bias[(m / g.rows_per_bias) * g.bias_ld + n] : bias[n];
+          atomicAdd(&C[m * g.ldc + n], v);
+        } else {
+          if (bias) v += (g.bias_mode == 2) ? bias[(m / g.rows_per_bias) * g.bias_ld + n] : bias[n];
+          v = apply_act(v, g.act);
+          if (res) v = fmaf(g.beta, res[m * g.ldr + n], v);
+          C[m * g.ldc + n] = v;
+        }
+      }
+    }
+}
+
 }  // namespace
+
+static int g_force_generic = 0;   // test hook: route everything through the generic kernel
+extern "C" void smml_gemm_force_generic(int on) { g_force_generic = on; }
 
 extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                              int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
@@ -152,6 +304,33 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
              sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1, bias_mode, rows_per_bias > 0 ? rows_per_bias : 1,
              bias_ld, act, splitk, alpha, beta, atomic, swap_xy};
   SMML_REQUIRE(!bias_mode || bias, "smml_gemm_f32: bias_mode set but bias is null");
+  // fast path: aligned operands with a unit stride on k or on the row index, K a multiple of 16
+  auto al4 = [](long long v) { return (v & 3) == 0; };
+  auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
+  const bool a_kc = (sak == 1), a_mc = (sam == 1 && sak != 1);
+  const bool b_kc = (sbk == 1 && sbn != 1), b_nc = (sbn == 1);
+  const bool a_ok = al16(A) && al4(sa0) && al4(sa1) && ((a_kc && al4(sam)) || (a_mc && al4(sak)));
+  const bool b_ok = al16(B) && al4(sb0) && al4(sb1) && ((b_kc && al4(sbn)) || (b_nc && al4(sbk)));
+  if (a_ok && b_ok && (K % 16) == 0 && !g_force_generic) {
+    const int bn = (N > 64) ? 128 : 64;
+    const long long fy = (N + bn - 1) / bn;
+    const int fswap = fy > 65535;
+    SMML_REQUIRE((fswap ? gx : fy) <= 65535, "smml_gemm_f32: grid too large");
+    g.swap_xy = fswap;
+    dim3 grid((unsigned)(fswap ? fy : gx), (unsigned)(fswap ? gx : fy), (unsigned)gz);
+    hipStream_t st = (hipStream_t)stream;
+#define SMML_FAST(BNV, AK, BK2) hipLaunchKernelGGL((gemm_f32_fast_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g)
+    if (bn == 128) {
+      if (a_kc && b_kc) SMML_FAST(128, true, true); else if (a_kc) SMML_FAST(128, true, false);
+      else if (b_kc) SMML_FAST(128, false, true); else SMML_FAST(128, false, false);
+    } else {
+      if (a_kc && b_kc) SMML_FAST(64, true, true); else if (a_kc) SMML_FAST(64, true, false);
+      else if (b_kc) SMML_FAST(64, false, true); else SMML_FAST(64, false, false);
+    }
+#undef SMML_FAST
+    SMML_LAUNCH_CHECK("smml_gemm_f32/fast");
+    return SMML_OK;
+  }
   dim3 grid((unsigned)(swap_xy ? gy : gx), (unsigned)(swap_xy ? gx : gy), (unsigned)gz);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
   SMML_LAUNCH_CHECK("smml_gemm_f32");

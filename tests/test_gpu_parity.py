@@ -82,6 +82,40 @@ def test_gemm_layouts_and_epilogues(cuda):
     _assert_close("batched", c, a @ b + rb.repeat_interleave(10, dim=2), 1e-5)
 
 
+def test_gemm_fast_path_matches_generic(cuda):
+    """Aligned shapes take the tiled fast kernel; all four operand layouts, ragged M / N edges, split-K, epilogues."""
+    torch.manual_seed(3)
+    L = smml.lib()
+    for (M, N, K) in [(300, 200, 64), (129, 65, 16), (1000, 64, 512), (77, 130, 32)]:
+        A = torch.randn(M, K); At = A.t().contiguous(); Bm = torch.randn(K, N); Bt = Bm.t().contiguous()
+        bias = torch.randn(N); res = torch.randn(M, N)
+        ref = torch.relu(0.5 * (A @ Bm) + bias) + 2.0 * res
+        for a_kc in (True, False):
+            for b_kc in (True, False):
+                if (not a_kc and M % 4) or (not b_kc and N % 4):
+                    continue                      # unaligned row strides fall back to the generic kernel anyway
+                C = torch.empty(M, N, device=cuda)
+                Ad = (A if a_kc else At).to(cuda); Bd = (Bt if b_kc else Bm).to(cuda)
+                Fh._gemm(Ad, Bd, C, M=M, N=N, K=K, sam=(K if a_kc else 1), sak=(1 if a_kc else M), sbk=(1 if b_kc else N),
+                         sbn=(K if b_kc else 1), ldc=N, bias=bias.to(cuda), bias_mode=1, residual=res.to(cuda), ldr=N, act=1,
+                         alpha=0.5, beta=2.0)
+                _assert_close(f"fast {M}x{N}x{K} a_kc={a_kc} b_kc={b_kc}", C, ref, 1e-5)
+        Cs = torch.zeros(M, N, device=cuda)
+        Fh._gemm(A.to(cuda), Bt.to(cuda), Cs, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, splitk=3 if K >= 48 else 1,
+                 accumulate=1)
+        _assert_close(f"fast splitk {M}x{N}x{K}", Cs, A @ Bm, 1e-5)
+    # same product through the generic kernel
+    A = torch.randn(200, 64, device=cuda); Bm = torch.randn(64, 96, device=cuda)
+    C1 = torch.empty(200, 96, device=cuda); C2 = torch.empty(200, 96, device=cuda)
+    Fh._gemm(A, Bm, C1, M=200, N=96, K=64, sam=64, sak=1, sbk=96, sbn=1, ldc=96)
+    L.smml_gemm_force_generic(1)
+    try:
+        Fh._gemm(A, Bm, C2, M=200, N=96, K=64, sam=64, sak=1, sbk=96, sbn=1, ldc=96)
+    finally:
+        L.smml_gemm_force_generic(0)
+    _assert_close("fast vs generic", C1, C2, 1e-6)
+
+
 def test_linear_layernorm_autograd(cuda):
     torch.manual_seed(1)
     x = torch.randn(3, 70, 96); w = torch.randn(50, 96) / 10; b = torch.randn(50); g = torch.randn(50); be = torch.randn(50)
