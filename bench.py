@@ -110,8 +110,7 @@ def main():
     torch.manual_seed(42)
     mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
-    mil = mil.to(dev).train()
-    mil.layer3.attn2d.dropout.p = 0.0      # attention dropout is not in the HIP path yet (eval-mode semantics)
+    mil = mil.to(dev).train()              # train mode: attention dropout 0.1 (DeformCrossTransMIL.py:49) is active
     model = pkg.BagDataParallel(mil) if world > 1 else mil
     opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True)
     bloss = pkg.BatchLoss(B, world)

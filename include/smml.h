@@ -121,8 +121,8 @@ int smml_deform_attn_nst(int N);
 int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
-                             int B, int N, int J, int H, int G, int posdim, float scale, void* ev_start,
-                             void* ev_stop, void* stream);
+                             int B, int N, int J, int H, int G, int posdim, float scale, float dropout_p,
+                             unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H);
 /* dlogits_t: scratch of logits_t's size (receives d scores); dq / dk / dv / dw* / db* overwritten;
  * dvs overwritten (zeroed inside). */
@@ -132,7 +132,13 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
                              float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
-                             int G, int posdim, float scale, void* ev_start, void* ev_stop, void* stream);
+                             int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
+                             void* ev_start, void* ev_stop, void* stream);
+/* attention dropout (nn.Dropout on the probabilities, DeformableAttention2D.py:309 / 1D :229): dropout_p in
+ * [0, 1) and a 64-bit seed select a counter-based keep decision per (b, h, query, key); pass the same pair to
+ * forward and backward.  The mask itself (0 / 1 floats [B, H, N, J]) is only materialised for tests: */
+int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p,
+                                      unsigned long long dropout_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Nystrom landmark self-attention, HBM-bound pieces (the contractions of models/NystromAttention.py:86,

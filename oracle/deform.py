@@ -96,8 +96,9 @@ def bilinear_gather(feats: torch.Tensor, vx: torch.Tensor, vy: torch.Tensor) -> 
     return out
 
 
-def _attend(q, k, v, bias_fn, heads, scale, q_chunk):
-    """softmax(scale*q k^T + bias) v, evaluated in query chunks.
+def _attend(q, k, v, bias_fn, heads, scale, q_chunk, attn_keep=None, keep_scale=1.0):
+    """dropout(softmax(scale*q k^T + bias)) v, evaluated in query chunks; `attn_keep` [B, h, n, J] is an explicit
+    0/1 keep mask (nn.Dropout semantics: kept probabilities are multiplied by keep_scale = 1 / (1 - p)).
     q [B, n, inner], k/v [B, J, inner]; bias_fn(i0, i1) -> [B, heads, i1-i0, J].
     DeformableAttention2D.py:284-312 / DeformableAttention1D.py:205-232 (dropout off)."""
     B, n, inner = q.shape
@@ -112,6 +113,8 @@ def _attend(q, k, v, bias_fn, heads, scale, q_chunk):
         sim = torch.einsum("bhid,bhjd->bhij", qh[:, :, i0:i1], kh) + bias_fn(i0, i1)
         sim = sim - sim.amax(dim=-1, keepdim=True).detach()
         attn = sim.softmax(dim=-1)
+        if attn_keep is not None:
+            attn = attn * (attn_keep[:, :, i0:i1].to(attn.dtype) * keep_scale)
         outs.append(torch.einsum("bhij,bhjd->bhid", attn, vh))
     out = torch.cat(outs, dim=2)                       # [B, h, n, d]
     return out.permute(0, 2, 1, 3).reshape(B, n, inner)  # b n (h d)
@@ -136,6 +139,8 @@ def deform_cross_attention_2d(
     group_key_values: bool = True,
     q_chunk: int = 512,
     return_aux: bool = False,
+    attn_keep: Optional[torch.Tensor] = None,
+    dropout_p: float = 0.0,
 ):
     """x1 (queries, fused stream) and x2 (keys/values, path stream): [B, C, N] channels-first as in
     the reference; returns (out [B, C, N], vgrid [(B g), 2, th, tw]) and optionally a dict of
@@ -191,7 +196,7 @@ def deform_cross_attention_2d(
         b = cpb_mlp(signed_log(pos), p)                                     # [(B g), i, J, o]
         return b.reshape(B, G, i1 - i0, J, o).permute(0, 1, 4, 2, 3).reshape(B, heads, i1 - i0, J)
 
-    attn_out = _attend(q, k, v, bias_fn, heads, scale, q_chunk)             # [B, N, inner]
+    attn_out = _attend(q, k, v, bias_fn, heads, scale, q_chunk, attn_keep, 1.0 / (1.0 - dropout_p))   # [B, N, inner]
     wo = p["to_out.weight"].reshape(C, inner)
     out = attn_out @ wo.t() + p["to_out.bias"]                              # :313
     out = out.transpose(1, 2)                                               # [B, C, N]

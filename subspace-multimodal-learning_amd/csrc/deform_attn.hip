@@ -52,6 +52,24 @@ constexpr int QT = 32;       // queries per wave
 constexpr int WAVES = 4;     // waves per workgroup
 constexpr int KT = 32;       // keys per tile
 
+// Attention dropout (nn.Dropout on the softmax'd probabilities, DeformableAttention2D.py:309): a counter-based
+// keep decision per (b, h, query, key) from a 64-bit seed - the same element gets the same decision in the
+// forward and in both backward passes, no mask is stored.  keep_scale = 1 / (1 - p); thresh = p * 2^32.
+struct DropCfg {
+  unsigned long long seed;
+  unsigned thresh;      // keep iff hash >= thresh; 0 disables dropout
+  float keep_scale;
+};
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = idx + seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ float drop_factor(const DropCfg& dc, unsigned long long idx) {
+  return (drop_hash(dc.seed, idx) >= dc.thresh) ? dc.keep_scale : 0.f;
+}
+
 struct CpbParams {
   const float* w1;  // [32, PD]
   const float* b1;  // [32]
@@ -68,7 +86,7 @@ template <int PD>
 __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
-    float* __restrict__ LSE, float* __restrict__ LT, int N, int J, int H, int G, int NST, float scale) {
+    float* __restrict__ LSE, float* __restrict__ LT, int N, int J, int H, int G, int NST, float scale, DropCfg dc) {
   __shared__ float Ks[DH][KT + 1];           // K tile, d-major (A operand of S^T)
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
@@ -202,8 +220,13 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = sexp(s[r] - m_new);
+      psum += p;                                  // the normaliser sums the un-dropped probabilities
       s[r] = p;
-      psum += p;
+    }
+    if (dc.thresh) {                              // dropped / rescaled probabilities feed P.V only
+      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= drop_factor(dc, base + acc_row(r, hf));
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
-    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST, float scale) {
+    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST, float scale, DropCfg dc) {
   __shared__ float Vt[DH][KT + 1];   // V tile d-major (A operand of dP^T = V . dO^T)
   __shared__ float Kr[KT][DH];       // K tile key-major (A operand of dQ^T = K^T . dS^T)
 
@@ -306,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       float v = 0.f;
       if (key < nk && qvalid) {
         const float p = expf(LTb[(size_t)(j0 + key) * NST + q0 + c] - lse);
-        v = p * (dp[r] - delta);
+        float dpr = dp[r];
+        if (dc.thresh) dpr *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qi) * J) + j0 + key);
+        v = p * (dpr - delta);
         dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
       }
       ds[r] = v;
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dK,
-    float* __restrict__ dV, int N, int J, int H, int NST, float scale) {
+    float* __restrict__ dV, int N, int J, int H, int NST, float scale, DropCfg dc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // per wave: Qs[32][64], dOs[32][64]; after the loop reused as reduce[4][2][64][33]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -382,7 +407,9 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
       for (int i = 0; i < 4; ++i) {
         const bool ok = kvalid && (qq + i) < N;
         const float lse = LSEb[min(qq + i, N - 1)];
-        p[4 * rg + i] = ok ? expf(lv[i] - lse) : 0.f;
+        float pv = ok ? expf(lv[i] - lse) : 0.f;
+        if (dc.thresh && ok) pv *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + (qq + i)) * J) + key);
+        p[4 * rg + i] = pv;                       // dV takes the dropped probabilities, dK the dS written by pass 1
         ds[4 * rg + i] = ok ? dv[i] : 0.f;
       }
     }
@@ -669,6 +696,20 @@ __global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o
   }
 }
 
+static DropCfg make_drop(float p, unsigned long long seed) {
+  DropCfg dc;
+  dc.seed = seed;
+  dc.thresh = (p > 0.f) ? (unsigned)((double)p * 4294967296.0) : 0u;
+  dc.keep_scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  return dc;
+}
+
+// keep-mask a launch with (dropout_p, dropout_seed) uses, as 0 / 1 floats [B, H, N, J] (tests only)
+__global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long total, DropCfg dc) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) mask[i] = (dc.thresh == 0 || drop_hash(dc.seed, i) >= dc.thresh) ? 1.f : 0.f;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -677,6 +718,17 @@ __global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o
 extern "C" {
 
 int smml_deform_attn_nst(int N) { return (N + 31) & ~31; }
+
+int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
+                                      void* stream) {
+  SMML_REQUIRE(mask && B > 0 && N > 0 && J > 0 && H > 0 && dropout_p >= 0.f && dropout_p < 1.f,
+               "smml_deform_attn_dropout_mask_f32: bad argument");
+  const unsigned long long total = (unsigned long long)B * H * N * J;
+  hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total,
+                     make_drop(dropout_p, dropout_seed));
+  SMML_LAUNCH_CHECK("smml_deform_attn_dropout_mask_f32");
+  return SMML_OK;
+}
 
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H) {
   const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
@@ -695,9 +747,11 @@ static int check_common(const char* fn, int B, int N, int J, int H, int G, int p
 int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
-                             int B, int N, int J, int H, int G, int posdim, float scale, void* ev_start,
-                             void* ev_stop, void* stream) {
+                             int B, int N, int J, int H, int G, int posdim, float scale, float dropout_p,
+                             unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
   int rc = check_common("smml_deform_attn_fwd_f32", B, N, J, H, G, posdim);
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_fwd_f32: dropout_p must be in [0, 1)");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
   if (rc) return rc;
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && lse,
                "smml_deform_attn_fwd_f32: null pointer");
@@ -708,10 +762,10 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   if (posdim == 2)
     hipLaunchKernelGGL(deform_attn_fwd_kernel<2>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
-                       N, J, H, G, nst, scale);
+                       N, J, H, G, nst, scale, dc);
   else
     hipLaunchKernelGGL(deform_attn_fwd_kernel<1>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
-                       N, J, H, G, nst, scale);
+                       N, J, H, G, nst, scale, dc);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   SMML_LAUNCH_CHECK("smml_deform_attn_fwd_f32");
   return SMML_OK;
@@ -723,8 +777,11 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
                              float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
-                             int G, int posdim, float scale, void* ev_start, void* ev_stop, void* stream) {
+                             int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
+                             void* ev_start, void* ev_stop, void* stream) {
   int rc = check_common("smml_deform_attn_bwd_f32", B, N, J, H, G, posdim);
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_bwd_f32: dropout_p must be in [0, 1)");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
   if (rc) return rc;
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits_t &&
                    dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
@@ -739,13 +796,13 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   dim3 block(256);
   // pass 1: dS^T, dQ
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
-                     dlogits_t, dq, N, J, H, nst, scale);
+                     dlogits_t, dq, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
   // pass 2: dK, dV
   {
     const size_t lds = (size_t)WAVES * 2 * DH * 33 * sizeof(float);   // >= WAVES * 2 * 32 * 64
     hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3((J + KT - 1) / KT, H, B), block, lds, st, q, dout, lse,
-                       logits_t, dlogits_t, dk, dv, N, J, H, nst, scale);
+                       logits_t, dlogits_t, dk, dv, N, J, H, nst, scale, dc);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dkv");
   }
   // pass 3: position-bias MLP backward

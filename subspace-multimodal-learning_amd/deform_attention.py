@@ -52,6 +52,17 @@ class CPB(nn.Module):
         return (m[0][0].weight, m[0][0].bias, m[1][0].weight, m[1][0].bias, m[2].weight, m[2].bias)
 
 
+def _dropout_args(mod):
+    """nn.Dropout semantics on the attention probabilities: active in train() with p > 0; the 64-bit seed of the
+    in-kernel counter-based mask is drawn from torch's default (CPU) generator, so torch.manual_seed reproduces it."""
+    p = float(mod.dropout.p)
+    if not mod.training or p <= 0.0:
+        return {"dropout_p": 0.0, "dropout_seed": 0}
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    mod.last_dropout_seed = seed
+    return {"dropout_p": p, "dropout_seed": seed}
+
+
 def _grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
     """Normalised query grid [N, 2] = (x, y) per token, restating create_grid_like + normalize_grid(dim=0)
     (DeformableAttention2D.py:88-108,296-297): x is divided by (rows - 1), y by (cols - 1)."""
@@ -104,9 +115,6 @@ class DeformCrossAttention2D(nn.Module):
 
     def forward_tokens(self, x1t, x2t, return_vgrid=False, residual=None):
         """Token-major entry: x1t (queries) / x2t (keys, values) [B, N, C] -> [B, N, C] (+ residual)."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention dropout is not implemented in the HIP path yet; call .eval() "
-                                      "or construct with dropout=0")
         B, N, C = x1t.shape
         Hh, Ww = self._grid(N)
         G, H = self.offset_groups, self.heads
@@ -119,7 +127,8 @@ class DeformCrossAttention2D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         gq = _grid_queries_2d(Hh, Ww, x1t.device)
-        o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale)
+        o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
+                                **_dropout_args(self))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 
@@ -169,9 +178,6 @@ class DeformCrossAttention1D(nn.Module):
         self.to_out = nn.Conv1d(inner_dim, dim, 1)
 
     def forward_tokens(self, x1t, x2t, return_vgrid=False, residual=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention dropout is not implemented in the HIP path yet; call .eval() "
-                                      "or construct with dropout=0")
         B, n, C = x1t.shape
         G, H = self.offset_groups, self.heads
         q = Fh.grouped_pointwise(x1t, self.to_q.weight, G if self.group_queries else 1)
@@ -185,7 +191,7 @@ class DeformCrossAttention1D(nn.Module):
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
-                                scale=self.scale)
+                                scale=self.scale, **_dropout_args(self))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 

@@ -332,7 +332,7 @@ def bilinear_corners(vs, Hh: int, Ww: int, posdim: int):
 # ------------------------------------------------------------------------------------------------
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale):
+    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed):
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
         B, N, HD = q.shape
@@ -352,17 +352,17 @@ class _DeformAttn(torch.autograd.Function):
         capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                               capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                               capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), B, N, J,
-                                              heads, groups, posdim, float(scale),
+                                              heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
                                               *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
                    "deform_attn_fwd")
-        ctx.cfg = (heads, groups, float(scale))
+        ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed))
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits = ctx.saved_tensors
-        heads, groups, scale = ctx.cfg
+        heads, groups, scale, dropout_p, dropout_seed = ctx.cfg
         B, N, _ = q.shape
         J = k.shape[1]
         posdim = vs.shape[-1]
@@ -379,14 +379,25 @@ class _DeformAttn(torch.autograd.Function):
             capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
             capi.fptr(logits), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
             capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
-            capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, *TIMER.events("cpb_bwd", B * heads * N * J),
+            capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
+            *TIMER.events("cpb_bwd", B * heads * N * J),
             capi.stream()), "deform_attn_bwd")
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None
 
 
-def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float):
-    """softmax(scale q k^T + CPB(gq - vs)) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P]."""
-    return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale)
+def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
+                     dropout_p: float = 0.0, dropout_seed: int = 0):
+    """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
+    dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed."""
+    return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed)
+
+
+def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device):
+    """The keep mask (0 / 1) [B, H, N, J] a launch with this (p, seed) applies; tests only."""
+    mask = torch.empty(B, H, N, J, device=device, dtype=torch.float32)
+    capi.check(capi.lib().smml_deform_attn_dropout_mask_f32(capi.fptr(mask), B, N, J, H, float(dropout_p), int(dropout_seed),
+                                                            capi.stream()), "dropout_mask")
+    return mask
 
 
 # ------------------------------------------------------------------------------------------------

@@ -173,6 +173,45 @@ def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     assert torch.equal(cm.cpu().bool(), torch.stack([c[3] for c in corners], -1).reshape(-1, 4))
 
 
+def test_deform2d_train_mode_dropout(cuda):
+    """train(): nn.Dropout(0.1) on the attention probabilities.  The kernels' counter-based mask for the drawn seed is
+    exported through the C-ABI and fed to the oracle as an explicit mask; forward and gradients must then agree."""
+    B, Hh, Ww, C = 2, 20, 20, 128
+    N = Hh * Ww
+    tag = "d2d:drop"
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww))
+    params = params_for(mod, 13, tag)
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).train()
+    x1 = synth.normal((B, C, N), 13, tag + ":x1"); x2 = synth.normal((B, C, N), 13, tag + ":x2")
+    w_out = synth.normal((B, C, N), 13, tag + ":wo")
+    torch.manual_seed(1234)
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    o, vg = mod(ad, bd, return_vgrid=True)
+    (o * w_out.to(cuda)).sum().backward()
+    J = vg.shape[-1] * vg.shape[-2]
+    keep = Fh.deform_attention_dropout_mask(B, N, J, 8, 0.1, mod.last_dropout_seed, cuda).cpu()
+    frac = float(keep.mean())
+    assert 0.88 < frac < 0.92, f"keep fraction {frac}"
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+        o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), attn_keep=keep, dropout_p=0.1)
+        (o_ref * w_out.to(dt)).sum().backward()
+        run[dt] = (o_ref, a.grad, b.grad, pref)
+    r32, r64 = run[torch.float32], run[torch.float64]
+    for name, got, i in (("out", o, 0), ("dx1", ad.grad, 1), ("dx2", bd.grad, 2)):
+        _calibrated(name, got, r32[i], r64[i])
+    _compare_param_grads(mod, r32[3], r64[3])
+    # a second forward draws a new seed (different mask), eval() switches dropout off
+    o2 = mod(ad.detach(), bd.detach())
+    assert not torch.equal(o2, o.detach())
+    mod.eval()
+    o3, o4 = mod(ad.detach(), bd.detach()), mod(ad.detach(), bd.detach())
+    assert torch.equal(o3, o4)
+
+
 def test_deform2d_golden_reference_grid(cuda):
     """N = 2500 (50 x 50), dim 128: against outputs of the reference itself."""
     g = Golden("deform2d_ref50")
