@@ -70,6 +70,11 @@ int smml_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, 
  * Pooler mean (DeformCrossTransMIL.py:193) and bias gradients. */
 int smml_colsum_f32(const float* x, float* out, int nb, long long R, int C, float scale, void* stream);
 
+/* OrthogonalLoss (models/cmta_utils.py:1212-1228) on rows P, P_hat, G, G_hat [B, D]: loss [B] (nullable) and, when
+ * dloss [B] is given, dP / dPh / dG / dGh [B, D]; one wave per sample, wavefront reductions. */
+int smml_orth_loss_f32(const float* P, const float* Ph, const float* G, const float* Gh, const float* dloss, float* loss,
+                       float* dP, float* dPh, float* dG, float* dGh, int B, int D, float gamma, void* stream);
+
 /* dx = dy * (y > 0)  (ReLU of _fc1, DeformCrossTransMIL.py:83) */
 int smml_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, void* stream);
 

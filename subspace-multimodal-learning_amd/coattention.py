@@ -1,0 +1,80 @@
+"""Host-side mirror of the reference's co-attention: models/MultiheadAttention.py:7-321 (functional form) and
+:333-489 (module) - a fork of torch.nn.MultiheadAttention whose forward returns the RAW pre-softmax scores
+(`need_raw`, :299,308-312).  Used by MCAT_Surv.coattn (models/model.py:587,626-628) and CMTA's P_in_G_Att /
+G_in_P_Att (models/model.py:748-750,809-818), always with embed_dim 256, one head, no masks.
+
+Same constructor, forward signature, return tuple and parameter names (in_proj_weight, in_proj_bias,
+out_proj.weight/bias).  In-projections, Q K^T, softmax, P V and the out-projection run on the HIP kernels.
+Not built (raise): key_padding_mask / attn_mask, add_bias_kv, add_zero_attn, kdim/vdim != embed_dim - no caller in
+the reference uses them.  The reference's `torch.equal(query, key)` host sync (:126,130) only selects between
+algebraically identical in-projection paths and is not reproduced."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import functional as Fh
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads, dropout=0., bias=True, add_bias_kv=False, add_zero_attn=False, kdim=None,
+                 vdim=None):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.kdim = kdim if kdim is not None else embed_dim
+        self.vdim = vdim if vdim is not None else embed_dim
+        self._qkv_same_embed_dim = self.kdim == embed_dim and self.vdim == embed_dim
+        if not self._qkv_same_embed_dim or add_bias_kv or add_zero_attn:
+            raise NotImplementedError("kdim/vdim != embed_dim, add_bias_kv and add_zero_attn are not built on the HIP path")
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == self.embed_dim, "embed_dim must be divisible by num_heads"
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        if bias:
+            self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        else:
+            self.register_parameter('in_proj_bias', None)
+        self.out_proj = nn.modules.linear.NonDynamicallyQuantizableLinear(embed_dim, embed_dim)
+        self.bias_k = self.bias_v = None
+        self.add_zero_attn = add_zero_attn
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        xavier_uniform_(self.in_proj_weight)
+        if self.in_proj_bias is not None:
+            constant_(self.in_proj_bias, 0.)
+            constant_(self.out_proj.bias, 0.)
+
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, need_raw=True, attn_mask=None):
+        """query [L, B, E], key / value [S, B, E] (sequence first) -> (out [L, B, E], raw scores [B, h, L, S])."""
+        if key_padding_mask is not None or attn_mask is not None:
+            raise NotImplementedError("masks are not built on the HIP path (no caller in the reference passes one)")
+        L, B, E = query.shape
+        S = key.shape[0]
+        h, hd = self.num_heads, self.head_dim
+        scaling = float(hd) ** -0.5
+        wq, wk, wv = self.in_proj_weight.chunk(3, dim=0)
+        bq = bk = bv = None
+        if self.in_proj_bias is not None:
+            bq, bk, bv = self.in_proj_bias.chunk(3, dim=0)
+
+        def heads_first(t, n):          # [B, n, E] -> [B, h, n, hd]
+            return t.reshape(B, 1, n, E) if h == 1 else t.reshape(B, n, h, hd).permute(0, 2, 1, 3)
+
+        q = heads_first(Fh.linear(query.transpose(0, 1), wq, bq), L)
+        k = heads_first(Fh.linear(key.transpose(0, 1), wk, bk), S)
+        v = heads_first(Fh.linear(value.transpose(0, 1), wv, bv), S)
+        raw = Fh.matmul4(q, k, tb=True, alpha=scaling)                 # (q * scaling) k^T, :284
+        attn = Fh.softmax_rows(raw)
+        if self.training and self.dropout > 0:
+            attn = F.dropout(attn, p=self.dropout, training=True)
+        o = Fh.matmul4(attn, v, merged=True)                           # [B, L, h*hd]
+        out = Fh.linear(o, self.out_proj.weight, self.out_proj.bias).transpose(0, 1)
+        if need_weights:
+            if need_raw:
+                return out, raw
+            return out, attn.sum(dim=1) / h
+        return out, None

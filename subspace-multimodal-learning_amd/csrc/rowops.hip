@@ -161,6 +161,43 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
   }
 }
 
+
+// OrthogonalLoss (models/cmta_utils.py:1217-1228): one wave per sample, five |cosine similarities| of the
+// rows P, P_hat, G, G_hat [B, D] by wavefront reductions:
+//   loss = (1 - |cos(sg P, Ph)|) + (1 - |cos(sg G, Gh)|) + gamma (|cos(P, G)| + |cos(sg P, Gh)| + |cos(sg G, Ph)|)
+// (sg = stop-gradient / .detach()).  Backward in the same kernel family: d cos(a,b)/da = b/(|a||b|) - cos a/|a|^2.
+__global__ __launch_bounds__(64) void orth_loss_kernel(const float* __restrict__ P, const float* __restrict__ Ph,
+                                                       const float* __restrict__ G, const float* __restrict__ Gh,
+                                                       const float* __restrict__ dloss, float* __restrict__ loss,
+                                                       float* __restrict__ dP, float* __restrict__ dPh, float* __restrict__ dG,
+                                                       float* __restrict__ dGh, int D, float gamma, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float *p = P + (long long)b * D, *ph = Ph + (long long)b * D, *g = G + (long long)b * D, *gh = Gh + (long long)b * D;
+  float pp = 0, hh = 0, gg = 0, kk = 0, p_ph = 0, g_gh = 0, p_g = 0, p_gh = 0, g_ph = 0;
+  for (int i = lane; i < D; i += 64) {
+    const float a = p[i], c = ph[i], e = g[i], f = gh[i];
+    pp = fmaf(a, a, pp); hh = fmaf(c, c, hh); gg = fmaf(e, e, gg); kk = fmaf(f, f, kk);
+    p_ph = fmaf(a, c, p_ph); g_gh = fmaf(e, f, g_gh); p_g = fmaf(a, e, p_g); p_gh = fmaf(a, f, p_gh); g_ph = fmaf(e, c, g_ph);
+  }
+  pp = wave_sum(pp); hh = wave_sum(hh); gg = wave_sum(gg); kk = wave_sum(kk);
+  p_ph = wave_sum(p_ph); g_gh = wave_sum(g_gh); p_g = wave_sum(p_g); p_gh = wave_sum(p_gh); g_ph = wave_sum(g_ph);
+  const float np = fmaxf(sqrtf(pp), eps), nh = fmaxf(sqrtf(hh), eps), ng = fmaxf(sqrtf(gg), eps), nk = fmaxf(sqrtf(kk), eps);
+  const float c1 = p_ph / (np * nh), c2 = g_gh / (ng * nk), c3 = p_g / (np * ng), c4 = p_gh / (np * nk), c5 = g_ph / (ng * nh);
+  if (loss && lane == 0) loss[b] = (1.f - fabsf(c1)) + (1.f - fabsf(c2)) + gamma * (fabsf(c3) + fabsf(c4) + fabsf(c5));
+  if (!dloss) return;
+  const float go = dloss[b];
+  const float s1 = -copysignf(1.f, c1) * go, s2 = -copysignf(1.f, c2) * go;                       // pos pairs
+  const float s3 = gamma * copysignf(1.f, c3) * go, s4 = gamma * copysignf(1.f, c4) * go, s5 = gamma * copysignf(1.f, c5) * go;
+  for (int i = lane; i < D; i += 64) {
+    const float a = p[i], c = ph[i], e = g[i], f = gh[i];
+    // d cos(x, y) / dy = x / (|x||y|) - cos * y / |y|^2
+    dPh[(long long)b * D + i] = s1 * (a / (np * nh) - c1 * c / (nh * nh)) + s5 * (e / (ng * nh) - c5 * c / (nh * nh));
+    dGh[(long long)b * D + i] = s2 * (e / (ng * nk) - c2 * f / (nk * nk)) + s4 * (a / (np * nk) - c4 * f / (nk * nk));
+    dP[(long long)b * D + i] = s3 * (e / (np * ng) - c3 * a / (np * np));                       // only cos(P, G) carries grad to P
+    dG[(long long)b * D + i] = s3 * (a / (np * ng) - c3 * e / (ng * ng));
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -198,6 +235,18 @@ int smml_colsum_f32(const float* x, float* out, int nb, long long R, int C, floa
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, R, C,
                      scale, rows_per_block);
   SMML_LAUNCH_CHECK("smml_colsum_f32");
+  return SMML_OK;
+}
+
+// loss [B] (nullable) and, when dloss [B] is given, the four gradients [B, D]
+int smml_orth_loss_f32(const float* P, const float* Ph, const float* G, const float* Gh, const float* dloss, float* loss,
+                       float* dP, float* dPh, float* dG, float* dGh, int B, int D, float gamma, void* stream) {
+  SMML_REQUIRE(P && Ph && G && Gh && B > 0 && D > 0, "smml_orth_loss_f32: bad argument");
+  SMML_REQUIRE(loss || dloss, "smml_orth_loss_f32: nothing to compute");
+  SMML_REQUIRE(!dloss || (dP && dPh && dG && dGh), "smml_orth_loss_f32: gradient outputs missing");
+  hipLaunchKernelGGL(orth_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P, Ph, G, Gh, dloss, loss, dP, dPh, dG,
+                     dGh, D, gamma, 1e-8f);
+  SMML_LAUNCH_CHECK("smml_orth_loss_f32");
   return SMML_OK;
 }
 

@@ -662,3 +662,30 @@ class _DwConv7(torch.autograd.Function):
 
 def dwconv7(x, wm, bias):
     return _DwConv7.apply(x, wm, bias)
+
+
+class _OrthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, Ph, G, Gh, gamma):
+        P, Ph, G, Gh = _c(P), _c(Ph), _c(G), _c(Gh)
+        B, D = P.shape
+        loss = torch.empty(B, device=P.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_orth_loss_f32(capi.fptr(P), capi.fptr(Ph), capi.fptr(G), capi.fptr(Gh), None, capi.fptr(loss),
+                                                 None, None, None, None, B, D, float(gamma), capi.stream()), "orth_loss")
+        ctx.gamma = float(gamma)
+        ctx.save_for_backward(P, Ph, G, Gh)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        P, Ph, G, Gh = ctx.saved_tensors
+        B, D = P.shape
+        dP, dPh, dG, dGh = (torch.empty_like(t) for t in (P, Ph, G, Gh))
+        capi.check(capi.lib().smml_orth_loss_f32(capi.fptr(P), capi.fptr(Ph), capi.fptr(G), capi.fptr(Gh), capi.fptr(_c(dloss)),
+                                                 None, capi.fptr(dP), capi.fptr(dPh), capi.fptr(dG), capi.fptr(dGh), B, D,
+                                                 ctx.gamma, capi.stream()), "orth_loss_bwd")
+        return dP, dPh, dG, dGh, None
+
+
+def orthogonal_loss(P, Ph, G, Gh, gamma: float = 0.5):
+    return _OrthLoss.apply(P, Ph, G, Gh, gamma)

@@ -61,14 +61,7 @@ class OrthogonalLoss(nn.Module):
         super().__init__()
         self.gamma = gamma
 
-    @staticmethod
-    def _abs_cos(a, b, eps: float = 1e-8):
-        # F.cosine_similarity(dim=1): x.y / (max(|x|, eps) * max(|y|, eps)) on [B, d] rows
-        num = (a * b).sum(dim=1)
-        return (num / (a.norm(dim=1).clamp_min(eps) * b.norm(dim=1).clamp_min(eps))).abs()
-
     def forward(self, P, P_hat, G, G_hat):
-        c = self._abs_cos
-        pos_pairs = (1 - c(P.detach(), P_hat)) + (1 - c(G.detach(), G_hat))
-        neg_pairs = c(P, G) + c(P.detach(), G_hat) + c(G.detach(), P_hat)
-        return pos_pairs + self.gamma * neg_pairs
+        """[B, d] x 4 -> [B]; the five cosine terms and their gradients are wavefront reductions in one kernel
+        (`.detach()` placements of the reference are built into its backward)."""
+        return Fh.orthogonal_loss(P, P_hat, G, G_hat, self.gamma)

@@ -6,8 +6,8 @@
   define_net        models/model.py:49-79     (mode 'deformpathomic' only)
 
 Same constructor arguments (an `args` namespace with the keys of config/config_mine.yaml), forward kwargs,
-return tuple and parameter names.  Only fusion_type == 'concat' (the shipped default, config_mine.yaml:17) is
-built here; 'pofusion' (BilinearFusion) raises."""
+return tuple and parameter names.  fusion_type 'concat' (the shipped default, config_mine.yaml:17) and 'pofusion'
+(BilinearFusion, fusion.py) are built."""
 from __future__ import annotations
 
 import math
@@ -18,6 +18,7 @@ from torch.nn import Parameter
 
 from . import functional as Fh
 from .deform_cross_trans_mil import DeformCrossTransMIL
+from .fusion import define_bifusion
 
 
 def init_max_weights(module):
@@ -69,8 +70,15 @@ class DeformPathomicNet(nn.Module):
         self.pathomic_net_immune = DeformCrossTransMIL(args)
         self.bilinear_dim = 20
         if args.fusion_type != "concat":
-            raise NotImplementedError("only fusion_type='concat' is built on the HIP path (BilinearFusion is not)")
-        self.classifier = nn.Linear(args.mmhid * 2, args.label_dim)
+            self.fusion = define_bifusion(fusion_type=args.fusion_type, skip=args.skip, use_bilinear=args.use_bilinear,
+                                          gate1=args.path_gate, gate2=args.omic_gate, dim1=args.path_dim, dim2=args.omic_dim,
+                                          scale_dim1=args.path_scale, scale_dim2=args.omic_scale, mmhid=args.mmhid,
+                                          dropout_rate=args.dropout_rate)
+            self.classifier = nn.Sequential(nn.Linear(args.mmhid, args.label_dim))
+        else:
+            self.classifier = nn.Linear(args.mmhid * 2, args.label_dim)
+        # The reference defines the two per-branch heads only in the 'concat' branch (model.py:463-469) while its
+        # forward reads them unconditionally (:522-523), i.e. 'pofusion' cannot run there; they are defined for both here.
         self.classifier_tumor = nn.Sequential(nn.Linear(args.mmhid, args.label_dim))
         self.classifier_immune = nn.Sequential(nn.Linear(args.mmhid, args.label_dim))
         self.return_grad = args.return_grad
@@ -87,11 +95,15 @@ class DeformPathomicNet(nn.Module):
         ri = self.pathomic_net_immune(path=x_path, omic=omic_vec_immune)
         pathomic_vec_tumor, pathomic_grads_tumor = rt[0], rt[2]
         pathomic_vec_immune, pathomic_grads_immune = ri[0], ri[2]
+        a, b = pathomic_vec_tumor, pathomic_vec_immune
         if self.cut_fuse_grad:
-            features = torch.cat((pathomic_vec_tumor.clone().detach(), pathomic_vec_immune.clone().detach()), 1)
+            a, b = a.clone().detach(), b.clone().detach()
+        if self.fusion_type == "concat":
+            features = torch.cat((a, b), 1)
+            hazard = Fh.linear(features, self.classifier.weight, self.classifier.bias)
         else:
-            features = torch.cat((pathomic_vec_tumor, pathomic_vec_immune), 1)
-        hazard = Fh.linear(features, self.classifier.weight, self.classifier.bias)
+            features = self.fusion(a, b)
+            hazard = Fh.linear(features, self.classifier[0].weight, self.classifier[0].bias)
         hazard_tumor = Fh.linear(pathomic_vec_tumor, self.classifier_tumor[0].weight, self.classifier_tumor[0].bias)
         hazard_immune = Fh.linear(pathomic_vec_immune, self.classifier_immune[0].weight, self.classifier_immune[0].bias)
         if self.return_grad == "True":

@@ -309,6 +309,54 @@ def case_losses(check):
         report("orthloss", orthogonal_loss(P.detach(), Ph.detach(), G.detach(), Gh.detach()), ol)
 
 
+def case_coattn_fusion(check):
+    from models.MultiheadAttention import MultiheadAttention
+    from oracle.coattn import bilinear_fusion, coattention
+    for tag, L, S, B in (("coattn_L4_S2500", 4, 2500, 2), ("coattn_L2500_S4", 2500, 4, 2), ("coattn_L200_S4096", 200, 4096, 1)):
+        mod = MultiheadAttention(embed_dim=256, num_heads=1).eval()
+        params = load_synth(mod, 42, tag)
+        q = synth.normal((L, B, 256), 42, tag + ":q").requires_grad_()
+        kv = synth.normal((S, B, 256), 42, tag + ":kv").requires_grad_()
+        w_o = synth.normal((L, B, 256), 42, tag + ":wo"); w_r = synth.normal((B, 1, L, S), 42, tag + ":wr")
+        out, raw = mod(q, kv, kv)
+        ((out * w_o).sum() + (raw * w_r).sum() * 1e-2).backward()
+        q64 = q.detach().double().requires_grad_(); kv64 = kv.detach().double().requires_grad_()
+        p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+        o64, r64 = coattention(q64, kv64, kv64, p64)
+        ((o64 * w_o.double()).sum() + (r64 * w_r.double()).sum() * 1e-2).backward()
+        payload = {"out": summarize(out, o64), "raw": summarize(raw, r64), "dq": summarize(q.grad, q64.grad),
+                   "dkv": summarize(kv.grad, kv64.grad)}
+        for k, g in grads_of(mod).items():
+            payload["grad:" + k] = summarize(g, p64[k].grad)
+        save(tag, payload)
+        if check:
+            report(tag + " out", o64.float(), out); report(tag + " raw", r64.float(), raw); report(tag + " dkv", kv64.grad.float(), kv.grad)
+    # BilinearFusion (eval mode: BatchNorm running stats, dropout off); forward builds torch.cuda.FloatTensor -> CPU patch
+    torch.cuda.FloatTensor = torch.FloatTensor
+    from models.fusion import BilinearFusion
+    for tag, skip in (("bifusion_skip0", 0), ("bifusion_skip1", 1)):
+        mod = BilinearFusion(skip=skip, use_bilinear=1, gate1=1, gate2=1, dim1=128, dim2=128, scale_dim1=1, scale_dim2=1,
+                             mmhid=128, dropout_rate=0.1).eval()
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        params = synth.fill_params({k: s for k, s in shapes.items() if "num_batches" not in k}, seed=42, tag=tag)
+        for k in list(params):
+            if k.endswith("running_var"):
+                params[k] = params[k].abs() + 0.5
+        sd = dict(mod.state_dict()); sd.update(params); mod.load_state_dict(sd)
+        v1 = synth.normal((4, 128), 42, tag + ":v1").requires_grad_(); v2 = synth.normal((4, 128), 42, tag + ":v2").requires_grad_()
+        w = synth.normal((4, 128), 42, tag + ":w")
+        out = mod(v1, v2); (out * w).sum().backward()
+        a64 = v1.detach().double().requires_grad_(); b64 = v2.detach().double().requires_grad_()
+        p64 = {k: (v.double().requires_grad_() if "running" not in k else v.double()) for k, v in params.items()}
+        o64 = bilinear_fusion(a64, b64, p64, skip=skip); (o64 * w.double()).sum().backward()
+        payload = {"out": summarize(out, o64), "dv1": summarize(v1.grad, a64.grad), "dv2": summarize(v2.grad, b64.grad)}
+        for k, g in grads_of(mod).items():
+            payload["grad:" + k] = summarize(g, p64[k].grad)
+        save(tag, payload)
+        if check:
+            report(tag + " out", o64.float(), out); report(tag + " dv1", a64.grad.float(), v1.grad)
+
+
 def rel_err(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -326,7 +374,8 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
     install_stubs()
     cases = {"deform2d": case_deform2d, "deform1d": case_deform1d, "nystrom": case_nystrom,
-             "translayer": case_translayer, "pathomic": case_pathomic, "losses": case_losses}
+             "translayer": case_translayer, "pathomic": case_pathomic, "losses": case_losses,
+             "coattn": case_coattn_fusion}
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -83,4 +83,4 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="GPU|HBM|CPU"):
         mod(torch.randn(1, 128, 144), torch.randn(1, 128, 144))
     with pytest.raises(NotImplementedError):
-        smml.DeformPathomicNet(pathomic_args(fusion_type="pofusion"))
+        smml.DeformPathomicNet(pathomic_args(fusion_type="nosuchfusion"))

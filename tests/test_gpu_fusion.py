@@ -1,0 +1,60 @@
+"""GPU parity of the co-attention (a10), BilinearFusion (a11) and OrthogonalLoss (a13) rows against golden vectors
+generated from the reference."""
+import pytest
+import torch
+
+from helpers import Golden, params_for, smml, synth
+from test_gpu_parity import _assert_close, _load
+from test_oracle_golden import bifusion_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,L,S,B", [("coattn_L4_S2500", 4, 2500, 2), ("coattn_L2500_S4", 2500, 4, 2), ("coattn_L200_S4096", 200, 4096, 1)])
+def test_coattention_golden(cuda, tag, L, S, B):
+    g = Golden(tag)
+    mod = smml.MultiheadAttention(embed_dim=256, num_heads=1)
+    mod = _load(mod, params_for(mod, 42, tag), cuda)
+    q = synth.normal((L, B, 256), 42, tag + ":q").to(cuda).requires_grad_()
+    kv = synth.normal((S, B, 256), 42, tag + ":kv").to(cuda).requires_grad_()
+    w_o = synth.normal((L, B, 256), 42, tag + ":wo").to(cuda); w_r = synth.normal((B, 1, L, S), 42, tag + ":wr").to(cuda)
+    out, raw = mod(q, kv, kv)
+    assert out.shape == (L, B, 256) and raw.shape == (B, 1, L, S)
+    ((out * w_o).sum() + (raw * w_r).sum() * 1e-2).backward()
+    g.check("out", out); g.check("raw", raw); g.check("dq", q.grad); g.check("dkv", kv.grad)
+    for k, p in mod.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
+def test_coattention_multi_head_vs_torch(cuda):
+    torch.manual_seed(0)
+    ref = torch.nn.MultiheadAttention(64, 4)
+    mod = smml.MultiheadAttention(64, 4)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(cuda).eval()
+    q, k = torch.randn(10, 3, 64), torch.randn(33, 3, 64)
+    o_ref, w_ref = ref(q, k, k, need_weights=True)
+    o, w = mod(q.to(cuda), k.to(cuda), k.to(cuda), need_raw=False)
+    _assert_close("mha out", o, o_ref, 1e-5); _assert_close("mha weights", w, w_ref, 1e-5)
+
+
+@pytest.mark.parametrize("tag,skip", [("bifusion_skip0", 0), ("bifusion_skip1", 1)])
+def test_bilinear_fusion_golden(cuda, tag, skip):
+    g = Golden(tag)
+    mod = smml.BilinearFusion(skip=skip, use_bilinear=1, gate1=1, gate2=1, dim1=128, dim2=128, mmhid=128, dropout_rate=0.1)
+    sd = dict(mod.state_dict()); sd.update(bifusion_params(mod, tag)); mod.load_state_dict(sd)
+    mod = mod.to(cuda).eval()
+    v1 = synth.normal((4, 128), 42, tag + ":v1").to(cuda).requires_grad_(); v2 = synth.normal((4, 128), 42, tag + ":v2").to(cuda).requires_grad_()
+    w = synth.normal((4, 128), 42, tag + ":w").to(cuda)
+    out = mod(v1, v2); (out * w).sum().backward()
+    g.check("out", out); g.check("dv1", v1.grad); g.check("dv2", v2.grad)
+    for k, p in mod.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
+def test_orthogonal_loss_golden(cuda):
+    g = Golden("orthloss_b4")
+    P, Ph, G, Gh = (synth.normal((4, 256), 42, "ol:" + t).to(cuda).requires_grad_() for t in "abcd")
+    ol = smml.OrthogonalLoss()(P, Ph, G, Gh)
+    ol.sum().backward()
+    g.check("out", ol); g.check("dP", P.grad); g.check("dPh", Ph.grad); g.check("dG", G.grad); g.check("dGh", Gh.grad)

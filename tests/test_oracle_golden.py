@@ -170,3 +170,40 @@ def test_full_model_reference_grid():
     # ill-conditioned gradients (position-bias MLP: ReLU-gated sums over 2.9e7 pairs) carry their own fp32
     # noise in the fixture; Golden.check widens the tolerance to 8 x that noise
     _check_grads(g, p)
+
+
+@pytest.mark.parametrize("tag,L,S,B", [("coattn_L4_S2500", 4, 2500, 2), ("coattn_L2500_S4", 2500, 4, 2), ("coattn_L200_S4096", 200, 4096, 1)])
+def test_coattention(tag, L, S, B):
+    from oracle.coattn import coattention
+    g = Golden(tag)
+    p = _req(params_for(smml.MultiheadAttention(256, 1), 42, tag))
+    q = synth.normal((L, B, 256), 42, tag + ":q").requires_grad_()
+    kv = synth.normal((S, B, 256), 42, tag + ":kv").requires_grad_()
+    w_o = synth.normal((L, B, 256), 42, tag + ":wo"); w_r = synth.normal((B, 1, L, S), 42, tag + ":wr")
+    out, raw = coattention(q, kv, kv, p)
+    ((out * w_o).sum() + (raw * w_r).sum() * 1e-2).backward()
+    g.check("out", out); g.check("raw", raw); g.check("dq", q.grad); g.check("dkv", kv.grad)
+    _check_grads(g, p)
+
+
+def bifusion_params(mod, tag):
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if "num_batches" not in k}
+    params = synth.fill_params(shapes, seed=42, tag=tag)
+    for k in list(params):
+        if k.endswith("running_var"):
+            params[k] = params[k].abs() + 0.5
+    return params
+
+
+@pytest.mark.parametrize("tag,skip", [("bifusion_skip0", 0), ("bifusion_skip1", 1)])
+def test_bilinear_fusion(tag, skip):
+    from oracle.coattn import bilinear_fusion
+    g = Golden(tag)
+    mod = smml.BilinearFusion(skip=skip, use_bilinear=1, gate1=1, gate2=1, dim1=128, dim2=128, mmhid=128, dropout_rate=0.1)
+    params = bifusion_params(mod, tag)
+    p = {k: (v.clone().requires_grad_() if "running" not in k else v) for k, v in params.items()}
+    v1 = synth.normal((4, 128), 42, tag + ":v1").requires_grad_(); v2 = synth.normal((4, 128), 42, tag + ":v2").requires_grad_()
+    w = synth.normal((4, 128), 42, tag + ":w")
+    out = bilinear_fusion(v1, v2, p, skip=skip); (out * w).sum().backward()
+    g.check("out", out); g.check("dv1", v1.grad); g.check("dv2", v2.grad)
+    _check_grads(g, p)
