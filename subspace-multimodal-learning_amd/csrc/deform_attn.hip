@@ -30,6 +30,17 @@
 #ifndef SMML_BWD_WPS
 #define SMML_BWD_WPS 2      // same for the position-bias backward kernel
 #endif
+#ifndef SMML_CPB_F16
+#define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
+                            //    (W = Wh + Wl, h1 = hh + hl; Wh hh + Wh hl + Wl hh, ~22 mantissa bits) that overlaps the
+                            //    VALU; 0: exact fp32 v_mfma_f32_32x32x2_f32 (shares the fp32 ALUs with the VALU)
+#endif
+#ifndef SMML_CPB_BWD_F16
+#define SMML_CPB_BWD_F16 0  // same for the position-bias backward kernel.  Off: measured slower on MI355X (17.6 vs 15.4 ms at
+                            // B = 4, N = 10 000: operand splits + 64 ds_write_b16 per chain cost more VALU / LDS issue than the
+                            // 48 f32 MFMAs they replace) and, with one launch-wide power-of-two gradient scale, fp16's
+                            // exponent range loses the small d bias values (dW2 off by 4e-4); kept for further tuning
+#endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 0    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
 #endif
@@ -51,6 +62,24 @@ constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
 constexpr int QT = 32;       // queries per wave
 constexpr int WAVES = 4;     // waves per workgroup
 constexpr int KT = 32;       // keys per tile
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+// v_mfma_f32_32x32x16_f16: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j], B[k = 8h + j][col r], j = 0..7;
+// C/D layout as for the f32 form.  32 cycles per instruction on the matrix pipe, concurrent with VALU work.
+__device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// split 8 fp32 values into fp16 hi (round toward zero) + fp16 lo (x - hi): hi + lo carries ~22 mantissa bits
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]));
+    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]));
+    hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+    lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
+  }
+}
 
 // Attention dropout (nn.Dropout on the softmax'd probabilities, DeformableAttention2D.py:309): a counter-based
 // keep decision per (b, h, query, key) from a 64-bit seed - the same element gets the same decision in the
@@ -136,6 +165,17 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     tabB[tid] = t;
   }
   const float4* tb = tabB + 16 * hf;
+#if SMML_CPB_F16
+  // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = 16 kb + 8 hf + j
+  half8 w2h[2], w2l[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + 16 * kb + 8 * hf + j];
+    split8(wv, w2h[kb], w2l[kb]);
+  }
+#endif
   const float b3 = cp.b3[oi];
 
   floatx16 oacc0 = {0}, oacc1 = {0};
@@ -182,6 +222,25 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       const float p0 = slog1p(gq0 - vsl[jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
+#if SMML_CPB_F16
+      // layer 1 for this lane's 16 channels (two K-blocks of 8), split into fp16 hi / lo, three MFMAs per block
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 t = tabB[16 * kb + 8 * hf + j];
+          float x = fmaf(t.x, p0, t.z);
+          if (PD == 2) x = fmaf(t.y, p1, x);
+          hv[j] = fmaxf(x, 0.f);
+        }
+        half8 bh, bl;
+        split8(hv, bh, bl);
+        d = mfma16(w2h[kb], bh, d);
+        d = mfma16(w2h[kb], bl, d);
+        d = mfma16(w2l[kb], bh, d);
+      }
+#else
 #pragma unroll
       for (int sp = 0; sp < 16; ++sp) {
         const float4 t = tb[sp];
@@ -189,6 +248,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
         if (PD == 2) hv = fmaf(t.y, p1, hv);
         d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
       }
+#endif
       float t3 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t3 = fmaf(fmaxf(d[r], 0.f), w3v[r], t3);
@@ -266,7 +326,8 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
-    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST, float scale, DropCfg dc) {
+    float* __restrict__ dLT, float* __restrict__ dQ, unsigned* __restrict__ gmax, int N, int J, int H, int NST,
+    float scale, DropCfg dc) {
   __shared__ float Vt[DH][KT + 1];   // V tile d-major (A operand of dP^T = V . dO^T)
   __shared__ float Kr[KT][DH];       // K tile key-major (A operand of dQ^T = K^T . dS^T)
 
@@ -294,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const float lse = LSE[(size_t)(b * H + h) * N + qi];
 
   floatx16 dq0 = {0}, dq1 = {0};
+  float amax = 0.f;                                  // max |dS| of this lane (feeds the fp16 gradient scale)
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
@@ -332,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         float dpr = dp[r];
         if (dc.thresh) dpr *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qi) * J) + j0 + key);
         v = p * (dpr - delta);
+        amax = fmaxf(amax, fabsf(v));
         dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
       }
       ds[r] = v;
@@ -343,6 +406,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       dq0 = mfma32(Kr[key][c], ds[r], dq0);
       dq1 = mfma32(Kr[key][32 + c], ds[r], dq1);
     }
+  }
+  if (gmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && amax > 0.f) atomicMax(gmax, __float_as_uint(amax));   // non-negative floats order as uints
   }
   if (qvalid) {
     float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
@@ -656,6 +724,238 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   }
 }
 
+
+// power-of-two S with gmax * S in [2^9, 2^10): fp16 headroom for |w3| up to 64, full precision down to 2^-24 gmax
+__device__ __forceinline__ float grad_scale_from_max(unsigned gbits) {
+  const float gm = __uint_as_float(gbits);
+  if (!(gm > 0.f) || gm > 3.0e38f) return 1.f;
+  int e;
+  (void)frexpf(gm, &e);
+  return ldexpf(1.f, 10 - e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Position-bias backward with the three 32x32 contractions on the 16-bit matrix pipe (v_mfma_f32_32x32x16_f16)
+// as split-fp16 products (x = hi + lo, three MFMAs per K-block: hi hi + hi lo + lo hi, ~22 mantissa bits).  The
+// matrix pipe then runs beside the VALU instead of sharing the fp32 ALUs with it.  The incoming gradients d bias
+// are multiplied by one power of two S (from the launch-wide max |dS| that pass 1 records) so that they sit in
+// fp16's normal range; every accumulator carries S and is divided by it once when it leaves the kernel.
+// Channel <-> operand slot: K-block kb, element j of a lane in half hf <-> channel acc_row(8 kb + j, hf), i.e. the
+// 16 channels a lane feeds into chain 1 are the 16 accumulator rows it receives from chain 2 - one set of layer-1
+// constants, and the ReLU masks come from registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int HLD = 40;          // LDS row stride (halfs) of the [32][32] fp16 operand tiles: 80 B rows, conflict-free b128 reads
+template <int PD>
+__global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_f16_kernel(
+    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
+    float* __restrict__ slab, float* __restrict__ dVS, const unsigned* __restrict__ gmax, int N, int J, int H, int G,
+    int NST) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // layout: tab[32] float4 {w1x, w1y, b1, b2} | w3tab[32] | dvs[2 J] | per wave 4 x [32][HLD] halfs | red[CPB_SLAB]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  float4* tab = reinterpret_cast<float4*>(smem);
+  float* w3tab = smem + 128;
+  float* dvs = smem + 160;
+  float* wbase = dvs + ((2 * J + 3) & ~3);
+  _Float16* tiles = reinterpret_cast<_Float16*>(wbase) + wave * (4 * 32 * HLD);
+  _Float16* Ah = tiles;                 // dD  hi  [out][query]
+  _Float16* Al = tiles + 32 * HLD;      // dD  lo
+  _Float16* Bh = tiles + 2 * 32 * HLD;  // h1  hi  [in][query]
+  _Float16* Bl = tiles + 3 * 32 * HLD;  // h1  lo
+  float* red = wbase + WAVES * (4 * 32 * HLD) / 2;
+  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
+  if (tid < 32) {
+    float4 t;
+    t.x = cp.w1[tid * PD];
+    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
+    t.z = cp.b1[tid];
+    t.w = cp.b2[tid];
+    tab[tid] = t;
+    w3tab[tid] = cp.w3[oi * CH + tid];
+  }
+  const float S = grad_scale_from_max(*gmax);
+  const float invS = 1.f / S;
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // W2 as A operand of chain 1 (rows = out = c, k = in) and of chain 2 (rows = in = c, k = out), split in hi / lo
+  half8 w2h[2], w2l[2], w2th[2], w2tl[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float a[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = acc_row(8 * kb + j, hf);
+      a[j] = cp.w2[c * CH + ch];
+      t[j] = cp.w2[ch * CH + c];
+    }
+    split8(a, w2h[kb], w2l[kb]);
+    split8(t, w2th[kb], w2tl[kb]);
+  }
+
+  floatx16 e = {0};
+  float aw3[16], ab2[16], aw1x[16], aw1y[16], ab1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aw3[r] = 0.f; ab2[r] = 0.f; aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
+  float ab3 = 0.f;
+
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+  __syncthreads();
+
+  float vx_n = VSb[0];
+  float vy_n = (PD == 2) ? VSb[1] : 0.f;
+  float db_n = qvalid ? dLTb[q0 + c] : 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float vx = vx_n, vy = vy_n, dbs = db_n * S;
+    if (j + 1 < J) {
+      vx_n = VSb[(size_t)(j + 1) * PD];
+      if (PD == 2) vy_n = VSb[(size_t)(j + 1) * PD + 1];
+      db_n = qvalid ? dLTb[(size_t)(j + 1) * NST + q0 + c] : 0.f;
+    }
+    const float d0 = gq0 - vx, d1 = gq1 - vy;
+    const float p0 = slog1p(d0);
+    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
+
+    // phase 1: h1 for this lane's 16 channels, split, parked in LDS for chain 3, chain 1: D = W2 h1
+    float hv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 t = tab[acc_row(r, hf)];
+      float x = fmaf(t.x, p0, t.z);
+      if (PD == 2) x = fmaf(t.y, p1, x);
+      hv[r] = fmaxf(x, 0.f);
+    }
+    floatx16 d = {0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float x8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
+      half8 bh, bl;
+      split8(x8, bh, bl);
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+        Bh[acc_row(8 * kb + jx, hf) * HLD + c] = bh[jx];
+        Bl[acc_row(8 * kb + jx, hf) * HLD + c] = bl[jx];
+      }
+      d = mfma16(w2h[kb], bh, d);
+      d = mfma16(w2h[kb], bl, d);
+      d = mfma16(w2l[kb], bh, d);
+    }
+    // phase 2: layer-3 backward (scaled by S), chain 2: dh1 = W2^T dD
+    floatx16 dh = {0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float g8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+        const int r = 8 * kb + jx, ch = acc_row(r, hf);
+        const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
+        aw3[r] = fmaf(dbs, h2, aw3[r]);
+        const float g2 = (h2 > 0.f) ? dbs * w3tab[ch] : 0.f;
+        ab2[r] += g2;
+        g8[jx] = g2;
+      }
+      half8 gh, gl;
+      split8(g8, gh, gl);
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+        Ah[acc_row(8 * kb + jx, hf) * HLD + c] = gh[jx];
+        Al[acc_row(8 * kb + jx, hf) * HLD + c] = gl[jx];
+      }
+      dh = mfma16(w2th[kb], gh, dh);
+      dh = mfma16(w2th[kb], gl, dh);
+      dh = mfma16(w2tl[kb], gh, dh);
+    }
+    ab3 += (hf == 0) ? dbs : 0.f;
+    asm volatile("" ::: "memory");
+    // phase 3: dW2[out, in] += sum_query dD[out, query] h1[in, query]  (both operands from the LDS tiles)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int off = c * HLD + 16 * kb + 8 * hf;
+      const half8 ah = *reinterpret_cast<const half8*>(Ah + off), al = *reinterpret_cast<const half8*>(Al + off);
+      const half8 bh = *reinterpret_cast<const half8*>(Bh + off), bl = *reinterpret_cast<const half8*>(Bl + off);
+      e = mfma16(ah, bh, e);
+      e = mfma16(ah, bl, e);
+      e = mfma16(al, bh, e);
+    }
+    // layer-1 backward on the accumulator rows of dh1 (= the channels of hv)
+    float dp0 = 0.f, dp1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 t = tab[acc_row(r, hf)];
+      const float g1 = (hv[r] > 0.f) ? dh[r] : 0.f;
+      ab1[r] += g1;
+      aw1x[r] = fmaf(g1, p0, aw1x[r]);
+      dp0 = fmaf(g1, t.x, dp0);
+      if (PD == 2) {
+        aw1y[r] = fmaf(g1, p1, aw1y[r]);
+        dp1 = fmaf(g1, t.y, dp1);
+      }
+    }
+    {
+      float t0 = wave_sum(-dp0 * srcp(fabsf(d0) + 1.f));
+      if (lane == 0) atomicAdd(&dvs[2 * j], t0);
+      if (PD == 2) {
+        float t1 = wave_sum(-dp1 * srcp(fabsf(d1) + 1.f));
+        if (lane == 0) atomicAdd(&dvs[2 * j + 1], t1);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- workgroup reduction of the per-lane partials -> slab[wg] (un-scaled by 1 / S) ----
+  __syncthreads();
+  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hf);
+    atomicAdd(&red[row * CH + c], e[r]);
+    float v;
+    v = aw3[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
+    v = ab2[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + row], v);
+    v = ab1[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
+    v = aw1x[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
+    v = aw1y[r];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
+  }
+  {
+    float v = wave_sum(ab3);
+    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
+  }
+  __syncthreads();
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* sl = slab + (size_t)wg * CPB_SLAB;
+  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i] * invS;
+  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
+  for (int i = tid; i < J * PD; i += 256) {
+    const int jj = i / PD, comp = i - jj * PD;
+    atomicAdd(&dVSb[i], dvs[2 * jj + comp] * invS);
+  }
+}
+
 // sums the per-workgroup slabs: out[k] = sum_wg slab[wg][k]; one block per 64 outputs
 __global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o, float* __restrict__ dW1,
                                   float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
@@ -732,7 +1032,7 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
 
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H) {
   const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
-  return nwg * CPB_SLAB * sizeof(float);
+  return nwg * CPB_SLAB * sizeof(float) + 256;       // + one cache line for the launch-wide max |dS|
 }
 
 static int check_common(const char* fn, int B, int N, int J, int H, int G, int posdim) {
@@ -794,9 +1094,12 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   const int nst = smml_deform_attn_nst(N);
   const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
   dim3 block(256);
-  // pass 1: dS^T, dQ
+  // pass 1: dS^T, dQ (+ the launch-wide max |dS| for the fp16 gradient scale)
+  unsigned* gmax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) +
+                                               (size_t)qtiles * H * B * CPB_SLAB * sizeof(float));
+  if (hipMemsetAsync(gmax, 0, 256, st) != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
-                     dlogits_t, dq, N, J, H, nst, scale, dc);
+                     dlogits_t, dq, gmax, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
   // pass 2: dK, dV
   {
@@ -809,9 +1112,20 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   {
     hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
     if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
+    float* slab = (float*)workspace;
+#if SMML_CPB_BWD_F16
+    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * (4 * 32 * HLD) / 2 + CPB_SLAB) * sizeof(float);
+    SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
+    if (posdim == 2)
+      hipLaunchKernelGGL(cpb_bwd_f16_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
+                         gmax, N, J, H, G, nst);
+    else
+      hipLaunchKernelGGL(cpb_bwd_f16_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
+                         gmax, N, J, H, G, nst);
+#else
     const size_t lds = ((size_t)288 + ((2 * J + 3) & ~3) + WAVES * (32 * 33 + 64) + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
-    float* slab = (float*)workspace;
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
       hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
@@ -819,6 +1133,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
                          J, H, G, nst);
+#endif
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;

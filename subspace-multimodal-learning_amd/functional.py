@@ -431,8 +431,13 @@ class _TileTokens(torch.autograd.Function):
 
 
 def tile_tokens(v, n: int):
-    """v [B, C] -> [B, n, C] (values of v.unsqueeze(1).repeat(1, n, 1)); backward is a column sum."""
-    return _TileTokens.apply(v, n)
+    """v [B, C] -> [B, n, C] (values of v.unsqueeze(1).repeat(1, n, 1)); backward is a column sum.
+    The result carries the un-tiled vector as `_smml_compact`: BatchLoss uses it to gather [B, C] instead of the
+    n-times larger tile across ranks (the Gram of a tile is n x the Gram of the vector, and the row normalisation
+    that follows cancels the factor)."""
+    out = _TileTokens.apply(v, n)
+    out._smml_compact = v
+    return out
 
 
 class _Gram(torch.autograd.Function):

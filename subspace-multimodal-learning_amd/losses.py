@@ -39,13 +39,22 @@ def _row_normalised_gram(x3: torch.Tensor) -> torch.Tensor:
 
 
 class BatchLoss(nn.Module):
-    def __init__(self, batch_size, world_size):
+    """Same constructor / forward as utils/loss.py:7-40.  `use_tile_hint` (additive, default on): when `omic` is the
+    token tile produced by DeformCrossTransMIL (it then carries the un-tiled [B, C] vector), the exchange and the Gram
+    run on the vector - 20 MB/rank of all-gather at B = 4, N = 10 000 shrink to 2 KB, values equal up to rounding
+    (SURVEY.md C4).  Any other tensor takes the reference's full path (gather the tile, Gram over N*C columns)."""
+
+    def __init__(self, batch_size, world_size, use_tile_hint=True):
         super().__init__()
         self.batch_size = batch_size
         self.world_size = world_size
+        self.use_tile_hint = use_tile_hint
 
     def forward(self, omic, vgrid):
         N = self.batch_size * self.world_size
+        compact = getattr(omic, "_smml_compact", None) if self.use_tile_hint else None
+        if compact is not None and compact.dim() == 2 and compact.shape[0] == omic.shape[0]:
+            omic = compact
         if self.world_size > 1:
             omic = torch.cat(GatherLayer.apply(omic), dim=0)
             vgrid = torch.cat(GatherLayer.apply(vgrid), dim=0)

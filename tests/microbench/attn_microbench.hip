@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
   for (int it = 0; it < reps + 1; ++it) {
     hipEventRecord(e0, 0);
     int rc = smml_deform_attn_fwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, lt, B, N, J, H, G, PD, scale,
-                                      nullptr, nullptr, nullptr);
+                                      0.f, 0ull, nullptr, nullptr, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("fwd error: %s\n", smml_last_error()); return 1; }
     hipEventSynchronize(e1);
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     if (it > 0) fwd_ms += ms;
     hipEventRecord(e0, 0);
     rc = smml_deform_attn_bwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, dout, lse, lt, dlt, dq, dk, dv, dvs, dw1,
-                                  db1, dw2, db2, dw3, db3, ws, wsb, B, N, J, H, G, PD, scale, c0, c1, nullptr);
+                                  db1, dw2, db2, dw3, db3, ws, wsb, B, N, J, H, G, PD, scale, 0.f, 0ull, c0, c1, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("bwd error: %s\n", smml_last_error()); return 1; }
     hipEventSynchronize(e1);

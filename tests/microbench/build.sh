@@ -1,16 +1,14 @@
 #!/bin/bash
-# builds one microbench binary per variant into gpurun-visible tests/microbench/bin/ (git-ignored via *.o? no: listed in .gitignore)
+# builds one microbench binary per variant into tests/microbench/bin/ (git-ignored, travels with gpurun)
 set -e
 cd "$(dirname "$0")"
-mkdir -p bin
+mkdir -p bin && rm -f bin/mb_*
 build() { # name, flags...
   local name=$1; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
-build wps2_acc
-build wps2_fast -DSMML_FAST_MATH=1
-build wps2_nodpp -DSMML_DPP_REDUCE=0
-build wps1_acc -DSMML_FWD_WPS=1 -DSMML_BWD_WPS=1
-build wps1_fast -DSMML_FWD_WPS=1 -DSMML_BWD_WPS=1 -DSMML_FAST_MATH=1
+build f16_bwps2
+build f16_bwps1 -DSMML_BWD_WPS=1
+build f32_ref -DSMML_CPB_F16=0
 wait
-ls -la bin
+ls bin

@@ -267,6 +267,16 @@ def test_batch_loss_vs_oracle(cuda):
     out = smml.BatchLoss(B, 1)(omic, vgrid)
     out.sum().backward()
     g.check("out", out); g.check("domic", omic.grad); g.check("dvgrid", vgrid.grad)
+    # tile hint: a tile made by tile_tokens is reduced to its vector before the Gram - same loss, same gradient
+    vec = synth.normal((B, 16), 3, "bl:vec")
+    vg = synth.normal((B * 8, 2, 3, 3), 3, "bl:vg2").to(cuda)
+    res = []
+    for hint in (True, False):
+        v = vec.clone().to(cuda).requires_grad_()
+        l = smml.BatchLoss(B, 1, use_tile_hint=hint)(Fh.tile_tokens(v, 50), vg).sum()
+        l.backward()
+        res.append((l.detach(), v.grad))
+    _assert_close("tile hint loss", res[0][0], res[1][0], 1e-5); _assert_close("tile hint grad", res[0][1], res[1][1], 1e-4)
     # long contraction (K = N*C as in the model) against the oracle
     o2 = synth.normal((8, 3000, 128), 1, "bl2:omic"); v2 = synth.normal((64, 2, 12, 12), 1, "bl2:vg")
     ref = batch_loss(o2, v2, 8)
