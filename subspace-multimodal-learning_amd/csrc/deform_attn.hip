@@ -70,15 +70,38 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-// split 8 fp32 values into fp16 hi (round toward zero) + fp16 lo (x - hi): hi + lo carries ~22 mantissa bits
+typedef float float2v __attribute__((ext_vector_type(2)));
+// split 8 fp32 values into fp16 hi + fp16 lo, both round-to-nearest: x - hi is exact in fp32, so hi + lo carries
+// ~23 mantissa bits (residual <= 2^-24 |x|)
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]));
-    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]));
+    const float2v v = {x[2 * i], x[2 * i + 1]};
+    const half2v h = __builtin_convertvector(v, half2v);
+    const float2v r = {x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]};
+    const half2v l = __builtin_convertvector(r, half2v);
     hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
     lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
   }
+}
+// three-term split of a constant operand: hi + mid + lo reproduces the fp32 value exactly (33 bits)
+__device__ __forceinline__ void split8_3(const float (&x)[8], half8& hi, half8& mid, half8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    const float r1 = x[i] - (float)h;
+    const _Float16 m = (_Float16)r1;
+    const _Float16 l = (_Float16)(r1 - (float)m);
+    hi[i] = h; mid[i] = m; lo[i] = l;
+  }
+}
+// D += W . h with W = wh + wm + wl (exact) and h = bh + bl: all products down to 2^-22 of the leading one
+__device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, half8 bh, half8 bl, floatx16 d) {
+  d = mfma16(wl, bh, d);
+  d = mfma16(wm, bl, d);
+  d = mfma16(wm, bh, d);
+  d = mfma16(wh, bl, d);
+  return mfma16(wh, bh, d);
 }
 
 // Attention dropout (nn.Dropout on the softmax'd probabilities, DeformableAttention2D.py:309): a counter-based
@@ -167,13 +190,13 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   const float4* tb = tabB + 16 * hf;
 #if SMML_CPB_F16
   // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = 16 kb + 8 hf + j
-  half8 w2h[2], w2l[2];
+  half8 w2h[2], w2m[2], w2l[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     float wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + 16 * kb + 8 * hf + j];
-    split8(wv, w2h[kb], w2l[kb]);
+    split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
   }
 #endif
   const float b3 = cp.b3[oi];
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 #pragma unroll
     for (int st = 0; st < 32; ++st) s = mfma32(Ks[32 * hf + st][c], Qs[wave][32 * hf + st][c], s);
 
-    // continuous position bias: one 16-MFMA chain per key.  On gfx950 v_mfma_f32_32x32x2_f32 runs at the fp32
+    // continuous position bias: one MFMA chain per key.  On gfx950 v_mfma_f32_32x32x2_f32 runs at the fp32
     // vector rate and does NOT overlap VALU work of the same SIMD (tests/microbench/mfma_probe.hip: every
     // VALU instruction between two of these MFMAs adds its full issue time), so the loop is written for the
     // fewest vector instructions: b2 rides in as the chain's initial accumulator, no register copies.
@@ -236,9 +259,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
         }
         half8 bh, bl;
         split8(hv, bh, bl);
-        d = mfma16(w2h[kb], bh, d);
-        d = mfma16(w2h[kb], bl, d);
-        d = mfma16(w2l[kb], bh, d);
+        d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
       }
 #else
 #pragma unroll
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
     float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: tab[64] float4 | w3 tab[32] | dvs[J*2] | per wave: dDl[32][33], pl[32][2] | red[CPB_SLAB]
+  // layout: tab[32] float4 {w1x, w1y, b1, b2} | w3tab[32] | dvs[J*2] | per wave: dDl[32][33], h1l[32][33] | red[CPB_SLAB]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
@@ -554,46 +575,43 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
 
-  float4* tab = reinterpret_cast<float4*>(smem);            // [64] float4 constant tables
-  float* dvs = smem + 288;                                  // [J][2]
+  float4* tab = reinterpret_cast<float4*>(smem);            // per hidden channel
+  float* w3tab = smem + 128;
+  float* dvs = smem + 160;                                  // [J][2]
   float* wbase = dvs + ((2 * J + 3) & ~3);
-  float* dDl = wbase + wave * (32 * 33 + 64);               // [32 out][33]
-  float* pl = dDl + 32 * 33;                                // [32 query][2]
+  float* dDl = wbase + wave * (2 * 32 * 33);                // [32 out][33]   d D of the current key
+  float* h1l = dDl + 32 * 33;                               // [32 in][33]    h1 of the current key
   for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
-
+  if (tid < 32) {
+    float4 t;
+    t.x = cp.w1[tid * PD];
+    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
+    t.z = cp.b1[tid];
+    t.w = cp.b2[tid];
+    tab[tid] = t;
+    w3tab[tid] = cp.w3[oi * CH + tid];
+  }
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
 
-  // constants: W2 in both operand layouts and w3 stay in VGPRs; the layer-1 weights (needed in the k-step
-  // layout ch = 16 hf + s and in the accumulator layout ch = acc_row(r, hf)) are broadcast-read from LDS
-  float w2a[16], w2t[16];
+  // Operand slots: chain 1 feeds channel acc_row(8 kb + j, hf) in K-block kb / element j, i.e. the 16 channels a
+  // lane evaluates layer 1 for are the 16 accumulator rows chain 2 hands back to it: the ReLU masks of the
+  // layer-1 backward are the hv registers, one constant table serves both.
+  half8 w2h[2], w2m[2], w2l[2];                             // W2[out = c][in = acc_row(8 kb + j, hf)], fp16 hi / mid / lo
+  float w2t[16];                                            // W2[out = acc_row(r, hf)][in = c]  (A operand of dh1 = W2^T dD)
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    w2a[s] = cp.w2[c * CH + 16 * hf + s];                  // W2[out = c][in = 16 hf + s]
-    const int rc = acc_row(s, hf);
-    w2t[s] = cp.w2[rc * CH + c];                           // W2^T: A[i = in = c][k = out = rc]
+  for (int kb = 0; kb < 2; ++kb) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = acc_row(8 * kb + j, hf);
+      a[j] = cp.w2[c * CH + ch];
+      w2t[8 * kb + j] = cp.w2[ch * CH + c];
+    }
+    split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
   }
-  if (tid < 64) {
-    const int thf = tid >> 4, ts = tid & 15;               // thf in 0..3: 0,1 -> tabB halves; 2,3 -> tabA halves
-    const int hh = thf & 1;
-    const int ch = (thf < 2) ? (16 * hh + ts) : acc_row(ts, hh);
-    float4 t;
-    t.x = cp.w1[ch * PD];
-    t.y = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
-    t.z = cp.b1[ch];
-    t.w = cp.b2[ch];
-    tab[(thf * 16 + ts)] = t;
-  } else if (tid < 96) {
-    const int i = tid - 64;                                // w3 of this head's output row, accumulator layout
-    smem[256 + i] = cp.w3[oi * CH + acc_row(i & 15, i >> 4)];
-  }
-  const float4* tabB = tab + hf * 16;                      // {w1x, w1y, b1, -} of channel 16 hf + s
-  const float4* tabA = tab + 32 + hf * 16;                 // {w1x, w1y, b1, b2} of channel acc_row(r, hf)
-  const float* tab3 = smem + 256 + hf * 16;                // w3[oi][acc_row(r, hf)]
-  // lane-channel layout (channel = c) for the dW2 B operand
-  const float w1xc = cp.w1[c * PD], w1yc = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, b1c = cp.b1[c];
 
-  floatx16 e = {0};                                        // dW2[out rows][in cols]
+  floatx16 e = {0};                                         // dW2[out rows][in cols]
   float aw3[16], ab2[16], aw1x[16], aw1y[16], ab1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { aw3[r] = 0.f; ab2[r] = 0.f; aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
@@ -617,45 +635,54 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
     const float d0 = gq0 - vx, d1 = gq1 - vy;
     const float p0 = slog1p(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
-    if (hf == 0) { pl[c * 2] = p0; pl[c * 2 + 1] = p1; }
 
-    // phase 1 - forward recompute: D = W2 . h1
+    // phase 1 - layer 1 for this lane's 16 channels (kept in registers, parked transposed in LDS for phase 3) and
+    // the recompute chain D = W2 h1 as a split-fp16 product on the 16-bit matrix pipe (overlaps the VALU)
+    float hv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = acc_row(r, hf);
+      const float4 t = tab[ch];
+      float x = fmaf(t.x, p0, t.z);
+      if (PD == 2) x = fmaf(t.y, p1, x);
+      hv[r] = fmaxf(x, 0.f);
+      h1l[ch * 33 + c] = hv[r];
+    }
     floatx16 d = {0};
 #pragma unroll
-    for (int sp = 0; sp < 16; ++sp) {
-      const float4 t = tabB[sp];
-      float hv = fmaf(t.x, p0, t.z);
-      if (PD == 2) hv = fmaf(t.y, p1, hv);
-      d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
+    for (int kb = 0; kb < 2; ++kb) {
+      float x8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
+      half8 bh, bl;
+      split8(x8, bh, bl);
+      d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
     }
     // phase 2 - layer-3 backward slice r feeds MFMA r of dh1[in, query] = W2^T . dD straight away
-    // (the sum runs over the accumulator-row index: register r is the B operand of k-step r)
+    // (exact fp32: the sum runs over the accumulator-row index, register r is the B operand of k-step r)
     floatx16 dh = {0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float h2 = fmaxf(d[r] + tabA[r].w, 0.f);
+      const int ch = acc_row(r, hf);
+      const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
       aw3[r] = fmaf(dbias, h2, aw3[r]);
-      const float g2 = (h2 > 0.f) ? dbias * tab3[r] : 0.f;
+      const float g2 = (h2 > 0.f) ? dbias * w3tab[ch] : 0.f;
       ab2[r] += g2;
-      dDl[acc_row(r, hf) * 33 + c] = g2;
+      dDl[ch * 33 + c] = g2;
       dh = mfma32(w2t[r], g2, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
     asm volatile("" ::: "memory");     // LDS of one wave is in order; only the compiler must not reorder
-    // phase 3 - dW2[out, in] += sum_query dD[out, query] h1[in, query] on the matrix cores
-    //   (A[i = out = c][k = query = 16 hf + s] from LDS, B[k = query][j = in = c] recomputed),
-    //   interleaved with the layer-1 backward of accumulator slice s
+    // phase 3 - dW2[out, in] += sum_query dD[out, query] h1[in, query] on the fp32 matrix cores: both operands
+    // come transposed out of LDS (A[i = out = c][k = query], B[k = query][j = in = c], query = 16 hf + s),
+    // interleaved with the layer-1 backward of accumulator slice s
     float dp0 = 0.f, dp1 = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
       const int qq = 16 * hf + s2;
-      float hv = fmaf(w1xc, pl[qq * 2], b1c);
-      if (PD == 2) hv = fmaf(w1yc, pl[qq * 2 + 1], hv);
-      e = mfma32(dDl[c * 33 + qq], fmaxf(hv, 0.f), e);
-      const float4 t = tabA[s2];
-      float pre = fmaf(t.x, p0, t.z);
-      if (PD == 2) pre = fmaf(t.y, p1, pre);
-      const float g1 = (pre > 0.f) ? dh[s2] : 0.f;
+      e = mfma32(dDl[c * 33 + qq], h1l[c * 33 + qq], e);
+      const float4 t = tab[acc_row(s2, hf)];
+      const float g1 = (hv[s2] > 0.f) ? dh[s2] : 0.f;
       ab1[s2] += g1;
       aw1x[s2] = fmaf(g1, p0, aw1x[s2]);
       dp0 = fmaf(g1, t.x, dp0);
@@ -678,7 +705,7 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
 
   // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
   __syncthreads();
-  float* red = wbase + WAVES * (32 * 33 + 64);              // [CPB_SLAB] accumulators in LDS
+  float* red = wbase + WAVES * (2 * 32 * 33);               // [CPB_SLAB] accumulators in LDS
   for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -1124,7 +1151,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
       hipLaunchKernelGGL(cpb_bwd_f16_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
                          gmax, N, J, H, G, nst);
 #else
-    const size_t lds = ((size_t)288 + ((2 * J + 3) & ~3) + WAVES * (32 * 33 + 64) + CPB_SLAB) * sizeof(float);
+    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * (2 * 32 * 33) + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)

@@ -7,8 +7,8 @@ build() { # name, flags...
   local name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
-build f16_bwps2
-build f16_bwps1 -DSMML_BWD_WPS=1
-build f32_ref -DSMML_CPB_F16=0
+build hybrid_wps2
+build hybrid_wps1 -DSMML_BWD_WPS=1
+build hybrid_wps2_fast -DSMML_FAST_MATH=1
 wait
 ls bin
