@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 PKG = "subspace-multimodal-learning_amd"
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
+F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
 
@@ -163,16 +164,23 @@ def main():
             n, ms, pairs = kt["cpb_bwd"]
             flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops, recompute not counted
             ach = flop / (ms * 1e-3) / 1e12
+            # dominant kernel.  Its dW2 contraction (a third of its matrix work) runs on v_mfma_f32_32x32x2_f32, whose
+            # 157.3 TF peak equals the fp32 vector peak the rest of the kernel (ReLUs, layer 1 / 3, splits) competes for;
+            # the two recompute / dh1 chains run as split-fp16 products on the 16-bit pipe.  Priced against the fp32 peak.
             out["roofline"] = {"kernel": "cpb_bwd_kernel<2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "launches": n, "avg_ms": ms, "flop_per_launch": flop}
+                               "launches": n, "avg_ms": ms, "flop_per_launch": flop,
+                               "note": "algorithmic fp32 flops (4480 per pair, recompute not counted) / fp32 matrix = vector peak"}
         if "deform_attn_fwd" in kt:
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
             ach = flop / (ms * 1e-3) / 1e12
             out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
                                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-                                   "launches": n, "avg_ms": ms, "flop_per_launch": flop}
+                                   "launches": n, "avg_ms": ms, "flop_per_launch": flop,
+                                   "note": "position-bias layer as split-fp16 products on the 16-bit matrix pipe (2.5 PF peak, "
+                                           f"{100 * ach / F16_MFMA_PEAK_TFLOPS:.1f} % of it); the kernel is bound by the fp32 "
+                                           "vector work (layer 1, ReLUs, splits), priced here against the 157.3 TF fp32 peak"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, in_dim)
         print(json.dumps(out))

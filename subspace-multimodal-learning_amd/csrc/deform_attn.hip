@@ -598,17 +598,18 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   // lane evaluates layer 1 for are the 16 accumulator rows chain 2 hands back to it: the ReLU masks of the
   // layer-1 backward are the hv registers, one constant table serves both.
   half8 w2h[2], w2m[2], w2l[2];                             // W2[out = c][in = acc_row(8 kb + j, hf)], fp16 hi / mid / lo
-  float w2t[16];                                            // W2[out = acc_row(r, hf)][in = c]  (A operand of dh1 = W2^T dD)
+  half8 w2th[2], w2tm[2], w2tl[2];                          // W2[out = acc_row(8 kb + j, hf)][in = c]  (A operand of dh1 = W2^T dD)
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    float a[8];
+    float a[8], t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ch = acc_row(8 * kb + j, hf);
       a[j] = cp.w2[c * CH + ch];
-      w2t[8 * kb + j] = cp.w2[ch * CH + c];
+      t[j] = cp.w2[ch * CH + c];
     }
     split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
+    split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
   }
 
   floatx16 e = {0};                                         // dW2[out rows][in cols]
@@ -658,18 +659,33 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       split8(x8, bh, bl);
       d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
     }
-    // phase 2 - layer-3 backward slice r feeds MFMA r of dh1[in, query] = W2^T . dD straight away
-    // (exact fp32: the sum runs over the accumulator-row index, register r is the B operand of k-step r)
+    // phase 2 - layer-3 backward, then dh1[in, query] = W2^T . dD as a split-fp16 product.  d bias spans many
+    // binades across queries, so each lane (= query = one column of the product) scales its column by the power of
+    // two that brings |d bias| into [1, 2) and un-scales its column of the result - exact, and fp16-range safe.
+    float sc = 1.f, isc = 1.f;
+    {
+      const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
+      if (eb != 0u && eb != 255u) { sc = __uint_as_float((254u - eb) << 23); isc = __uint_as_float(eb << 23); }
+    }
+    const float dbs = dbias * sc;
     floatx16 dh = {0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = acc_row(r, hf);
-      const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
-      aw3[r] = fmaf(dbias, h2, aw3[r]);
-      const float g2 = (h2 > 0.f) ? dbias * w3tab[ch] : 0.f;
-      ab2[r] += g2;
-      dDl[ch * 33 + c] = g2;
-      dh = mfma32(w2t[r], g2, dh);
+    for (int kb = 0; kb < 2; ++kb) {
+      float g8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+        const int r = 8 * kb + jx, ch = acc_row(r, hf);
+        const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
+        aw3[r] = fmaf(dbias, h2, aw3[r]);
+        const float g2s = (h2 > 0.f) ? dbs * w3tab[ch] : 0.f;
+        const float g2 = g2s * isc;
+        ab2[r] += g2;
+        dDl[ch * 33 + c] = g2;
+        g8[jx] = g2s;
+      }
+      half8 gh, gl;
+      split8(g8, gh, gl);
+      dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
     asm volatile("" ::: "memory");     // LDS of one wave is in order; only the compiler must not reorder
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       const int qq = 16 * hf + s2;
       e = mfma32(dDl[c * 33 + qq], h1l[c * 33 + qq], e);
       const float4 t = tab[acc_row(s2, hf)];
-      const float g1 = (hv[s2] > 0.f) ? dh[s2] : 0.f;
+      const float g1 = (hv[s2] > 0.f) ? dh[s2] * isc : 0.f;
       ab1[s2] += g1;
       aw1x[s2] = fmaf(g1, p0, aw1x[s2]);
       dp0 = fmaf(g1, t.x, dp0);
