@@ -34,6 +34,17 @@ CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # SURVEY.md 8(d): 
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
 
 
+def measured_traffic(kernel, bags):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_hbm_traffic.json), scaled to this
+    run's bags per launch; None if no measurement is on file (bench.py itself cannot collect PMC counters)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            t = json.load(f)
+        return t["kernels"][kernel]["hbm_bytes_per_launch"] * bags / t["bags_per_launch"]
+    except Exception:
+        return None
+
+
 def mil_args(in_dim):
     return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim)
 
@@ -168,7 +179,8 @@ def main():
             # 157.3 TF peak equals the fp32 vector peak the rest of the kernel (ReLUs, layer 1 / 3, splits) competes for;
             # the two recompute / dh1 chains run as split-fp16 products on the 16-bit pipe.  Priced against the fp32 peak.
             out["roofline"] = {"kernel": "cpb_bwd_kernel<2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                               "traffic": measured_traffic("cpb_bwd_kernel<2>", B) if (S, in_dim) == (100, 512) else None,
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                "note": "algorithmic fp32 flops (4480 per pair, recompute not counted) / fp32 matrix = vector peak"}
         if "deform_attn_fwd" in kt:

@@ -24,8 +24,7 @@ class GatherLayer(torch.autograd.Function):
     def forward(ctx, input):
         world = dist.get_world_size()
         out = torch.empty((world,) + tuple(input.shape), dtype=input.dtype, device=input.device)
-        dist.all_gather_into_tensor(out, input.contiguous()) if input.is_cuda else \
-            dist.all_gather(list(out.unbind(0)), input.contiguous())
+        dist.all_gather(list(out.unbind(0)), input.contiguous())     # contiguous slices of one buffer
         return tuple(out.unbind(0))
 
     @staticmethod
