@@ -28,7 +28,7 @@
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
 #ifndef SMML_BWD_WPS
-#define SMML_BWD_WPS 2      // same for the position-bias backward kernel
+#define SMML_BWD_WPS 1      // same for the position-bias backward kernel (1: its per-channel constants live in VGPRs)
 #endif
 #ifndef SMML_CPB_F16
 #define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
@@ -41,8 +41,32 @@
                             // 48 f32 MFMAs they replace) and, with one launch-wide power-of-two gradient scale, fp16's
                             // exponent range loses the small d bias values (dW2 off by 4e-4); kept for further tuning
 #endif
+#ifndef SMML_BWD_UNROLL
+#define SMML_BWD_UNROLL 1   // keys per loop trip of the position-bias backward (2 gives the scheduler a second, independent key)
+#endif
 #ifndef SMML_FAST_MATH
-#define SMML_FAST_MATH 0    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
+#define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
+#endif
+
+// diagnostic build only (-DSMML_STAMPS): s_memtime shares of the position-bias backward's loop phases, written into
+// the unused tail of the first workgroup's slab; never enabled in the shipped library
+#ifdef SMML_STAMPS
+#define SMML_STAMP_DECL unsigned long long st_[5] = {0, 0, 0, 0, 0}, sp_ = 0;
+#define SMML_STAMP(i)                                                                                     \
+  {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    unsigned long long t_;                                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    if (i > 0) st_[i] += t_ - sp_; else if (j > 0) st_[0] += t_ - sp_;                                    \
+    sp_ = t_;                                                                                             \
+  }
+#define SMML_STAMP_STORE                                                                                  \
+  if (tid == 0) { for (int i_ = 0; i_ < 5; ++i_) sl[1186 + i_] = (float)st_[i_] / (float)J; }
+#else
+#define SMML_STAMP_DECL
+#define SMML_STAMP(i)
+#define SMML_STAMP_STORE
 #endif
 
 namespace {
@@ -561,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
 // slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
 // ------------------------------------------------------------------------------------------------
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
+constexpr int CPB_WAVE_LDS = 2 * 32 * 33 + 2 * 32 * 65 + 8;   // floats of LDS per wave of cpb_bwd_kernel (multiple of 4)
 
 template <int PD>
 __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
@@ -579,8 +604,9 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   float* w3tab = smem + 128;
   float* dvs = smem + 160;                                  // [J][2]
   float* wbase = dvs + ((2 * J + 3) & ~3);
-  float* dDl = wbase + wave * (2 * 32 * 33);                // [32 out][33]   d D of the current key
+  float* dDl = wbase + wave * CPB_WAVE_LDS;                 // [32 out][33]   d D of the current key
   float* h1l = dDl + 32 * 33;                               // [32 in][33]    h1 of the current key
+  float2* stg = reinterpret_cast<float2*>(h1l + 32 * 33);   // [32 keys][65]  per-lane d vs partials of the last <= 32 keys
   for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
   if (tid < 32) {
     float4 t;
@@ -593,6 +619,31 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   }
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+#if SMML_BWD_WPS == 1
+  // one wave per SIMD (512-register budget): the per-channel constants of this lane's 16 channels live in VGPRs,
+  // the loop's only LDS traffic is the two operand transposes
+  float cw1x[16], cw1y[16], cb1[16], cb2[16], cw3[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = acc_row(r, hf);
+    cw1x[r] = cp.w1[ch * PD];
+    cw1y[r] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    cb1[r] = cp.b1[ch];
+    cb2[r] = cp.b2[ch];
+    cw3[r] = cp.w3[oi * CH + ch];
+  }
+#define CW1X(r) cw1x[r]
+#define CW1Y(r) cw1y[r]
+#define CB1(r) cb1[r]
+#define CB2(r) cb2[r]
+#define CW3(r) cw3[r]
+#else
+#define CW1X(r) tab[acc_row(r, hf)].x
+#define CW1Y(r) tab[acc_row(r, hf)].y
+#define CB1(r) tab[acc_row(r, hf)].z
+#define CB2(r) tab[acc_row(r, hf)].w
+#define CW3(r) w3tab[acc_row(r, hf)]
+#endif
 
   // Operand slots: chain 1 feeds channel acc_row(8 kb + j, hf) in K-block kb / element j, i.e. the 16 channels a
   // lane evaluates layer 1 for are the 16 accumulator rows chain 2 hands back to it: the ReLU masks of the
@@ -625,14 +676,69 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   // next key's operands are fetched one iteration ahead (d bias streams from HBM, used once)
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
-  float db_n = qvalid ? dLTb[q0 + c] : 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float vx = vx_n, vy = vy_n, dbias = db_n;
-    if (j + 1 < J) {
-      vx_n = VSb[(size_t)(j + 1) * PD];
-      if (PD == 2) vy_n = VSb[(size_t)(j + 1) * PD + 1];
-      db_n = qvalid ? dLTb[(size_t)(j + 1) * NST + q0 + c] : 0.f;
+  const int qcol = qvalid ? (q0 + c) : q0;                  // lanes past the bag end read a valid column and are zeroed
+  float db_n = dLTb[qcol];
+  SMML_STAMP_DECL
+
+  // The loop is rotated by one key: the layer-1 backward of key j-1 (which consumes chain 2's result) is issued
+  // right after chain 1 of key j, so both 10-MFMA fp16 chains (~320 cycles each) complete behind vector work
+  // instead of stalling the in-order wave.  State of the previous key:
+  float hv_p[16];
+  floatx16 dh_p = {0};
+  float p0_p = 0.f, p1_p = 0.f, d0_p = 0.f, d1_p = 0.f, isc_p = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hv_p[r] = 0.f;
+
+  // layer-1 backward of one key + its d vs contribution: per-lane partials go to the staging tile (row = key % 32);
+  // every 32 keys each lane sums one (key, half) and lanes 0..31 add the totals to the LDS accumulator
+  auto layer1_bwd = [&](int jk, const float (&hvk)[16], const floatx16& dhk, float p0k, float p1k, float d0k, float d1k,
+                        float isck) {
+    float dp0 = 0.f, dp1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float g1 = (hvk[r] > 0.f) ? dhk[r] * isck : 0.f;
+      ab1[r] += g1;
+      aw1x[r] = fmaf(g1, p0k, aw1x[r]);
+      dp0 = fmaf(g1, CW1X(r), dp0);
+      if (PD == 2) {
+        aw1y[r] = fmaf(g1, p1k, aw1y[r]);
+        dp1 = fmaf(g1, CW1Y(r), dp1);
+      }
     }
+    float2 v;
+    v.x = -dp0 * srcp(fabsf(d0k) + 1.f);
+    v.y = (PD == 2) ? -dp1 * srcp(fabsf(d1k) + 1.f) : 0.f;
+    stg[(jk & 31) * 65 + lane] = v;
+    if ((jk & 31) == 31 || jk == J - 1) {
+      asm volatile("" ::: "memory");
+      const int kk = lane & 31, nrow = (jk & 31) + 1;
+      float sx = 0.f, sy = 0.f;
+      if (kk < nrow) {
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const float2 t = stg[kk * 65 + 32 * hf + i];
+          sx += t.x; sy += t.y;
+        }
+      }
+      sx = xhalf_sum(sx); sy = xhalf_sum(sy);
+      if (hf == 0 && kk < nrow) {
+        const int key = (jk & ~31) + kk;
+        atomicAdd(&dvs[2 * key], sx);
+        if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
+      }
+      asm volatile("" ::: "memory");
+    }
+  };
+
+  for (int j = 0; j < J; ++j) {
+    const float vx = vx_n, vy = vy_n, dbias = qvalid ? db_n : 0.f;
+    {
+      const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
+      vx_n = VSb[(size_t)jn * PD];
+      if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
+      db_n = dLTb[(size_t)jn * NST + qcol];
+    }
+    SMML_STAMP(0)
     const float d0 = gq0 - vx, d1 = gq1 - vy;
     const float p0 = slog1p(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
@@ -643,9 +749,8 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = acc_row(r, hf);
-      const float4 t = tab[ch];
-      float x = fmaf(t.x, p0, t.z);
-      if (PD == 2) x = fmaf(t.y, p1, x);
+      float x = fmaf(CW1X(r), p0, CB1(r));
+      if (PD == 2) x = fmaf(CW1Y(r), p1, x);
       hv[r] = fmaxf(x, 0.f);
       h1l[ch * 33 + c] = hv[r];
     }
@@ -659,6 +764,10 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       split8(x8, bh, bl);
       d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
     }
+    SMML_STAMP(1)
+    // previous key: layer-1 backward while chain 1 of this key is in flight (no-op data for j = 0)
+    if (j > 0) layer1_bwd(j - 1, hv_p, dh_p, p0_p, p1_p, d0_p, d1_p, isc_p);
+    SMML_STAMP(2)
     // phase 2 - layer-3 backward, then dh1[in, query] = W2^T . dD as a split-fp16 product.  d bias spans many
     // binades across queries, so each lane (= query = one column of the product) scales its column by the power of
     // two that brings |d bias| into [1, 2) and un-scales its column of the result - exact, and fp16-range safe.
@@ -675,9 +784,9 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
 #pragma unroll
       for (int jx = 0; jx < 8; ++jx) {
         const int r = 8 * kb + jx, ch = acc_row(r, hf);
-        const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
+        const float h2 = fmaxf(d[r] + CB2(r), 0.f);
         aw3[r] = fmaf(dbias, h2, aw3[r]);
-        const float g2s = (h2 > 0.f) ? dbs * w3tab[ch] : 0.f;
+        const float g2s = (h2 > 0.f) ? dbs * CW3(r) : 0.f;
         const float g2 = g2s * isc;
         ab2[r] += g2;
         dDl[ch * 33 + c] = g2;
@@ -688,40 +797,27 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
+    SMML_STAMP(3)
     asm volatile("" ::: "memory");     // LDS of one wave is in order; only the compiler must not reorder
     // phase 3 - dW2[out, in] += sum_query dD[out, query] h1[in, query] on the fp32 matrix cores: both operands
-    // come transposed out of LDS (A[i = out = c][k = query], B[k = query][j = in = c], query = 16 hf + s),
-    // interleaved with the layer-1 backward of accumulator slice s
-    float dp0 = 0.f, dp1 = 0.f;
+    // come transposed out of LDS (A[i = out = c][k = query], B[k = query][j = in = c], query = 16 hf + s)
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
       const int qq = 16 * hf + s2;
       e = mfma32(dDl[c * 33 + qq], h1l[c * 33 + qq], e);
-      const float4 t = tab[acc_row(s2, hf)];
-      const float g1 = (hv[s2] > 0.f) ? dh[s2] * isc : 0.f;
-      ab1[s2] += g1;
-      aw1x[s2] = fmaf(g1, p0, aw1x[s2]);
-      dp0 = fmaf(g1, t.x, dp0);
-      if (PD == 2) {
-        aw1y[s2] = fmaf(g1, p1, aw1y[s2]);
-        dp1 = fmaf(g1, t.y, dp1);
-      }
     }
-    // d vs[j] = - sum_query dp / (|d| + 1)
-    {
-      float t0 = wave_sum(-dp0 * srcp(fabsf(d0) + 1.f));
-      if (lane == 0) atomicAdd(&dvs[2 * j], t0);
-      if (PD == 2) {
-        float t1 = wave_sum(-dp1 * srcp(fabsf(d1) + 1.f));
-        if (lane == 0) atomicAdd(&dvs[2 * j + 1], t1);
-      }
-    }
+    SMML_STAMP(4)
     asm volatile("" ::: "memory");
+    // rotate
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hv_p[r] = hv[r];
+    dh_p = dh; p0_p = p0; p1_p = p1; d0_p = d0; d1_p = d1; isc_p = isc;
   }
+  layer1_bwd(J - 1, hv_p, dh_p, p0_p, p1_p, d0_p, d1_p, isc_p);
 
   // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
   __syncthreads();
-  float* red = wbase + WAVES * (2 * 32 * 33);               // [CPB_SLAB] accumulators in LDS
+  float* red = wbase + WAVES * CPB_WAVE_LDS;                // [CPB_SLAB] accumulators in LDS
   for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -759,6 +855,7 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   float* sl = slab + (size_t)wg * CPB_SLAB;
   for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
+  SMML_STAMP_STORE
   // sample-position gradients: float atomics, contiguous rows
   float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
   for (int i = tid; i < J * PD; i += 256) {
@@ -767,6 +864,12 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   }
 }
 
+
+#undef CW1X
+#undef CW1Y
+#undef CB1
+#undef CB2
+#undef CW3
 
 // power-of-two S with gmax * S in [2^9, 2^10): fp16 headroom for |w3| up to 64, full precision down to 2^-24 gmax
 __device__ __forceinline__ float grad_scale_from_max(unsigned gbits) {
@@ -1167,7 +1270,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
       hipLaunchKernelGGL(cpb_bwd_f16_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
                          gmax, N, J, H, G, nst);
 #else
-    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * (2 * 32 * 33) + CPB_SLAB) * sizeof(float);
+    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * CPB_WAVE_LDS + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)

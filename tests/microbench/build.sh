@@ -7,8 +7,8 @@ build() { # name, flags...
   local name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
-build hybrid_wps2
-build hybrid_wps1 -DSMML_BWD_WPS=1
-build hybrid_wps2_fast -DSMML_FAST_MATH=1
+build rot_w1
+build rot_w1_stamps -DSMML_STAMPS
+build rot_w2 -DSMML_BWD_WPS=2
 wait
 ls bin
