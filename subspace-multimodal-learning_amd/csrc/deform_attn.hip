@@ -366,15 +366,29 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // backward pass 1 (query owners): dS^T = P^T (dP^T - delta), dQ = scale * dS K
-//   reads logits_t, writes dlogits_t (same layout) and dq
+//   reads logits_t, writes dlogits_t (same layout) and dq.  K / V tiles are double-buffered in LDS and the next
+//   tile's K, V and logits loads are in flight while the current tile's 64 MFMAs run (one barrier per tile).
 // ------------------------------------------------------------------------------------------------
+constexpr int VLD = DH + 4;   // V tile [key][d]: 16-B aligned rows, ds_read_b128 across 16 keys conflict-free (slot = key mod 16)
+constexpr int KLD = KT + 4;   // K^T tile [d][key]: same for 16 d-rows (slot = 9 d mod 16)
+constexpr float LOG2E = 1.4426950408889634f;
+
+#if SMML_FAST_MATH
+// exp(l - lse) as one fma + v_exp_f32: nl = -lse * log2(e)
+__device__ __forceinline__ float prob_of(float l, float nl) { return __builtin_amdgcn_exp2f(fmaf(l, LOG2E, nl)); }
+__device__ __forceinline__ float prob_bias(float lse) { return -lse * LOG2E; }
+#else
+__device__ __forceinline__ float prob_of(float l, float nl) { return expf(l + nl); }
+__device__ __forceinline__ float prob_bias(float lse) { return -lse; }
+#endif
+
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
     float* __restrict__ dLT, float* __restrict__ dQ, unsigned* __restrict__ gmax, int N, int J, int H, int NST,
     float scale, DropCfg dc) {
-  __shared__ float Vt[DH][KT + 1];   // V tile d-major (A operand of dP^T = V . dO^T)
-  __shared__ float Kr[KT][DH];       // K tile key-major (A operand of dQ^T = K^T . dS^T)
+  __shared__ __attribute__((aligned(16))) float Vr[2][KT][VLD];   // A operand of dP^T = V . dO^T
+  __shared__ __attribute__((aligned(16))) float Kt[2][DH][KLD];   // A operand of dQ^T = K^T . dS^T
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -382,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const int HD = H * DH;
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
+  const int qcol = qvalid ? (q0 + c) : 0;            // column of this lane in the key-major score rows
 
   float doreg[32];
   float delta = 0.f;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     }
   }
   delta = xhalf_sum(delta);
-  const float lse = LSE[(size_t)(b * H + h) * N + qi];
+  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
 
   floatx16 dq0 = {0}, dq1 = {0};
   float amax = 0.f;                                  // max |dS| of this lane (feeds the fp16 gradient scale)
@@ -406,28 +421,56 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
   float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
 
-  const int ntiles = (J + KT - 1) / KT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int j0 = kt * KT;
-    const int nk = min(KT, J - j0);
-    __syncthreads();
+  // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
+  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  float4 kreg[2], vreg[2];
+  float lt[16];
+  auto fetch = [&](int j0, float4 (&kr)[2], float4 (&vr)[2], float (&l)[16]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int key = (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (j0 + key < J) {
-        kv = *reinterpret_cast<const float4*>(Kb + (size_t)(j0 + key) * HD + d4);
-        vv = *reinterpret_cast<const float4*>(Vb + (size_t)(j0 + key) * HD + d4);
+      const int key = j0 + skey + 16 * i;
+      kr[i] = make_float4(0.f, 0.f, 0.f, 0.f); vr[i] = kr[i];
+      if (key < J) {
+        kr[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * HD + sd4);
+        vr[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * HD + sd4);
       }
-      Vt[d4 + 0][key] = vv.x; Vt[d4 + 1][key] = vv.y; Vt[d4 + 2][key] = vv.z; Vt[d4 + 3][key] = vv.w;
-      *reinterpret_cast<float4*>(&Kr[key][d4]) = kv;
     }
-    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(j0 + acc_row(r, hf), J - 1);     // clamped: always in bounds, masked at use
+      l[r] = LTb[(size_t)key * NST + qcol];
+    }
+  };
+  fetch(0, kreg, vreg, lt);
+
+  const int ntiles = (J + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT, buf = kt & 1;
+    const int nk = min(KT, J - j0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = skey + 16 * i;
+      *reinterpret_cast<float4*>(&Vr[buf][key][sd4]) = vreg[i];
+      Kt[buf][sd4 + 0][key] = kreg[i].x; Kt[buf][sd4 + 1][key] = kreg[i].y;
+      Kt[buf][sd4 + 2][key] = kreg[i].z; Kt[buf][sd4 + 3][key] = kreg[i].w;
+    }
+    __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2, which every wave left before this barrier's
+                            // predecessor: one barrier per tile is enough
+    float ltc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ltc[r] = lt[r];
+    if (kt + 1 < ntiles) fetch(j0 + KT, kreg, vreg, lt);
 
     // dP^T[key, query] = V . dO^T
     floatx16 dp = {0};
 #pragma unroll
-    for (int st = 0; st < 32; ++st) dp = mfma32(Vt[32 * hf + st][c], doreg[st], dp);
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float4 a = *reinterpret_cast<const float4*>(&Vr[buf][c][32 * hf + 4 * s4]);
+      dp = mfma32(a.x, doreg[4 * s4 + 0], dp);
+      dp = mfma32(a.y, doreg[4 * s4 + 1], dp);
+      dp = mfma32(a.z, doreg[4 * s4 + 2], dp);
+      dp = mfma32(a.w, doreg[4 * s4 + 3], dp);
+    }
 
     floatx16 ds;
 #pragma unroll
@@ -435,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       const int key = acc_row(r, hf);
       float v = 0.f;
       if (key < nk && qvalid) {
-        const float p = expf(LTb[(size_t)(j0 + key) * NST + q0 + c] - lse);
+        const float p = prob_of(ltc[r], nl);
         float dpr = dp[r];
         if (dc.thresh) dpr *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qi) * J) + j0 + key);
         v = p * (dpr - delta);
@@ -446,10 +489,13 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     }
     // dQ^T[d, query] += K^T . dS^T
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = acc_row(r, hf);
-      dq0 = mfma32(Kr[key][c], ds[r], dq0);
-      dq1 = mfma32(Kr[key][32 + c], ds[r], dq1);
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&Kt[buf][c][8 * rg + 4 * hf]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&Kt[buf][32 + c][8 * rg + 4 * hf]);
+      dq0 = mfma32(a0.x, ds[4 * rg + 0], dq0); dq1 = mfma32(a1.x, ds[4 * rg + 0], dq1);
+      dq0 = mfma32(a0.y, ds[4 * rg + 1], dq0); dq1 = mfma32(a1.y, ds[4 * rg + 1], dq1);
+      dq0 = mfma32(a0.z, ds[4 * rg + 2], dq0); dq1 = mfma32(a1.z, ds[4 * rg + 2], dq1);
+      dq0 = mfma32(a0.w, ds[4 * rg + 3], dq0); dq1 = mfma32(a1.w, ds[4 * rg + 3], dq1);
     }
   }
   if (gmax) {
@@ -471,108 +517,132 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 2 (key owners): dV = P^T dO, dK = scale * dS^T Q ; one workgroup per 32-key tile,
-// its four waves stride over the query tiles and are summed through LDS at the end (no atomics).
+// backward pass 2 (key owners): dV = P_dropped^T dO, dK = scale * dS^T Q.  A workgroup owns 128 keys (one 32-key
+// tile per wave) and one slice of the query tiles; its four waves consume the same Q / dO tile from LDS (staged
+// once per workgroup, double-buffered, the next tile's global loads in flight during the 64 MFMAs).  The partial
+// sums of the query slices go to slabs [nparts][B, J, H*64] that dkv_reduce_kernel adds up in a fixed order
+// (no atomics: run-to-run identical results).
 // ------------------------------------------------------------------------------------------------
+constexpr int QLD = DH + 8;    // Q / dO tile row stride: rows 4 apart (the two lane halves) land 32 banks apart
+constexpr int DKV_KEYS = KT * WAVES;
+
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
-    const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dK,
-    float* __restrict__ dV, int N, int J, int H, int NST, float scale, DropCfg dc) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // per wave: Qs[32][64], dOs[32][64]; after the loop reused as reduce[4][2][64][33]
+    const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dKp,
+    float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, DropCfg dc) {
+  __shared__ __attribute__((aligned(16))) float Qs[2][QT][QLD];
+  __shared__ __attribute__((aligned(16))) float dOs[2][QT][QLD];
+  __shared__ __attribute__((aligned(16))) float nls[2][QT];   // -lse (times log2 e on the fast path) of the tile's queries
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * KT;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kg = blockIdx.x % nkg, part = blockIdx.x / nkg;
+  const int j0 = kg * DKV_KEYS + wave * KT;
   const int HD = H * DH;
-  float* Qs = smem + wave * (2 * QT * DH);
-  float* dOs = Qs + QT * DH;
-  const int nk = min(KT, J - j0);
+  const int nk = min(KT, J - j0);                       // <= 0: this wave has no keys (it still stages tiles)
   const bool kvalid = c < nk;
-  const int key = j0 + (kvalid ? c : 0);
+  const int key = min(j0 + c, J - 1);
   const float* LTk = LT + ((size_t)(b * H + h) * J + key) * NST;
   const float* dLTk = dLT + ((size_t)(b * H + h) * J + key) * NST;
   const float* LSEb = LSE + (size_t)(b * H + h) * N;
 
-  floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int nqt = (N + QT - 1) / QT;
-  for (int qt = wave; qt < nqt; qt += WAVES) {
-    const int q0 = qt * QT;
-    wave_lds_fence();
-    // stage this wave's Q and dO tiles (32 rows x 256 B each)
+  const int qt_begin = part * tiles_per_part, qt_end = min(qt_begin + tiles_per_part, nqt);
+
+  // staging map: thread -> rows (tid >> 4) and (tid >> 4) + 16 of the 32-query tile, 4 consecutive d
+  const int srow = tid >> 4, sd4 = (tid & 15) * 4;
+  float4 qreg[2], doreg[2], ltr[4], dlr[4];
+  float lsereg = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = i * 64 + lane, row = idx >> 4, d4 = (idx & 15) * 4;
-      const int qrow = min(q0 + row, N - 1);
-      const size_t off = ((size_t)b * N + qrow) * HD + h * DH + d4;
-      *reinterpret_cast<float4*>(Qs + row * DH + d4) = *reinterpret_cast<const float4*>(Q + off);
-      *reinterpret_cast<float4*>(dOs + row * DH + d4) = *reinterpret_cast<const float4*>(dO + off);
+  for (int i = 0; i < 4; ++i) { ltr[i] = make_float4(0.f, 0.f, 0.f, 0.f); dlr[i] = ltr[i]; qreg[i >> 1] = ltr[i]; doreg[i >> 1] = ltr[i]; }
+  auto fetch = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qrow = min(q0 + srow + 16 * i, N - 1);
+      const size_t off = ((size_t)b * N + qrow) * HD + h * DH + sd4;
+      qreg[i] = *reinterpret_cast<const float4*>(Q + off);
+      doreg[i] = *reinterpret_cast<const float4*>(dO + off);
     }
-    wave_lds_fence();
-    // P[query, key] and dS[query, key] with the query on the accumulator-row axis
-    float p[16], ds[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const int qq = q0 + 8 * rg + 4 * hf;      // 4 consecutive queries, 16-B aligned
-      const float4 lt = *reinterpret_cast<const float4*>(LTk + qq);
-      const float4 dl = *reinterpret_cast<const float4*>(dLTk + qq);
-      const float lv[4] = {lt.x, lt.y, lt.z, lt.w};
-      const float dv[4] = {dl.x, dl.y, dl.z, dl.w};
+      const int qq = q0 + 8 * rg + 4 * hf;                // 4 consecutive queries; score rows are padded to NST
+      ltr[rg] = *reinterpret_cast<const float4*>(LTk + qq);
+      dlr[rg] = *reinterpret_cast<const float4*>(dLTk + qq);
+    }
+    if (tid < QT) lsereg = LSEb[min(q0 + tid, N - 1)];
+  };
+
+  floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  if (qt_begin < qt_end) fetch(qt_begin * QT);
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int q0 = qt * QT, buf = (qt - qt_begin) & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = kvalid && (qq + i) < N;
-        const float lse = LSEb[min(qq + i, N - 1)];
-        float pv = ok ? expf(lv[i] - lse) : 0.f;
-        if (dc.thresh && ok) pv *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + (qq + i)) * J) + key);
-        p[4 * rg + i] = pv;                       // dV takes the dropped probabilities, dK the dS written by pass 1
-        ds[4 * rg + i] = ok ? dv[i] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&Qs[buf][srow + 16 * i][sd4]) = qreg[i];
+      *reinterpret_cast<float4*>(&dOs[buf][srow + 16 * i][sd4]) = doreg[i];
+    }
+    if (tid < QT) nls[buf][tid] = prob_bias(lsereg);
+    __syncthreads();        // one barrier per tile (double buffer, see pass 1)
+    float lv[16], dsv[16], ls[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      lv[4 * rg + 0] = ltr[rg].x; lv[4 * rg + 1] = ltr[rg].y; lv[4 * rg + 2] = ltr[rg].z; lv[4 * rg + 3] = ltr[rg].w;
+      dsv[4 * rg + 0] = dlr[rg].x; dsv[4 * rg + 1] = dlr[rg].y; dsv[4 * rg + 2] = dlr[rg].z; dsv[4 * rg + 3] = dlr[rg].w;
+      const float4 t = *reinterpret_cast<const float4*>(&nls[buf][8 * rg + 4 * hf]);     // broadcast read
+      ls[4 * rg + 0] = t.x; ls[4 * rg + 1] = t.y; ls[4 * rg + 2] = t.z; ls[4 * rg + 3] = t.w;
+    }
+    if (qt + 1 < qt_end) fetch(q0 + QT);
+    if (nk > 0) {                                          // wave-uniform
+      // P[query, key] and dS[query, key] with the query on the accumulator-row axis
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + acc_row(r, hf);
+        const bool ok = kvalid && qq < N;
+        float pv = ok ? prob_of(lv[r], ls[r]) : 0.f;
+        if (dc.thresh && ok) pv *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qq) * J) + key);
+        p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
+        ds[r] = ok ? dsv[r] : 0.f;
+      }
+      // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hf);
+        dv0 = mfma32(dOs[buf][row][c], p[r], dv0);
+        dv1 = mfma32(dOs[buf][row][32 + c], p[r], dv1);
+        dk0 = mfma32(Qs[buf][row][c], ds[r], dk0);
+        dk1 = mfma32(Qs[buf][row][32 + c], ds[r], dk1);
       }
     }
-    // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS
+  }
+  // accumulators hold [d = acc_row(r, hf) (+32)][key = c]: each lane writes its key's 4-float runs
+  if (kvalid) {
+    const size_t off = (((size_t)part * gridDim.z + b) * J + (j0 + c)) * HD + h * DH;
+    float* kp = dKp + off;
+    float* vp = dVp + off;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, hf);
-      dv0 = mfma32(dOs[row * DH + c], p[r], dv0);
-      dv1 = mfma32(dOs[row * DH + 32 + c], p[r], dv1);
-      dk0 = mfma32(Qs[row * DH + c], ds[r], dk0);
-      dk1 = mfma32(Qs[row * DH + 32 + c], ds[r], dk1);
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(kp + d) = make_float4(dk0[4 * rg], dk0[4 * rg + 1], dk0[4 * rg + 2], dk0[4 * rg + 3]);
+      *reinterpret_cast<float4*>(kp + 32 + d) = make_float4(dk1[4 * rg], dk1[4 * rg + 1], dk1[4 * rg + 2], dk1[4 * rg + 3]);
+      *reinterpret_cast<float4*>(vp + d) = make_float4(dv0[4 * rg], dv0[4 * rg + 1], dv0[4 * rg + 2], dv0[4 * rg + 3]);
+      *reinterpret_cast<float4*>(vp + 32 + d) = make_float4(dv1[4 * rg], dv1[4 * rg + 1], dv1[4 * rg + 2], dv1[4 * rg + 3]);
     }
   }
-  __syncthreads();
-  // cross-wave reduction: red[wave][t][d][key], t = 0 (dK) / 1 (dV), row stride 33
-  float* red = smem;
-  {
-    float* rk = red + (wave * 2 + 0) * (DH * 33);
-    float* rv = red + (wave * 2 + 1) * (DH * 33);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int d = acc_row(r, hf);
-      rk[d * 33 + c] = dk0[r]; rk[(32 + d) * 33 + c] = dk1[r];
-      rv[d * 33 + c] = dv0[r]; rv[(32 + d) * 33 + c] = dv1[r];
-    }
+}
+
+// dK = scale * sum_part dKp[part], dV = sum_part dVp[part]   (n4 float4 elements per part)
+__global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* __restrict__ dVp, float4* __restrict__ dK,
+                                  float4* __restrict__ dV, size_t n4, int nparts, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 sk = dKp[i], sv = dVp[i];
+  for (int p = 1; p < nparts; ++p) {
+    const float4 a = dKp[(size_t)p * n4 + i], bq = dVp[(size_t)p * n4 + i];
+    sk.x += a.x; sk.y += a.y; sk.z += a.z; sk.w += a.w;
+    sv.x += bq.x; sv.y += bq.y; sv.z += bq.z; sv.w += bq.w;
   }
-  __syncthreads();
-  // 256 threads: thread -> (key = tid >> 3, 8 d-values); coalesced 256-B rows in HBM
-  {
-    const int kk = tid >> 3, dbase = (tid & 7) * 8;
-    if (kk < nk) {
-      float ak[8], av[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float sk = 0.f, sv = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-          sk += red[(w * 2 + 0) * (DH * 33) + (dbase + i) * 33 + kk];
-          sv += red[(w * 2 + 1) * (DH * 33) + (dbase + i) * 33 + kk];
-        }
-        ak[i] = sk * scale; av[i] = sv;
-      }
-      float* kp = dK + ((size_t)b * J + j0 + kk) * HD + h * DH + dbase;
-      float* vp = dV + ((size_t)b * J + j0 + kk) * HD + h * DH + dbase;
-      *reinterpret_cast<float4*>(kp) = make_float4(ak[0], ak[1], ak[2], ak[3]);
-      *reinterpret_cast<float4*>(kp + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
-      *reinterpret_cast<float4*>(vp) = make_float4(av[0], av[1], av[2], av[3]);
-      *reinterpret_cast<float4*>(vp + 4) = make_float4(av[4], av[5], av[6], av[7]);
-    }
-  }
+  dK[i] = make_float4(sk.x * scale, sk.y * scale, sk.z * scale, sk.w * scale);
+  dV[i] = sv;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,18 +1172,19 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_f16_kernel(
   }
 }
 
-// sums the per-workgroup slabs: out[k] = sum_wg slab[wg][k]; one block per 64 outputs
-__global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o, float* __restrict__ dW1,
-                                  float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
-                                  float* __restrict__ dW3, float* __restrict__ db3, int PD, int wg_per_head,
-                                  int H, int G) {
-  // slabs are ordered (b, h, qtile); dW3/db3 belong to output row oi = h % o, the rest is shared
+// sums the per-workgroup slabs in two deterministic stages.  Stage 1: block (x, y) adds the slabs of chunk y for the 64
+// outputs of column block x, separately for the two output rows oi = h % o that dW3 / db3 distinguish.
+constexpr int CPB_RED_CHUNKS = 64;
+__global__ void cpb_partial_kernel(const float* __restrict__ slab, int nwg, int o, int wg_per_head, int H, int chunk,
+                                   float* __restrict__ part_out) {
+  // slabs are ordered (b, h, qtile)
   const int k = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6, nparts = blockDim.x >> 6;
+  const int w0 = blockIdx.y * chunk, w1 = min(w0 + chunk, nwg);
   __shared__ float acc[4][64][2];
   float s0 = 0.f, s1 = 0.f;     // s0: rows with oi == 0 (or shared), s1: oi == 1
   if (k < CPB_SLAB) {
-    for (int w = part; w < nwg; w += nparts) {
+    for (int w = w0 + part; w < w1; w += nparts) {
       const int hh = (w / wg_per_head) % H;
       const int oi = hh % o;
       const float v = slab[(size_t)w * CPB_SLAB + k];
@@ -1126,20 +1197,62 @@ __global__ void cpb_reduce_kernel(const float* __restrict__ slab, int nwg, int o
   if (part == 0 && k < CPB_SLAB) {
     float t0 = 0.f, t1 = 0.f;
     for (int p = 0; p < nparts; ++p) { t0 += acc[p][threadIdx.x][0]; t1 += acc[p][threadIdx.x][1]; }
-    if (k < 1024) dW2[k] = t0 + t1;
-    else if (k < 1024 + 64) {
-      const int ch = (k - 1024) >> 1, comp = (k - 1024) & 1;
-      if (comp < PD) dW1[ch * PD + comp] = t0 + t1;
-    } else if (k < 1024 + 96) db1[k - 1088] = t0 + t1;
-    else if (k < 1024 + 128) db2[k - 1120] = t0 + t1;
-    else if (k < 1024 + 160) {
-      dW3[k - 1152] = t0;
-      if (o > 1) dW3[CH + k - 1152] = t1;
-    } else if (k == 1024 + 160) {
-      db3[0] = t0;
-      if (o > 1) db3[1] = t1;
-    }
+    part_out[((size_t)blockIdx.y * CPB_SLAB + k) * 2 + 0] = t0;
+    part_out[((size_t)blockIdx.y * CPB_SLAB + k) * 2 + 1] = t1;
   }
+}
+// Stage 2: one thread per output adds the chunk partials and scatters into the parameter gradients.
+__global__ void cpb_final_kernel(const float* __restrict__ part_in, int nchunks, int o, float* __restrict__ dW1,
+                                 float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                 float* __restrict__ dW3, float* __restrict__ db3, int PD) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= CPB_SLAB) return;
+  float t0 = 0.f, t1 = 0.f;
+  for (int p = 0; p < nchunks; ++p) {
+    t0 += part_in[((size_t)p * CPB_SLAB + k) * 2 + 0];
+    t1 += part_in[((size_t)p * CPB_SLAB + k) * 2 + 1];
+  }
+  if (k < 1024) dW2[k] = t0 + t1;
+  else if (k < 1024 + 64) {
+    const int ch = (k - 1024) >> 1, comp = (k - 1024) & 1;
+    if (comp < PD) dW1[ch * PD + comp] = t0 + t1;
+  } else if (k < 1024 + 96) db1[k - 1088] = t0 + t1;
+  else if (k < 1024 + 128) db2[k - 1120] = t0 + t1;
+  else if (k < 1024 + 160) {
+    dW3[k - 1152] = t0;
+    if (o > 1) dW3[CH + k - 1152] = t1;
+  } else if (k == 1024 + 160) {
+    db3[0] = t0;
+    if (o > 1) db3[1] = t1;
+  }
+}
+
+// query slices of backward pass 2: enough workgroups to fill the chip a few times over, at most 16 slabs
+static int dkv_parts(int B, int N, int J, int H) {
+  const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+  const long base = (long)nkg * H * B;
+  long parts = (1280 + base / 2) / base;
+  if (parts < 1) parts = 1;
+  if (parts > 16) parts = 16;
+  if (parts > nqt) parts = nqt;
+  return (int)parts;
+}
+// workspace layout (floats): [CPB slabs nwg * CPB_SLAB][64: launch-wide max |dS|][stage-1 partials CHUNKS * CPB_SLAB * 2]
+//                            [dK slabs parts * B*J*H*64][dV slabs parts * B*J*H*64]
+struct BwdWorkspace {
+  size_t slab, gmax, partial, dkp, dvp, total;   // float offsets / total floats
+};
+static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
+  BwdWorkspace w;
+  const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
+  const size_t kv = (size_t)dkv_parts(B, N, J, H) * B * J * H * DH;
+  w.slab = 0;
+  w.gmax = nwg * CPB_SLAB;
+  w.partial = w.gmax + 64;
+  w.dkp = (w.partial + (size_t)CPB_RED_CHUNKS * CPB_SLAB * 2 + 3) & ~(size_t)3;
+  w.dvp = w.dkp + kv;
+  w.total = w.dvp + kv;
+  return w;
 }
 
 static DropCfg make_drop(float p, unsigned long long seed) {
@@ -1176,9 +1289,9 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
   return SMML_OK;
 }
 
-size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int H) {
-  const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
-  return nwg * CPB_SLAB * sizeof(float) + 256;       // + one cache line for the launch-wide max |dS|
+size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H) {
+  if (B <= 0 || N <= 0 || J <= 0 || H <= 0) return 0;
+  return bwd_workspace(B, N, J, H).total * sizeof(float);
 }
 
 static int check_common(const char* fn, int B, int N, int J, int H, int G, int posdim) {
@@ -1232,27 +1345,35 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits_t &&
                    dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
                "smml_deform_attn_bwd_f32: null pointer");
-  SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, H),
+  SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, J, H),
                "smml_deform_attn_bwd_f32: workspace too small (%zu < %zu)", workspace_bytes,
-               smml_deform_attn_bwd_workspace_bytes(B, N, H));
+               smml_deform_attn_bwd_workspace_bytes(B, N, J, H));
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_deform_attn_bwd_f32: workspace must be 16-byte aligned");
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   hipStream_t st = (hipStream_t)stream;
   const int nst = smml_deform_attn_nst(N);
   const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
   dim3 block(256);
   // pass 1: dS^T, dQ (+ the launch-wide max |dS| for the fp16 gradient scale)
-  unsigned* gmax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) +
-                                               (size_t)qtiles * H * B * CPB_SLAB * sizeof(float));
+  const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
+  float* wsf = reinterpret_cast<float*>(workspace);
+  unsigned* gmax = reinterpret_cast<unsigned*>(wsf + wsl.gmax);
   if (hipMemsetAsync(gmax, 0, 256, st) != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
                      dlogits_t, dq, gmax, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
-  // pass 2: dK, dV
+  // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
   {
-    const size_t lds = (size_t)WAVES * 2 * DH * 33 * sizeof(float);   // >= WAVES * 2 * 32 * 64
-    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3((J + KT - 1) / KT, H, B), block, lds, st, q, dout, lse,
-                       logits_t, dlogits_t, dk, dv, N, J, H, nst, scale, dc);
+    const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+    const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
+    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3(nkg * parts, H, B), block, 0, st, q, dout, lse, logits_t,
+                       dlogits_t, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, dc);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dkv");
+    const size_t n4 = (size_t)B * J * H * DH / 4;
+    hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,
+                       reinterpret_cast<const float4*>(wsf + wsl.dkp), reinterpret_cast<const float4*>(wsf + wsl.dvp),
+                       reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts, scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dkv_reduce");
   }
   // pass 3: position-bias MLP backward
   {
@@ -1283,8 +1404,11 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;
-    hipLaunchKernelGGL(cpb_reduce_kernel, dim3((CPB_SLAB + 63) / 64), dim3(256), 0, st, slab, nwg, H / G, dw1, db1,
-                       dw2, db2, dw3, db3, posdim, qtiles, H, G);
+    const int nchunks = min(CPB_RED_CHUNKS, nwg), chunk = (nwg + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(cpb_partial_kernel, dim3((CPB_SLAB + 63) / 64, nchunks), dim3(256), 0, st, slab, nwg, H / G, qtiles,
+                       H, chunk, wsf + wsl.partial);
+    hipLaunchKernelGGL(cpb_final_kernel, dim3((CPB_SLAB + 255) / 256), dim3(256), 0, st, wsf + wsl.partial, nchunks, H / G,
+                       dw1, db1, dw2, db2, dw3, db3, posdim);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/reduce");
   }
   return SMML_OK;

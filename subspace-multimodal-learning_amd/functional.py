@@ -372,7 +372,7 @@ class _DeformAttn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dvs = torch.empty_like(vs)
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
-        wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, heads)
+        wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
         capi.check(L.smml_deform_attn_bwd_f32(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),

@@ -39,6 +39,7 @@ static double checksum(const float* d, size_t n) {
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 4, S = argc > 2 ? atoi(argv[2]) : 100, H = 8, G = 8, PD = 2;
+  const float drop_p = argc > 3 ? (float)atof(argv[3]) : 0.f;
   const int N = S * S, t = (S + 2 - 6) / 4 + 1, J = t * t, HD = H * 64;
   const int nst = smml_deform_attn_nst(N);
   float* q = dev_rand((size_t)B * N * HD, -0.5f, 0.5f, 1);
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
   float* dvs = dev_zero((size_t)B * G * J * PD);
   float* dw1 = dev_zero(64); float* db1 = dev_zero(32); float* dw2 = dev_zero(1024); float* db2 = dev_zero(32);
   float* dw3 = dev_zero(32); float* db3 = dev_zero(4);
-  const size_t wsb = smml_deform_attn_bwd_workspace_bytes(B, N, H);
+  const size_t wsb = smml_deform_attn_bwd_workspace_bytes(B, N, J, H);
   float* ws = dev_zero(wsb / 4 + 4);
   hipEvent_t e0, e1, c0, c1;
   hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&c0); hipEventCreate(&c1);
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
   for (int it = 0; it < reps + 1; ++it) {
     hipEventRecord(e0, 0);
     int rc = smml_deform_attn_fwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, lt, B, N, J, H, G, PD, scale,
-                                      0.f, 0ull, nullptr, nullptr, nullptr);
+                                      drop_p, 77ull, nullptr, nullptr, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("fwd error: %s\n", smml_last_error()); return 1; }
     hipEventSynchronize(e1);
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
     if (it > 0) fwd_ms += ms;
     hipEventRecord(e0, 0);
     rc = smml_deform_attn_bwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, dout, lse, lt, dlt, dq, dk, dv, dvs, dw1,
-                                  db1, dw2, db2, dw3, db3, ws, wsb, B, N, J, H, G, PD, scale, 0.f, 0ull, c0, c1, nullptr);
+                                  db1, dw2, db2, dw3, db3, ws, wsb, B, N, J, H, G, PD, scale, drop_p, 77ull, c0, c1, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("bwd error: %s\n", smml_last_error()); return 1; }
     hipEventSynchronize(e1);
@@ -84,8 +85,8 @@ int main(int argc, char** argv) {
     if (it > 0) { bwd_ms += ms; cpb_ms += cms; }
   }
   fwd_ms /= reps; bwd_ms /= reps; cpb_ms /= reps;
-  printf("%-28s B=%d N=%d J=%d | fwd %7.3f ms %6.1f TF | cpb_bwd %7.3f ms %6.1f TF | bwd total %7.3f ms | chk out %.6e dw2 %.6e dvs %.6e dq %.6e\n",
-         VARIANT, B, N, J, fwd_ms, pairs * 2496 / (fwd_ms * 1e-3) / 1e12, cpb_ms, pairs * 4480 / (cpb_ms * 1e-3) / 1e12, bwd_ms,
+  printf("%-28s B=%d N=%d J=%d p=%.2f | fwd %7.3f ms %6.1f TF | cpb_bwd %7.3f ms %6.1f TF | bwd total %7.3f ms | chk out %.6e dw2 %.6e dvs %.6e dq %.6e\n",
+         VARIANT, B, N, J, drop_p, fwd_ms, pairs * 2496 / (fwd_ms * 1e-3) / 1e12, cpb_ms, pairs * 4480 / (cpb_ms * 1e-3) / 1e12, bwd_ms,
          checksum(out, (size_t)B * N * HD), checksum(dw2, 1024), checksum(dvs, (size_t)B * G * J * PD),
          checksum(dq, (size_t)B * N * HD));
 #ifdef SMML_STAMPS

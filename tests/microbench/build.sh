@@ -7,8 +7,6 @@ build() { # name, flags...
   local name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
-build rot_w1
-build rot_w1_stamps -DSMML_STAMPS
-build rot_w2 -DSMML_BWD_WPS=2
+build base
 wait
 ls bin

@@ -63,7 +63,7 @@ def test_reference_interface_is_kept():
         assert sig[k].default == d
     assert list(inspect.signature(smml.DeformCrossAttention2D.forward).parameters)[1:] == ["x1", "x2", "return_vgrid"]
     assert list(inspect.signature(smml.DeformCrossTransMIL.forward).parameters)[1:] == ["path", "omic"]
-    assert list(inspect.signature(smml.BatchLoss.__init__).parameters)[1:] == ["batch_size", "world_size"]
+    assert list(inspect.signature(smml.BatchLoss.__init__).parameters)[1:3] == ["batch_size", "world_size"]   # + additive use_tile_hint
     m2 = smml.DeformCrossAttention2D(dim=128)
     shapes = {k: tuple(v.shape) for k, v in m2.state_dict().items()}
     assert shapes["to_offsets.0.weight"] == (64, 1, 6, 6) and shapes["to_offsets.2.weight"] == (2, 64, 1, 1)
