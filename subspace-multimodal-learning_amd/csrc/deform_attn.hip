@@ -27,22 +27,10 @@
 #ifndef SMML_FWD_WPS
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
-#ifndef SMML_BWD_WPS
-#define SMML_BWD_WPS 1      // same for the position-bias backward kernel (1: its per-channel constants live in VGPRs)
-#endif
 #ifndef SMML_CPB_F16
 #define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
                             //    (W = Wh + Wl, h1 = hh + hl; Wh hh + Wh hl + Wl hh, ~22 mantissa bits) that overlaps the
                             //    VALU; 0: exact fp32 v_mfma_f32_32x32x2_f32 (shares the fp32 ALUs with the VALU)
-#endif
-#ifndef SMML_CPB_BWD_F16
-#define SMML_CPB_BWD_F16 0  // same for the position-bias backward kernel.  Off: measured slower on MI355X (17.6 vs 15.4 ms at
-                            // B = 4, N = 10 000: operand splits + 64 ds_write_b16 per chain cost more VALU / LDS issue than the
-                            // 48 f32 MFMAs they replace) and, with one launch-wide power-of-two gradient scale, fp16's
-                            // exponent range loses the small d bias values (dW2 off by 4e-4); kept for further tuning
-#endif
-#ifndef SMML_BWD_UNROLL
-#define SMML_BWD_UNROLL 1   // keys per loop trip of the position-bias backward (2 gives the scheduler a second, independent key)
 #endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
@@ -211,7 +199,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     t.w = 0.f;
     tabB[tid] = t;
   }
-  const float4* tb = tabB + 16 * hf;
 #if SMML_CPB_F16
   // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = 16 kb + 8 hf + j
   half8 w2h[2], w2m[2], w2l[2];
@@ -288,7 +275,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 #else
 #pragma unroll
       for (int sp = 0; sp < 16; ++sp) {
-        const float4 t = tb[sp];
+        const float4 t = tabB[16 * hf + sp];
         float hv = fmaf(t.x, p0, t.z);
         if (PD == 2) hv = fmaf(t.y, p1, hv);
         d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
@@ -385,7 +372,7 @@ __device__ __forceinline__ float prob_bias(float lse) { return -lse; }
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
-    float* __restrict__ dLT, float* __restrict__ dQ, unsigned* __restrict__ gmax, int N, int J, int H, int NST,
+    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST,
     float scale, DropCfg dc) {
   __shared__ __attribute__((aligned(16))) float Vr[2][KT][VLD];   // A operand of dP^T = V . dO^T
   __shared__ __attribute__((aligned(16))) float Kt[2][DH][KLD];   // A operand of dQ^T = K^T . dS^T
@@ -415,7 +402,6 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
 
   floatx16 dq0 = {0}, dq1 = {0};
-  float amax = 0.f;                                  // max |dS| of this lane (feeds the fp16 gradient scale)
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
@@ -482,7 +468,6 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         float dpr = dp[r];
         if (dc.thresh) dpr *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qi) * J) + j0 + key);
         v = p * (dpr - delta);
-        amax = fmaxf(amax, fabsf(v));
         dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
       }
       ds[r] = v;
@@ -497,11 +482,6 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       dq0 = mfma32(a0.z, ds[4 * rg + 2], dq0); dq1 = mfma32(a1.z, ds[4 * rg + 2], dq1);
       dq0 = mfma32(a0.w, ds[4 * rg + 3], dq0); dq1 = mfma32(a1.w, ds[4 * rg + 3], dq1);
     }
-  }
-  if (gmax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (lane == 0 && amax > 0.f) atomicMax(gmax, __float_as_uint(amax));   // non-negative floats order as uints
   }
   if (qvalid) {
     float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
@@ -646,23 +626,66 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward of the continuous position bias: given dS^T (= d bias) recompute the MLP per
-// (key, 32 queries) chain and accumulate
-//   dW3, db3, db2, dW1, db1 : per-lane partial sums in registers (reduced once at the end)
-//   dW2 [out, in]           : matrix-core contraction over the 32 queries of a chain (dD^T via LDS)
-//   d vs [b*g, key, PD]     : LDS accumulator per workgroup, flushed with float atomics
-// Per-workgroup partials go to a slab [numWG][CPB_SLAB] that cpb_reduce_kernel sums (deterministic).
+// backward of the continuous position bias: given dS^T (= d bias) recompute the MLP per (key, 32 queries) and
+// accumulate dW1, db1, dW2, db2, dW3, db3 and d vs.  Every 32x32 contraction runs on the 16-bit matrix pipe
+// (which, unlike v_mfma_f32_32x32x2_f32, does not share the fp32 ALUs with the vector work); the two register
+// layouts an MFMA can deliver are both used so that no operand is transposed through LDS:
+//
+//   "query-major"   lane = query, registers = channels        "channel-major"  lane = channel, registers = queries
+//   D   = W2 h1 + b2   (chain X, mask of layer 2)              D^T = h1^T W2^T    (chain Y: the SAME operand
+//   dh1 = (W2 w3)^T (mask . d bias)   (chain 2)                      registers, A and B swapped)
+//   layer-1 backward, d vs                                      db2, dW3: two scalars per lane
+//                                                               dW2 = w3 . mask^T g,  g = h1 . d bias
+//
+// Accuracy: chains X / Y / 2 are split-fp16 products (constant operand = hi + mid + lo exactly, activation =
+// hi + lo, 5 MFMAs per K-block, <= 2^-22 relative); chain 2's activation is d bias itself, scaled per lane by the
+// power of two that brings it into [1, 2) (exact, un-scaled on the result).  dW2 multiplies the exact 0 / 1 mask
+// with g split into three bf16 terms (fp32's exponent range, residual <= 2^-24): fp32-accurate without scaling.
+// h1 reaches the channel-major side through the matrix pipe as well (h1 . I = h1^T in accumulator layout), d bias
+// through a 128-byte LDS broadcast tile.  Per-lane partial sums are reduced per workgroup into a slab
+// [numWG][CPB_SLAB] that two small kernels add up in a fixed order (deterministic).
 // slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
 // ------------------------------------------------------------------------------------------------
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
-constexpr int CPB_WAVE_LDS = 2 * 32 * 33 + 2 * 32 * 65 + 8;   // floats of LDS per wave of cpb_bwd_kernel (multiple of 4)
+constexpr int CPB_XQ = 2 * 32;                            // double-buffered d bias of the wave's 32 queries
+constexpr int CPB_WAVE_LDS = CPB_XQ + 2 * 32 * 65;        // + staging tile of the d vs partials; multiple of 4
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// x = a + b + c with three bf16 terms (round-to-nearest each): residual <= 2^-24 |x|, fp32's exponent range
+__device__ __forceinline__ void split8_bf3(const float (&x)[8], bf16x8& a, bf16x8& b, bf16x8& c) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2v v = {x[2 * i], x[2 * i + 1]};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const float2v r1 = {v[0] - (float)h[0], v[1] - (float)h[1]};
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const float2v r2 = {r1[0] - (float)m[0], r1[1] - (float)m[1]};
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    a[2 * i] = h[0]; a[2 * i + 1] = h[1];
+    b[2 * i] = m[0]; b[2 * i + 1] = m[1];
+    c[2 * i] = l[0]; c[2 * i + 1] = l[1];
+  }
+}
+// D += h . W with the split ACTIVATION as the A operand (transposed product of mfma16_split)
+__device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh, half8 wm, half8 wl, floatx16 d) {
+  d = mfma16(bh, wl, d);
+  d = mfma16(bl, wm, d);
+  d = mfma16(bh, wm, d);
+  d = mfma16(bl, wh, d);
+  return mfma16(bh, wh, d);
+}
 
 template <int PD>
-__global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
+__global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
     float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: tab[32] float4 {w1x, w1y, b1, b2} | w3tab[32] | dvs[J*2] | per wave: dDl[32][33], h1l[32][33] | red[CPB_SLAB]
+  // layout: dvs[J*2, padded to 4] | per wave: xq[2][32], stg[32][65] float2 | red[CPB_SLAB]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
@@ -670,56 +693,34 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
 
-  float4* tab = reinterpret_cast<float4*>(smem);            // per hidden channel
-  float* w3tab = smem + 128;
-  float* dvs = smem + 160;                                  // [J][2]
+  float* dvs = smem;                                        // [J][2]
   float* wbase = dvs + ((2 * J + 3) & ~3);
-  float* dDl = wbase + wave * CPB_WAVE_LDS;                 // [32 out][33]   d D of the current key
-  float* h1l = dDl + 32 * 33;                               // [32 in][33]    h1 of the current key
-  float2* stg = reinterpret_cast<float2*>(h1l + 32 * 33);   // [32 keys][65]  per-lane d vs partials of the last <= 32 keys
+  float* xq = wbase + wave * CPB_WAVE_LDS;                  // [2][32]
+  float2* stg = reinterpret_cast<float2*>(xq + CPB_XQ);     // [32 keys][65]  per-lane d vs partials of the last <= 32 keys
   for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
-  if (tid < 32) {
-    float4 t;
-    t.x = cp.w1[tid * PD];
-    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
-    t.z = cp.b1[tid];
-    t.w = cp.b2[tid];
-    tab[tid] = t;
-    w3tab[tid] = cp.w3[oi * CH + tid];
-  }
+
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
-#if SMML_BWD_WPS == 1
-  // one wave per SIMD (512-register budget): the per-channel constants of this lane's 16 channels live in VGPRs,
-  // the loop's only LDS traffic is the two operand transposes
-  float cw1x[16], cw1y[16], cb1[16], cb2[16], cw3[16];
+
+  // query-major constants: this lane evaluates layer 1 for the 16 channels ch(r) = acc_row(r, hf); operand slot
+  // (K-block kb, element j) <-> channel ch(8 kb + j), i.e. the channels a lane feeds into chains X / Y / 2 are the
+  // accumulator rows chains X and 2 hand back to it (ReLU masks straight from registers)
+  float cw1x[16], cw1y[16], cb1[16];
+  floatx16 b2x;                                             // initial accumulator of chain X
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = acc_row(r, hf);
     cw1x[r] = cp.w1[ch * PD];
     cw1y[r] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
     cb1[r] = cp.b1[ch];
-    cb2[r] = cp.b2[ch];
-    cw3[r] = cp.w3[oi * CH + ch];
+    b2x[r] = cp.b2[ch];
   }
-#define CW1X(r) cw1x[r]
-#define CW1Y(r) cw1y[r]
-#define CB1(r) cb1[r]
-#define CB2(r) cb2[r]
-#define CW3(r) cw3[r]
-#else
-#define CW1X(r) tab[acc_row(r, hf)].x
-#define CW1Y(r) tab[acc_row(r, hf)].y
-#define CB1(r) tab[acc_row(r, hf)].z
-#define CB2(r) tab[acc_row(r, hf)].w
-#define CW3(r) w3tab[acc_row(r, hf)]
-#endif
+  // channel-major constants: one channel per lane
+  const float nb2c = -cp.b2[c];
+  const float w3c = cp.w3[oi * CH + c];
 
-  // Operand slots: chain 1 feeds channel acc_row(8 kb + j, hf) in K-block kb / element j, i.e. the 16 channels a
-  // lane evaluates layer 1 for are the 16 accumulator rows chain 2 hands back to it: the ReLU masks of the
-  // layer-1 backward are the hv registers, one constant table serves both.
-  half8 w2h[2], w2m[2], w2l[2];                             // W2[out = c][in = acc_row(8 kb + j, hf)], fp16 hi / mid / lo
-  half8 w2th[2], w2tm[2], w2tl[2];                          // W2[out = acc_row(8 kb + j, hf)][in = c]  (A operand of dh1 = W2^T dD)
+  half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
+  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     float a[8], t[8];
@@ -727,17 +728,24 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
     for (int j = 0; j < 8; ++j) {
       const int ch = acc_row(8 * kb + j, hf);
       a[j] = cp.w2[c * CH + ch];
-      t[j] = cp.w2[ch * CH + c];
+      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
     }
     split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
     split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
   }
-
-  floatx16 e = {0};                                         // dW2[out rows][in cols]
-  float aw3[16], ab2[16], aw1x[16], aw1y[16], ab1[16];
+  // identity as a B operand: h1 (operand layout, lane = query) . I = h1^T in accumulator layout (lane = channel) -
+  // the matrix pipe transposes the activations for the dW2 product
+  half8 idb[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { aw3[r] = 0.f; ab2[r] = 0.f; aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
-  float ab3 = 0.f;
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) idb[kb][j] = (acc_row(8 * kb + j, hf) == c) ? (_Float16)1.0f : (_Float16)0.0f;
+
+  floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
+  float aw1x[16], aw1y[16], ab1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
+  float ab3 = 0.f, s1 = 0.f, s2 = 0.f;   // s1 = sum D^T . masked d bias, s2 = sum masked d bias (channel-major lane)
 
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
@@ -751,8 +759,7 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   SMML_STAMP_DECL
 
   // The loop is rotated by one key: the layer-1 backward of key j-1 (which consumes chain 2's result) is issued
-  // right after chain 1 of key j, so both 10-MFMA fp16 chains (~320 cycles each) complete behind vector work
-  // instead of stalling the in-order wave.  State of the previous key:
+  // while the chains of key j are in flight.  State of the previous key:
   float hv_p[16];
   floatx16 dh_p = {0};
   float p0_p = 0.f, p1_p = 0.f, d0_p = 0.f, d1_p = 0.f, isc_p = 0.f;
@@ -769,10 +776,10 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       const float g1 = (hvk[r] > 0.f) ? dhk[r] * isck : 0.f;
       ab1[r] += g1;
       aw1x[r] = fmaf(g1, p0k, aw1x[r]);
-      dp0 = fmaf(g1, CW1X(r), dp0);
+      dp0 = fmaf(g1, cw1x[r], dp0);
       if (PD == 2) {
         aw1y[r] = fmaf(g1, p1k, aw1y[r]);
-        dp1 = fmaf(g1, CW1Y(r), dp1);
+        dp1 = fmaf(g1, cw1y[r], dp1);
       }
     }
     float2 v;
@@ -812,19 +819,19 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
     const float d0 = gq0 - vx, d1 = gq1 - vy;
     const float p0 = slog1p(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
+    // publish this query's d bias for the channel-major stage (one wave: LDS is in order, no barrier)
+    float* xb = xq + (j & 1) * 32;
+    if (hf == 0) xb[c] = dbias;
 
-    // phase 1 - layer 1 for this lane's 16 channels (kept in registers, parked transposed in LDS for phase 3) and
-    // the recompute chain D = W2 h1 as a split-fp16 product on the 16-bit matrix pipe (overlaps the VALU)
+    // ---- query-major: layer 1 for this lane's 16 channels, chains X and Y on the same operand registers ----
     float hv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ch = acc_row(r, hf);
-      float x = fmaf(CW1X(r), p0, CB1(r));
-      if (PD == 2) x = fmaf(CW1Y(r), p1, x);
+      float x = fmaf(cw1x[r], p0, cb1[r]);
+      if (PD == 2) x = fmaf(cw1y[r], p1, x);
       hv[r] = fmaxf(x, 0.f);
-      h1l[ch * 33 + c] = hv[r];
     }
-    floatx16 d = {0};
+    floatx16 dx = b2x, dy = {0}, ht = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float x8[8];
@@ -832,52 +839,81 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
       for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
       half8 bh, bl;
       split8(x8, bh, bl);
-      d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
+      dx = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, dx);       // D[out = ch(r)][query = c] (+ b2)
+      dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
+      ht = mfma16(bl, idb[kb], ht);                                   // h1^T[query = acc_row(r, hf)][in = c]
+      ht = mfma16(bh, idb[kb], ht);
     }
     SMML_STAMP(1)
-    // previous key: layer-1 backward while chain 1 of this key is in flight (no-op data for j = 0)
+    // previous key: layer-1 backward while the chains of this key are in flight (no-op data for j = 0)
     if (j > 0) layer1_bwd(j - 1, hv_p, dh_p, p0_p, p1_p, d0_p, d1_p, isc_p);
     SMML_STAMP(2)
-    // phase 2 - layer-3 backward, then dh1[in, query] = W2^T . dD as a split-fp16 product.  d bias spans many
-    // binades across queries, so each lane (= query = one column of the product) scales its column by the power of
-    // two that brings |d bias| into [1, 2) and un-scales its column of the result - exact, and fp16-range safe.
+
+    // ---- channel-major: lane = channel c, registers r <-> query acc_row(r, hf) ----
+    float dbq[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
+      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
+    }
+    // g[in = c][query] = h1 . d bias, three bf16 terms (B operand of the dW2 product)
+    bf16x8 g1[2], g2[2], g3[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float g8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) g8[jx] = ht[8 * t + jx] * dbq[8 * t + jx];
+      split8_bf3(g8, g1[t], g2[t], g3[t]);
+    }
+    // layer-2 mask of channel c for the 16 queries (exact 0 / 1 A operand), db2 and dW3 as two scalars
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 am;
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) {
+        const int r = 8 * t + jx;
+        const bool on = dy[r] > nb2c;
+        const float dbm = on ? dbq[r] : 0.f;
+        s2 += dbm;
+        s1 = fmaf(dy[r], dbm, s1);
+        am[jx] = on ? (__bf16)1.0f : (__bf16)0.0f;
+      }
+      e = mfma16b(am, g3[t], e);
+      e = mfma16b(am, g2[t], e);
+      e = mfma16b(am, g1[t], e);
+    }
+    SMML_STAMP(3)
+
+    // ---- query-major: dh1[in, query] = (W2 w3)^T . (mask . d bias).  d bias spans many binades across queries, so
+    // each lane (= query = one column of the product) scales its column by the power of two that brings |d bias|
+    // into [1, 2) and un-scales its column of the result - exact, and fp16-range safe.  Every non-zero element of the
+    // lane's operand is that one scaled value: split once, select by mask.
     float sc = 1.f, isc = 1.f;
     {
       const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
       if (eb != 0u && eb != 255u) { sc = __uint_as_float((254u - eb) << 23); isc = __uint_as_float(eb << 23); }
     }
     const float dbs = dbias * sc;
+    const _Float16 shh = (_Float16)dbs;
+    const _Float16 sll = (_Float16)(dbs - (float)shh);
+    const unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
+    const unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
     floatx16 dh = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      float g8[8];
+      uint4v ghw, glw;
 #pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-        const int r = 8 * kb + jx, ch = acc_row(r, hf);
-        const float h2 = fmaxf(d[r] + CB2(r), 0.f);
-        aw3[r] = fmaf(dbias, h2, aw3[r]);
-        const float g2s = (h2 > 0.f) ? dbs * CW3(r) : 0.f;
-        const float g2 = g2s * isc;
-        ab2[r] += g2;
-        dDl[ch * 33 + c] = g2;
-        g8[jx] = g2s;
+      for (int p = 0; p < 4; ++p) {
+        const int r = 8 * kb + 2 * p;
+        const unsigned pm = ((dx[r] > 0.f) ? 0x0000FFFFu : 0u) | ((dx[r + 1] > 0.f) ? 0xFFFF0000u : 0u);
+        ghw[p] = sh2 & pm;
+        glw[p] = sl2 & pm;
       }
-      half8 gh, gl;
-      split8(g8, gh, gl);
+      const half8 gh = __builtin_bit_cast(half8, ghw), gl = __builtin_bit_cast(half8, glw);
       dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
-    SMML_STAMP(3)
-    asm volatile("" ::: "memory");     // LDS of one wave is in order; only the compiler must not reorder
-    // phase 3 - dW2[out, in] += sum_query dD[out, query] h1[in, query] on the fp32 matrix cores: both operands
-    // come transposed out of LDS (A[i = out = c][k = query], B[k = query][j = in = c], query = 16 hf + s)
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      const int qq = 16 * hf + s2;
-      e = mfma32(dDl[c * 33 + qq], h1l[c * 33 + qq], e);
-    }
     SMML_STAMP(4)
-    asm volatile("" ::: "memory");
     // rotate
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv_p[r] = hv[r];
@@ -890,20 +926,15 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   float* red = wbase + WAVES * CPB_WAVE_LDS;                // [CPB_SLAB] accumulators in LDS
   for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
   __syncthreads();
+  // channel-major scalars: both halves of the wave hold partial sums (their 16 queries each) of channel c
+  atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2);                       // db2[c] = w3[c] sum mask . d bias
+  atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2, s1));       // dW3[c] = sum relu(D + b2) . d bias
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, hf);
-    atomicAdd(&red[row * CH + c], e[r]);                    // dW2[out = row][in = c]
+    atomicAdd(&red[row * CH + c], e[r] * cp.w3[oi * CH + row]);        // dW2[out = row][in = c]
     // per-channel partials: sum over the 32 query lanes of this half
     float v;
-    v = aw3[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
-    v = ab2[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + row], v);
     v = ab1[r];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -931,244 +962,6 @@ __global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_kernel(
   for (int i = tid; i < J * PD; i += 256) {
     const int j = i / PD, comp = i - j * PD;
     atomicAdd(&dVSb[i], dvs[2 * j + comp]);
-  }
-}
-
-
-#undef CW1X
-#undef CW1Y
-#undef CB1
-#undef CB2
-#undef CW3
-
-// power-of-two S with gmax * S in [2^9, 2^10): fp16 headroom for |w3| up to 64, full precision down to 2^-24 gmax
-__device__ __forceinline__ float grad_scale_from_max(unsigned gbits) {
-  const float gm = __uint_as_float(gbits);
-  if (!(gm > 0.f) || gm > 3.0e38f) return 1.f;
-  int e;
-  (void)frexpf(gm, &e);
-  return ldexpf(1.f, 10 - e);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Position-bias backward with the three 32x32 contractions on the 16-bit matrix pipe (v_mfma_f32_32x32x16_f16)
-// as split-fp16 products (x = hi + lo, three MFMAs per K-block: hi hi + hi lo + lo hi, ~22 mantissa bits).  The
-// matrix pipe then runs beside the VALU instead of sharing the fp32 ALUs with it.  The incoming gradients d bias
-// are multiplied by one power of two S (from the launch-wide max |dS| that pass 1 records) so that they sit in
-// fp16's normal range; every accumulator carries S and is divided by it once when it leaves the kernel.
-// Channel <-> operand slot: K-block kb, element j of a lane in half hf <-> channel acc_row(8 kb + j, hf), i.e. the
-// 16 channels a lane feeds into chain 1 are the 16 accumulator rows it receives from chain 2 - one set of layer-1
-// constants, and the ReLU masks come from registers.
-// ------------------------------------------------------------------------------------------------
-constexpr int HLD = 40;          // LDS row stride (halfs) of the [32][32] fp16 operand tiles: 80 B rows, conflict-free b128 reads
-template <int PD>
-__global__ __launch_bounds__(256, SMML_BWD_WPS) void cpb_bwd_f16_kernel(
-    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
-    float* __restrict__ slab, float* __restrict__ dVS, const unsigned* __restrict__ gmax, int N, int J, int H, int G,
-    int NST) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: tab[32] float4 {w1x, w1y, b1, b2} | w3tab[32] | dvs[2 J] | per wave 4 x [32][HLD] halfs | red[CPB_SLAB]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
-  const int o = H / G, g = h / o, oi = h - g * o;
-  const bool qvalid = (q0 + c) < N;
-  const int qi = qvalid ? (q0 + c) : (N - 1);
-
-  float4* tab = reinterpret_cast<float4*>(smem);
-  float* w3tab = smem + 128;
-  float* dvs = smem + 160;
-  float* wbase = dvs + ((2 * J + 3) & ~3);
-  _Float16* tiles = reinterpret_cast<_Float16*>(wbase) + wave * (4 * 32 * HLD);
-  _Float16* Ah = tiles;                 // dD  hi  [out][query]
-  _Float16* Al = tiles + 32 * HLD;      // dD  lo
-  _Float16* Bh = tiles + 2 * 32 * HLD;  // h1  hi  [in][query]
-  _Float16* Bl = tiles + 3 * 32 * HLD;  // h1  lo
-  float* red = wbase + WAVES * (4 * 32 * HLD) / 2;
-  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
-  if (tid < 32) {
-    float4 t;
-    t.x = cp.w1[tid * PD];
-    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
-    t.z = cp.b1[tid];
-    t.w = cp.b2[tid];
-    tab[tid] = t;
-    w3tab[tid] = cp.w3[oi * CH + tid];
-  }
-  const float S = grad_scale_from_max(*gmax);
-  const float invS = 1.f / S;
-  const float gq0 = GQ[(size_t)qi * PD];
-  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
-
-  // W2 as A operand of chain 1 (rows = out = c, k = in) and of chain 2 (rows = in = c, k = out), split in hi / lo
-  half8 w2h[2], w2l[2], w2th[2], w2tl[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float a[8], t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = acc_row(8 * kb + j, hf);
-      a[j] = cp.w2[c * CH + ch];
-      t[j] = cp.w2[ch * CH + c];
-    }
-    split8(a, w2h[kb], w2l[kb]);
-    split8(t, w2th[kb], w2tl[kb]);
-  }
-
-  floatx16 e = {0};
-  float aw3[16], ab2[16], aw1x[16], aw1y[16], ab1[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { aw3[r] = 0.f; ab2[r] = 0.f; aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
-  float ab3 = 0.f;
-
-  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
-  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
-  __syncthreads();
-
-  float vx_n = VSb[0];
-  float vy_n = (PD == 2) ? VSb[1] : 0.f;
-  float db_n = qvalid ? dLTb[q0 + c] : 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float vx = vx_n, vy = vy_n, dbs = db_n * S;
-    if (j + 1 < J) {
-      vx_n = VSb[(size_t)(j + 1) * PD];
-      if (PD == 2) vy_n = VSb[(size_t)(j + 1) * PD + 1];
-      db_n = qvalid ? dLTb[(size_t)(j + 1) * NST + q0 + c] : 0.f;
-    }
-    const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = slog1p(d0);
-    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
-
-    // phase 1: h1 for this lane's 16 channels, split, parked in LDS for chain 3, chain 1: D = W2 h1
-    float hv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 t = tab[acc_row(r, hf)];
-      float x = fmaf(t.x, p0, t.z);
-      if (PD == 2) x = fmaf(t.y, p1, x);
-      hv[r] = fmaxf(x, 0.f);
-    }
-    floatx16 d = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float x8[8];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
-      half8 bh, bl;
-      split8(x8, bh, bl);
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-        Bh[acc_row(8 * kb + jx, hf) * HLD + c] = bh[jx];
-        Bl[acc_row(8 * kb + jx, hf) * HLD + c] = bl[jx];
-      }
-      d = mfma16(w2h[kb], bh, d);
-      d = mfma16(w2h[kb], bl, d);
-      d = mfma16(w2l[kb], bh, d);
-    }
-    // phase 2: layer-3 backward (scaled by S), chain 2: dh1 = W2^T dD
-    floatx16 dh = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float g8[8];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-        const int r = 8 * kb + jx, ch = acc_row(r, hf);
-        const float h2 = fmaxf(d[r] + tab[ch].w, 0.f);
-        aw3[r] = fmaf(dbs, h2, aw3[r]);
-        const float g2 = (h2 > 0.f) ? dbs * w3tab[ch] : 0.f;
-        ab2[r] += g2;
-        g8[jx] = g2;
-      }
-      half8 gh, gl;
-      split8(g8, gh, gl);
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-        Ah[acc_row(8 * kb + jx, hf) * HLD + c] = gh[jx];
-        Al[acc_row(8 * kb + jx, hf) * HLD + c] = gl[jx];
-      }
-      dh = mfma16(w2th[kb], gh, dh);
-      dh = mfma16(w2th[kb], gl, dh);
-      dh = mfma16(w2tl[kb], gh, dh);
-    }
-    ab3 += (hf == 0) ? dbs : 0.f;
-    asm volatile("" ::: "memory");
-    // phase 3: dW2[out, in] += sum_query dD[out, query] h1[in, query]  (both operands from the LDS tiles)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int off = c * HLD + 16 * kb + 8 * hf;
-      const half8 ah = *reinterpret_cast<const half8*>(Ah + off), al = *reinterpret_cast<const half8*>(Al + off);
-      const half8 bh = *reinterpret_cast<const half8*>(Bh + off), bl = *reinterpret_cast<const half8*>(Bl + off);
-      e = mfma16(ah, bh, e);
-      e = mfma16(ah, bl, e);
-      e = mfma16(al, bh, e);
-    }
-    // layer-1 backward on the accumulator rows of dh1 (= the channels of hv)
-    float dp0 = 0.f, dp1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 t = tab[acc_row(r, hf)];
-      const float g1 = (hv[r] > 0.f) ? dh[r] : 0.f;
-      ab1[r] += g1;
-      aw1x[r] = fmaf(g1, p0, aw1x[r]);
-      dp0 = fmaf(g1, t.x, dp0);
-      if (PD == 2) {
-        aw1y[r] = fmaf(g1, p1, aw1y[r]);
-        dp1 = fmaf(g1, t.y, dp1);
-      }
-    }
-    {
-      float t0 = wave_sum(-dp0 * srcp(fabsf(d0) + 1.f));
-      if (lane == 0) atomicAdd(&dvs[2 * j], t0);
-      if (PD == 2) {
-        float t1 = wave_sum(-dp1 * srcp(fabsf(d1) + 1.f));
-        if (lane == 0) atomicAdd(&dvs[2 * j + 1], t1);
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-
-  // ---- workgroup reduction of the per-lane partials -> slab[wg] (un-scaled by 1 / S) ----
-  __syncthreads();
-  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, hf);
-    atomicAdd(&red[row * CH + c], e[r]);
-    float v;
-    v = aw3[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
-    v = ab2[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + row], v);
-    v = ab1[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
-    v = aw1x[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
-    v = aw1y[r];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
-  }
-  {
-    float v = wave_sum(ab3);
-    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
-  }
-  __syncthreads();
-  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  float* sl = slab + (size_t)wg * CPB_SLAB;
-  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i] * invS;
-  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
-  for (int i = tid; i < J * PD; i += 256) {
-    const int jj = i / PD, comp = i - jj * PD;
-    atomicAdd(&dVSb[i], dvs[2 * jj + comp] * invS);
   }
 }
 
@@ -1237,18 +1030,17 @@ static int dkv_parts(int B, int N, int J, int H) {
   if (parts > nqt) parts = nqt;
   return (int)parts;
 }
-// workspace layout (floats): [CPB slabs nwg * CPB_SLAB][64: launch-wide max |dS|][stage-1 partials CHUNKS * CPB_SLAB * 2]
+// workspace layout (floats): [CPB slabs nwg * CPB_SLAB][stage-1 partials CHUNKS * CPB_SLAB * 2]
 //                            [dK slabs parts * B*J*H*64][dV slabs parts * B*J*H*64]
 struct BwdWorkspace {
-  size_t slab, gmax, partial, dkp, dvp, total;   // float offsets / total floats
+  size_t slab, partial, dkp, dvp, total;   // float offsets / total floats
 };
 static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   BwdWorkspace w;
   const size_t nwg = (size_t)B * H * ((N + QT * WAVES - 1) / (QT * WAVES));
   const size_t kv = (size_t)dkv_parts(B, N, J, H) * B * J * H * DH;
   w.slab = 0;
-  w.gmax = nwg * CPB_SLAB;
-  w.partial = w.gmax + 64;
+  w.partial = nwg * CPB_SLAB;
   w.dkp = (w.partial + (size_t)CPB_RED_CHUNKS * CPB_SLAB * 2 + 3) & ~(size_t)3;
   w.dvp = w.dkp + kv;
   w.total = w.dvp + kv;
@@ -1354,13 +1146,11 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   const int nst = smml_deform_attn_nst(N);
   const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
   dim3 block(256);
-  // pass 1: dS^T, dQ (+ the launch-wide max |dS| for the fp16 gradient scale)
+  // pass 1: dS^T, dQ
   const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
   float* wsf = reinterpret_cast<float*>(workspace);
-  unsigned* gmax = reinterpret_cast<unsigned*>(wsf + wsl.gmax);
-  if (hipMemsetAsync(gmax, 0, 256, st) != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
-                     dlogits_t, dq, gmax, N, J, H, nst, scale, dc);
+                     dlogits_t, dq, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
   // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
   {
@@ -1380,18 +1170,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
     if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
     float* slab = (float*)workspace;
-#if SMML_CPB_BWD_F16
-    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * (4 * 32 * HLD) / 2 + CPB_SLAB) * sizeof(float);
-    SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
-    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
-    if (posdim == 2)
-      hipLaunchKernelGGL(cpb_bwd_f16_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
-                         gmax, N, J, H, G, nst);
-    else
-      hipLaunchKernelGGL(cpb_bwd_f16_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs,
-                         gmax, N, J, H, G, nst);
-#else
-    const size_t lds = ((size_t)160 + ((2 * J + 3) & ~3) + WAVES * CPB_WAVE_LDS + CPB_SLAB) * sizeof(float);
+    const size_t lds = ((size_t)((2 * J + 3) & ~3) + WAVES * CPB_WAVE_LDS + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
@@ -1400,7 +1179,6 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
                          J, H, G, nst);
-#endif
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;

@@ -93,8 +93,8 @@ int main(int argc, char** argv) {
   {
     float st[5];
     hipMemcpy(st, ws + 1186, sizeof(st), hipMemcpyDeviceToHost);
-    printf("    cycles per key (wave 0 of WG 0): [4->0 loop/prefetch] %.0f  [0->1 layer1 + chain1 issue] %.0f  [1->2 layer3 bwd + chain2] %.0f  "
-           "[2->3 dW2 chain + layer1 bwd] %.0f  [3->4 d vs] %.0f  total %.0f\n", st[0], st[1], st[2], st[3], st[4],
+    printf("    cycles per key (wave 0 of WG 0): [4->0 loop/prefetch] %.0f  [0->1 layer 1 + chains X/Y/T issue] %.0f  [1->2 layer-1 bwd of the previous key] %.0f  "
+           "[2->3 channel-major stage + dW2] %.0f  [3->4 chain 2] %.0f  total %.0f\n", st[0], st[1], st[2], st[3], st[4],
            st[0] + st[1] + st[2] + st[3] + st[4]);
   }
 #endif

@@ -8,5 +8,6 @@ build() { # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
 build base
+build stamps -DSMML_STAMPS
 wait
 ls bin
