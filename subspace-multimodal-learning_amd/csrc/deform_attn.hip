@@ -62,7 +62,7 @@ namespace {
 #if SMML_FAST_MATH
 __device__ __forceinline__ float slog1p(float d) { return copysignf(__logf(fabsf(d) + 1.0f), d); }
 __device__ __forceinline__ float sexp(float x) { return __expf(x); }
-__device__ __forceinline__ float srcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float srcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
 __device__ __forceinline__ float slog1p(float d) { return signed_log1p(d); }
 __device__ __forceinline__ float sexp(float x) { return expf(x); }
@@ -705,14 +705,14 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
   // query-major constants: this lane evaluates layer 1 for the 16 channels ch(r) = acc_row(r, hf); operand slot
   // (K-block kb, element j) <-> channel ch(8 kb + j), i.e. the channels a lane feeds into chains X / Y / 2 are the
   // accumulator rows chains X and 2 hand back to it (ReLU masks straight from registers)
-  float cw1x[16], cw1y[16], cb1[16];
+  float2v cw1x[8], cw1y[8], cb1[8];                        // channel pairs (registers 2 p, 2 p + 1)
   floatx16 b2x;                                             // initial accumulator of chain X
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = acc_row(r, hf);
-    cw1x[r] = cp.w1[ch * PD];
-    cw1y[r] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
-    cb1[r] = cp.b1[ch];
+    cw1x[r >> 1][r & 1] = cp.w1[ch * PD];
+    cw1y[r >> 1][r & 1] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    cb1[r >> 1][r & 1] = cp.b1[ch];
     b2x[r] = cp.b2[ch];
   }
   // channel-major constants: one channel per lane
@@ -742,152 +742,123 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     for (int j = 0; j < 8; ++j) idb[kb][j] = (acc_row(8 * kb + j, hf) == c) ? (_Float16)1.0f : (_Float16)0.0f;
 
   floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
-  float aw1x[16], aw1y[16], ab1[16];
+  float2v aw1x[8], aw1y[8], ab1[8];    // channel pairs (registers 2 p, 2 p + 1)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { aw1x[r] = 0.f; aw1y[r] = 0.f; ab1[r] = 0.f; }
-  float ab3 = 0.f, s1 = 0.f, s2 = 0.f;   // s1 = sum D^T . masked d bias, s2 = sum masked d bias (channel-major lane)
+  for (int p = 0; p < 8; ++p) { aw1x[p] = (float2v){0.f, 0.f}; aw1y[p] = aw1x[p]; ab1[p] = aw1x[p]; }
+  float ab3 = 0.f;
+  float2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};   // s1 = sum D^T . masked d bias, s2 = sum masked d bias (channel-major lane)
 
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
   __syncthreads();
-
-  // next key's operands are fetched one iteration ahead (d bias streams from HBM, used once)
-  float vx_n = VSb[0];
-  float vy_n = (PD == 2) ? VSb[1] : 0.f;
   const int qcol = qvalid ? (q0 + c) : q0;                  // lanes past the bag end read a valid column and are zeroed
-  float db_n = dLTb[qcol];
   SMML_STAMP_DECL
 
-  // The loop is rotated by one key: the layer-1 backward of key j-1 (which consumes chain 2's result) is issued
-  // while the chains of key j are in flight.  State of the previous key:
-  float hv_p[16];
-  floatx16 dh_p = {0};
-  float p0_p = 0.f, p1_p = 0.f, d0_p = 0.f, d1_p = 0.f, isc_p = 0.f;
+  // ---- the units the schedule below is built from ----
+  // positions of one key for this lane's query
+  auto positions = [&](float vx, float vy, float& d0, float& d1, float& p0, float& p1) {
+    d0 = gq0 - vx; d1 = gq1 - vy;
+    p0 = slog1p(d0);
+    p1 = (PD == 2) ? slog1p(d1) : 0.f;
+  };
+  // layer 1 of channel pair p (query-major)
+  auto layer1_pair = [&](int p, float p0, float p1, float (&hv)[16]) {
+    float2v x = cw1x[p] * (float2v){p0, p0} + cb1[p];
+    if (PD == 2) x = cw1y[p] * (float2v){p1, p1} + x;
+    hv[2 * p] = fmaxf(x[0], 0.f); hv[2 * p + 1] = fmaxf(x[1], 0.f);
+  };
+  auto split_kb = [&](int kb, const float (&hv)[16], half8& bh, half8& bl) {
+    float x8[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) hv_p[r] = 0.f;
-
-  // layer-1 backward of one key + its d vs contribution: per-lane partials go to the staging tile (row = key % 32);
-  // every 32 keys each lane sums one (key, half) and lanes 0..31 add the totals to the LDS accumulator
-  auto layer1_bwd = [&](int jk, const float (&hvk)[16], const floatx16& dhk, float p0k, float p1k, float d0k, float d1k,
-                        float isck) {
-    float dp0 = 0.f, dp1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float g1 = (hvk[r] > 0.f) ? dhk[r] * isck : 0.f;
-      ab1[r] += g1;
-      aw1x[r] = fmaf(g1, p0k, aw1x[r]);
-      dp0 = fmaf(g1, cw1x[r], dp0);
-      if (PD == 2) {
-        aw1y[r] = fmaf(g1, p1k, aw1y[r]);
-        dp1 = fmaf(g1, cw1y[r], dp1);
-      }
-    }
-    float2 v;
-    v.x = -dp0 * srcp(fabsf(d0k) + 1.f);
-    v.y = (PD == 2) ? -dp1 * srcp(fabsf(d1k) + 1.f) : 0.f;
-    stg[(jk & 31) * 65 + lane] = v;
-    if ((jk & 31) == 31 || jk == J - 1) {
-      asm volatile("" ::: "memory");
-      const int kk = lane & 31, nrow = (jk & 31) + 1;
-      float sx = 0.f, sy = 0.f;
-      if (kk < nrow) {
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-          const float2 t = stg[kk * 65 + 32 * hf + i];
-          sx += t.x; sy += t.y;
-        }
-      }
-      sx = xhalf_sum(sx); sy = xhalf_sum(sy);
-      if (hf == 0 && kk < nrow) {
-        const int key = (jk & ~31) + kk;
-        atomicAdd(&dvs[2 * key], sx);
-        if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
-      }
-      asm volatile("" ::: "memory");
+    for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
+    split8(x8, bh, bl);
+  };
+  // layer-1 backward of channel pair p for the previous key; the chain-2 result still carries the lane's power-of-two
+  // scale, which is folded into the multipliers (isc) instead of un-scaling the 16 values
+  float2v dp0v, dp1v;
+  auto l1b_pair = [&](int p, const float (&hvk)[16], const floatx16& dhk, float p0i, float p1i, float isck) {
+    float2v g1;
+    g1[0] = (hvk[2 * p] > 0.f) ? dhk[2 * p] : 0.f;
+    g1[1] = (hvk[2 * p + 1] > 0.f) ? dhk[2 * p + 1] : 0.f;
+    ab1[p] = g1 * (float2v){isck, isck} + ab1[p];
+    aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
+    dp0v = g1 * cw1x[p] + dp0v;
+    if (PD == 2) {
+      aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
+      dp1v = g1 * cw1y[p] + dp1v;
     }
   };
-
-  for (int j = 0; j < J; ++j) {
-    const float vx = vx_n, vy = vy_n, dbias = qvalid ? db_n : 0.f;
-    {
-      const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
-      vx_n = VSb[(size_t)jn * PD];
-      if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
-      db_n = dLTb[(size_t)jn * NST + qcol];
-    }
-    SMML_STAMP(0)
-    const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = slog1p(d0);
-    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
-    // publish this query's d bias for the channel-major stage (one wave: LDS is in order, no barrier)
-    float* xb = xq + (j & 1) * 32;
-    if (hf == 0) xb[c] = dbias;
-
-    // ---- query-major: layer 1 for this lane's 16 channels, chains X and Y on the same operand registers ----
-    float hv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float x = fmaf(cw1x[r], p0, cb1[r]);
-      if (PD == 2) x = fmaf(cw1y[r], p1, x);
-      hv[r] = fmaxf(x, 0.f);
-    }
-    floatx16 dx = b2x, dy = {0}, ht = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float x8[8];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
-      half8 bh, bl;
-      split8(x8, bh, bl);
-      dx = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, dx);       // D[out = ch(r)][query = c] (+ b2)
-      dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
-      ht = mfma16(bl, idb[kb], ht);                                   // h1^T[query = acc_row(r, hf)][in = c]
-      ht = mfma16(bh, idb[kb], ht);
-    }
-    SMML_STAMP(1)
-    // previous key: layer-1 backward while the chains of this key are in flight (no-op data for j = 0)
-    if (j > 0) layer1_bwd(j - 1, hv_p, dh_p, p0_p, p1_p, d0_p, d1_p, isc_p);
-    SMML_STAMP(2)
-
-    // ---- channel-major: lane = channel c, registers r <-> query acc_row(r, hf) ----
-    float dbq[16];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
-      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
-    }
-    // g[in = c][query] = h1 . d bias, three bf16 terms (B operand of the dW2 product)
-    bf16x8 g1[2], g2[2], g3[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float g8[8];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) g8[jx] = ht[8 * t + jx] * dbq[8 * t + jx];
-      split8_bf3(g8, g1[t], g2[t], g3[t]);
-    }
-    // layer-2 mask of channel c for the 16 queries (exact 0 / 1 A operand), db2 and dW3 as two scalars
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bf16x8 am;
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) {
-        const int r = 8 * t + jx;
-        const bool on = dy[r] > nb2c;
-        const float dbm = on ? dbq[r] : 0.f;
-        s2 += dbm;
-        s1 = fmaf(dy[r], dbm, s1);
-        am[jx] = on ? (__bf16)1.0f : (__bf16)0.0f;
+  // d vs of one (query, key): per-lane partials go to the staging tile (row = key % 32)
+  auto dvs_store = [&](int jk, float d0k, float d1k, float isck) {
+    float2 v;
+    v.x = -(dp0v[0] + dp0v[1]) * isck * srcp(fabsf(d0k) + 1.f);
+    v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * isck * srcp(fabsf(d1k) + 1.f) : 0.f;
+    stg[(jk & 31) * 65 + lane] = v;
+  };
+  // every 32 keys each lane sums one (key, half) of the staging tile and lanes 0..31 add the totals to the accumulator
+  auto dvs_flush = [&](int jk) {
+    asm volatile("" ::: "memory");
+    const int kk = lane & 31, nrow = (jk & 31) + 1;
+    float sx = 0.f, sy = 0.f;
+    if (kk < nrow) {
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) {
+        const float2 t = stg[kk * 65 + 32 * hf + i];
+        sx += t.x; sy += t.y;
       }
-      e = mfma16b(am, g3[t], e);
-      e = mfma16b(am, g2[t], e);
-      e = mfma16b(am, g1[t], e);
     }
-    SMML_STAMP(3)
+    sx = xhalf_sum(sx); sy = xhalf_sum(sy);
+    if (hf == 0 && kk < nrow) {
+      const int key = (jk & ~31) + kk;
+      atomicAdd(&dvs[2 * key], sx);
+      if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
+    }
+    asm volatile("" ::: "memory");
+  };
 
-    // ---- query-major: dh1[in, query] = (W2 w3)^T . (mask . d bias).  d bias spans many binades across queries, so
-    // each lane (= query = one column of the product) scales its column by the power of two that brings |d bias|
-    // into [1, 2) and un-scales its column of the result - exact, and fp16-range safe.  Every non-zero element of the
-    // lane's operand is that one scaled value: split once, select by mask.
+  // ---- pipeline state: key j ("c": layer 1 done one iteration ahead), key j - 1 ("p": waits for its layer-1 backward) ----
+  // The layer-1 activations of two keys are alive at any time (their ReLU masks feed the layer-1 backward two trips
+  // after they were computed): two buffers that swap roles every trip - the loop is unrolled by two by hand.
+  float hvA[16], hvB[16];
+  half8 bh_c[2], bl_c[2];
+  floatx16 dh = {0};                   // chain 2 of the previous key; overwritten by this key's chain 2 in phase 3
+  float p0_c, p1_c, d0_c, d1_c, p0_p = 0.f, p1_p = 0.f, d0_p = 0.f, d1_p = 0.f, isc_p = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hvA[r] = 0.f;
+  positions(VSb[0], (PD == 2) ? VSb[1] : 0.f, d0_c, d1_c, p0_c, p1_c);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) layer1_pair(p, p0_c, p1_c, hvB);
+  split_kb(0, hvB, bh_c[0], bl_c[0]);
+  split_kb(1, hvB, bh_c[1], bl_c[1]);
+  float db_n = dLTb[qcol];
+
+#define SMML_SB __builtin_amdgcn_sched_barrier(0);
+  // To the compiler MFMAs and vector arithmetic are pure values: left alone they sink to their consumers, below any
+  // scheduling fence.  An empty asm that "modifies" the result pins each piece of work at its place in the stream.
+#ifndef SMML_PIN_ACC
+#define SMML_PIN_ACC "+a"
+#endif
+#define PINA(acc) asm volatile("" : SMML_PIN_ACC(acc));
+#define PINV(x) asm volatile("" : "+v"(x));
+#define MF(acc, a, b) acc = mfma16(a, b, acc); PINA(acc)
+#define MB(acc, a, b) acc = mfma16b(a, b, acc); PINA(acc)
+  // One key per trip.  The 16-bit matrix pipe runs beside the VALU, but a wave issues in order and the pipe takes one
+  // MFMA per 32 cycles: every MFMA below is followed by a unit of independent vector work and a fence, so that MFMAs
+  // never queue up behind each other with the VALU idle.
+  // hvx: in = layer-1 activations of key j - 1, out = those of key j + 1
+  auto step = [&](const int j, float (&hvx)[16]) __attribute__((always_inline)) {
+    const float dbias = qvalid ? db_n : 0.f;
+    const int jn = min(j + 1, J - 1);                       // branch-free prefetch of the next key's operands
+    db_n = dLTb[(size_t)jn * NST + qcol];
+    const float vx_n = VSb[(size_t)jn * PD];
+    const float vy_n = (PD == 2) ? VSb[(size_t)jn * PD + 1] : 0.f;
+    SMML_STAMP(0)
+    // publish this query's d bias for the channel-major stage (one wave: LDS is in order, no barrier; both halves
+    // store the same value)
+    float* xb = xq + (j & 1) * 32;
+    xb[c] = dbias;
+    // d bias spans many binades across queries: each lane (= query = one column of chain 2) scales its column by the
+    // power of two that brings |d bias| into [1, 2) and un-scales its column of the result - exact, fp16-range safe
     float sc = 1.f, isc = 1.f;
     {
       const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
@@ -896,30 +867,160 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     const float dbs = dbias * sc;
     const _Float16 shh = (_Float16)dbs;
     const _Float16 sll = (_Float16)(dbs - (float)shh);
-    const unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
-    const unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
-    floatx16 dh = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      uint4v ghw, glw;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int r = 8 * kb + 2 * p;
-        const unsigned pm = ((dx[r] > 0.f) ? 0x0000FFFFu : 0u) | ((dx[r + 1] > 0.f) ? 0xFFFF0000u : 0u);
-        ghw[p] = sh2 & pm;
-        glw[p] = sl2 & pm;
-      }
-      const half8 gh = __builtin_bit_cast(half8, ghw), gl = __builtin_bit_cast(half8, glw);
-      dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
-    }
+    unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
+    unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
     ab3 += (hf == 0) ? dbias : 0.f;
-    SMML_STAMP(4)
-    // rotate
+    SMML_SB
+
+    // ---- phase 1: chain X  D[out = ch(r)][query = c] = W2 h1 + b2   |   layer-1 backward of key j - 1 ----
+    floatx16 dx;
+    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
+    float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
+#define L1B(p) l1b_pair(p, hvx, dh, p0i, p1i, isc_p); PINV(dp0v) PINV(ab1[p]) PINV(aw1x[p]) SMML_SB
+    dx = mfma16(w2l[0], bh_c[0], b2x); PINA(dx)  L1B(0)
+    MF(dx, w2m[0], bl_c[0])   L1B(1)
+    MF(dx, w2m[0], bh_c[0])   L1B(2)
+    MF(dx, w2h[0], bl_c[0])   L1B(3)
+    MF(dx, w2h[0], bh_c[0])   L1B(4)
+    MF(dx, w2l[1], bh_c[1])   L1B(5)
+    MF(dx, w2m[1], bl_c[1])   L1B(6)
+    MF(dx, w2m[1], bh_c[1])   L1B(7)
+#undef L1B
+    MF(dx, w2h[1], bl_c[1])   dvs_store(j - 1, d0_p, d1_p, isc_p); SMML_SB
+    MF(dx, w2h[1], bh_c[1])
+    float d0_n, d1_n, p0_n, p1_n;
+    positions(vx_n, vy_n, d0_n, d1_n, p0_n, p1_n);
+    PINV(p0_n) PINV(p1_n)
+    SMML_SB
+    SMML_STAMP(1)
+
+    // ---- phase 2: h1^T (identity product, chain T) and chain Y  D^T[query = acc_row(r, hf)][out = c]   |   layer 1 of
+    //      key j + 1; the chain-2 operand of key j (every non-zero element of the lane's operand is the one scaled
+    //      d bias value: split once, selected by the layer-2 mask from chain X); g = h1 . d bias in three bf16 terms
+    //      (B operand of dW2) ----
+    floatx16 ht = {0}, dy = {0};
+    unsigned ghs[8], gls[8], g1s[8], g2s[8], g3s[8], ams[8];
+    float dbq[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hv_p[r] = hv[r];
-    dh_p = dh; p0_p = p0; p1_p = p1; d0_p = d0; d1_p = d1; isc_p = isc;
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
+      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
+    }
+#define L1(p) layer1_pair(p, p0_n, p1_n, hvx); PINV(hvx[2 * (p)]) PINV(hvx[2 * (p) + 1])
+    // operand elements 2 pp, 2 pp + 1 of K-block pp / 4
+#define PM(pp)                                                                                                  \
+  {                                                                                                             \
+    const unsigned pm = ((dx[2 * (pp)] > 0.f) ? 0x0000FFFFu : 0u) | ((dx[2 * (pp) + 1] > 0.f) ? 0xFFFF0000u : 0u); \
+    ghs[pp] = sh2 & pm; gls[pp] = sl2 & pm;                                                                     \
+    PINV(ghs[pp]) PINV(gls[pp])                                                                                 \
   }
-  layer1_bwd(J - 1, hv_p, dh_p, p0_p, p1_p, d0_p, d1_p, isc_p);
+#define GP(pp)                                                                                                  \
+  {                                                                                                             \
+    const float2v v = (float2v){ht[2 * (pp)], ht[2 * (pp) + 1]} * (float2v){dbq[2 * (pp)], dbq[2 * (pp) + 1]};   \
+    const bf16x2 hh = __builtin_convertvector(v, bf16x2);                                                       \
+    const float2v r1 = {v[0] - (float)hh[0], v[1] - (float)hh[1]};                                              \
+    const bf16x2 mm = __builtin_convertvector(r1, bf16x2);                                                      \
+    const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};                                            \
+    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);                                                      \
+    g1s[pp] = __builtin_bit_cast(unsigned, hh); g2s[pp] = __builtin_bit_cast(unsigned, mm);                     \
+    g3s[pp] = __builtin_bit_cast(unsigned, ll);                                                                 \
+    PINV(g1s[pp]) PINV(g2s[pp]) PINV(g3s[pp])                                                                   \
+  }
+    // layer-2 mask of channel c for query pair pp (exact 0 / 1 A operand of dW2), db2 and dW3 partial sums
+#define MP(pp)                                                                                                  \
+  {                                                                                                             \
+    const bool on0 = dy[2 * (pp)] > nb2c, on1 = dy[2 * (pp) + 1] > nb2c;                                        \
+    const float2v dbm = {on0 ? dbq[2 * (pp)] : 0.f, on1 ? dbq[2 * (pp) + 1] : 0.f};                             \
+    s2 += dbm;                                                                                                  \
+    s1 = (float2v){dy[2 * (pp)], dy[2 * (pp) + 1]} * dbm + s1;                                                  \
+    ams[pp] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);                                              \
+    PINV(ams[pp]) PINV(s1) PINV(s2)                                                                             \
+  }
+    MF(ht, bl_c[0], idb[0])      L1(0) SMML_SB
+    MF(dy, bh_c[0], w2l[0])      L1(1) SMML_SB
+    MF(ht, bh_c[0], idb[0])      L1(2) SMML_SB
+    MF(dy, bl_c[0], w2m[0])      L1(3) SMML_SB
+    MF(ht, bl_c[1], idb[1])      L1(4) SMML_SB
+    MF(dy, bh_c[0], w2m[0])      L1(5) SMML_SB
+    MF(ht, bh_c[1], idb[1])      L1(6) SMML_SB
+    MF(dy, bl_c[0], w2h[0])      L1(7) SMML_SB
+    MF(dy, bh_c[0], w2h[0])      PM(0) PM(1) SMML_SB
+    MF(dy, bh_c[1], w2l[1])      PM(2) PM(3) SMML_SB
+    MF(dy, bl_c[1], w2m[1])      PM(4) PM(5) GP(0) SMML_SB
+    MF(dy, bh_c[1], w2m[1])      PM(6) PM(7) GP(1) SMML_SB
+    MF(dy, bl_c[1], w2h[1])      GP(2) GP(3) SMML_SB
+    MF(dy, bh_c[1], w2h[1])      GP(4) GP(5) SMML_SB
+    SMML_STAMP(2)
+
+    // ---- phase 3: chain 2  dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias)   |   rest of the channel-major
+    //      stage; then dW2 += mask^T g (6 bf16 MFMAs)   |   operand split of key j + 1 ----
+    const half8 gh0 = __builtin_bit_cast(half8, (uint4v){ghs[0], ghs[1], ghs[2], ghs[3]});
+    const half8 gl0 = __builtin_bit_cast(half8, (uint4v){gls[0], gls[1], gls[2], gls[3]});
+    const half8 gh1 = __builtin_bit_cast(half8, (uint4v){ghs[4], ghs[5], ghs[6], ghs[7]});
+    const half8 gl1 = __builtin_bit_cast(half8, (uint4v){gls[4], gls[5], gls[6], gls[7]});
+    dh = mfma16(w2tl[0], gh0, (floatx16){0}); PINA(dh)   GP(6) GP(7) SMML_SB
+    MF(dh, w2tm[0], gl0)   MP(0) MP(1) SMML_SB
+    MF(dh, w2tm[0], gh0)   MP(2) MP(3) SMML_SB
+    MF(dh, w2th[0], gl0)   MP(4) MP(5) SMML_SB
+    MF(dh, w2th[0], gh0)   MP(6) MP(7) SMML_SB
+#undef L1
+#undef PM
+#undef GP
+#undef MP
+    SMML_STAMP(3)
+    float x8a[8], x8b[8];
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx) { x8a[jx] = hvx[jx]; x8b[jx] = hvx[8 + jx]; }
+    const bf16x8 am0 = __builtin_bit_cast(bf16x8, (uint4v){ams[0], ams[1], ams[2], ams[3]});
+    const bf16x8 am1 = __builtin_bit_cast(bf16x8, (uint4v){ams[4], ams[5], ams[6], ams[7]});
+    const bf16x8 g10 = __builtin_bit_cast(bf16x8, (uint4v){g1s[0], g1s[1], g1s[2], g1s[3]});
+    const bf16x8 g20 = __builtin_bit_cast(bf16x8, (uint4v){g2s[0], g2s[1], g2s[2], g2s[3]});
+    const bf16x8 g30 = __builtin_bit_cast(bf16x8, (uint4v){g3s[0], g3s[1], g3s[2], g3s[3]});
+    const bf16x8 g11 = __builtin_bit_cast(bf16x8, (uint4v){g1s[4], g1s[5], g1s[6], g1s[7]});
+    const bf16x8 g21 = __builtin_bit_cast(bf16x8, (uint4v){g2s[4], g2s[5], g2s[6], g2s[7]});
+    const bf16x8 g31 = __builtin_bit_cast(bf16x8, (uint4v){g3s[4], g3s[5], g3s[6], g3s[7]});
+    MF(dh, w2tl[1], gh1)   split8(x8a, bh_c[0], bl_c[0]); PINV(bh_c[0]) PINV(bl_c[0]) SMML_SB
+    MB(e, am0, g30)        SMML_SB
+    MF(dh, w2tm[1], gl1)   split8(x8b, bh_c[1], bl_c[1]); PINV(bh_c[1]) PINV(bl_c[1]) SMML_SB
+    MB(e, am0, g20)        SMML_SB
+    MF(dh, w2tm[1], gh1)   SMML_SB
+    MB(e, am0, g10)        SMML_SB
+    MF(dh, w2th[1], gl1)   SMML_SB
+    MB(e, am1, g31)        SMML_SB
+    MF(dh, w2th[1], gh1)   SMML_SB
+    MB(e, am1, g21)        SMML_SB
+    MB(e, am1, g11)        SMML_SB
+    SMML_STAMP(4)
+
+    // rotate the scalar pipeline state
+    p0_p = p0_c; p1_p = p1_c; d0_p = d0_c; d1_p = d1_c; isc_p = isc;
+    p0_c = p0_n; p1_c = p1_n; d0_c = d0_n; d1_c = d1_n;
+    if (j > 0 && ((j - 1) & 31) == 31) dvs_flush(j - 1);      // uniform branch, once per 32 keys
+  };
+  {
+    int j = 0;
+    for (; j + 1 < J; j += 2) { step(j, hvA); step(j + 1, hvB); }
+    if (j < J) step(j, hvA);
+  }
+  // drain: layer-1 backward of the last key
+  {
+    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
+    const float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
+    if ((J - 1) & 1) {                 // key J - 1 odd: its activations were written by the even trip J - 2 into hvA
+#pragma unroll
+      for (int p = 0; p < 8; ++p) l1b_pair(p, hvA, dh, p0i, p1i, isc_p);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) l1b_pair(p, hvB, dh, p0i, p1i, isc_p);
+    }
+    dvs_store(J - 1, d0_p, d1_p, isc_p);
+    dvs_flush(J - 1);
+  }
+#undef PINA
+#undef PINV
+#undef MF
+#undef MB
+#undef SMML_SB
 
   // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
   __syncthreads();
@@ -927,23 +1028,26 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
   for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
   __syncthreads();
   // channel-major scalars: both halves of the wave hold partial sums (their 16 queries each) of channel c
-  atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2);                       // db2[c] = w3[c] sum mask . d bias
-  atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2, s1));       // dW3[c] = sum relu(D + b2) . d bias
+  {
+    const float s1s = s1[0] + s1[1], s2s = s2[0] + s2[1];
+    atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
+    atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2s, s1s));   // dW3[c] = sum relu(D + b2) . d bias
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, hf);
     atomicAdd(&red[row * CH + c], e[r] * cp.w3[oi * CH + row]);        // dW2[out = row][in = c]
     // per-channel partials: sum over the 32 query lanes of this half
     float v;
-    v = ab1[r];
+    v = ab1[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
-    v = aw1x[r];
+    v = aw1x[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if (c == 0) atomicAdd(&red[1024 + row * 2], v);
-    v = aw1y[r];
+    v = aw1y[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);

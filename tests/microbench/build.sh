@@ -9,5 +9,6 @@ build() { # name, flags...
 }
 build base
 build stamps -DSMML_STAMPS
+build pinv '-DSMML_PIN_ACC="+v"'
 wait
 ls bin
