@@ -27,6 +27,9 @@
 #ifndef SMML_FWD_WPS
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
+#ifndef SMML_BWD_WPS
+#define SMML_BWD_WPS 2      // position-bias backward: 2 = two waves per SIMD (cpb_bwd2_kernel), 1 = one software-pipelined wave
+#endif
 #ifndef SMML_CPB_F16
 #define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
                             //    (W = Wh + Wl, h1 = hh + hl; Wh hh + Wh hl + Wl hh, ~22 mantissa bits) that overlaps the
@@ -870,51 +873,56 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
     unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
     ab3 += (hf == 0) ? dbias : 0.f;
-    SMML_SB
-
-    // ---- phase 1: chain X  D[out = ch(r)][query = c] = W2 h1 + b2   |   layer-1 backward of key j - 1 ----
-    floatx16 dx;
-    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
-    float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
-#define L1B(p) l1b_pair(p, hvx, dh, p0i, p1i, isc_p); PINV(dp0v) PINV(ab1[p]) PINV(aw1x[p]) SMML_SB
-    dx = mfma16(w2l[0], bh_c[0], b2x); PINA(dx)  L1B(0)
-    MF(dx, w2m[0], bl_c[0])   L1B(1)
-    MF(dx, w2m[0], bh_c[0])   L1B(2)
-    MF(dx, w2h[0], bl_c[0])   L1B(3)
-    MF(dx, w2h[0], bh_c[0])   L1B(4)
-    MF(dx, w2l[1], bh_c[1])   L1B(5)
-    MF(dx, w2m[1], bl_c[1])   L1B(6)
-    MF(dx, w2m[1], bh_c[1])   L1B(7)
-#undef L1B
-    MF(dx, w2h[1], bl_c[1])   dvs_store(j - 1, d0_p, d1_p, isc_p); SMML_SB
-    MF(dx, w2h[1], bh_c[1])
-    float d0_n, d1_n, p0_n, p1_n;
-    positions(vx_n, vy_n, d0_n, d1_n, p0_n, p1_n);
-    PINV(p0_n) PINV(p1_n)
-    SMML_SB
-    SMML_STAMP(1)
-
-    // ---- phase 2: h1^T (identity product, chain T) and chain Y  D^T[query = acc_row(r, hf)][out = c]   |   layer 1 of
-    //      key j + 1; the chain-2 operand of key j (every non-zero element of the lane's operand is the one scaled
-    //      d bias value: split once, selected by the layer-2 mask from chain X); g = h1 . d bias in three bf16 terms
-    //      (B operand of dW2) ----
-    floatx16 ht = {0}, dy = {0};
-    unsigned ghs[8], gls[8], g1s[8], g2s[8], g3s[8], ams[8];
     float dbq[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
       dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
     }
-#define L1(p) layer1_pair(p, p0_n, p1_n, hvx); PINV(hvx[2 * (p)]) PINV(hvx[2 * (p) + 1])
-    // operand elements 2 pp, 2 pp + 1 of K-block pp / 4
-#define PM(pp)                                                                                                  \
+    SMML_SB
+
+    // The trip is cut into regions of 2 - 3 MFMAs plus one unit of independent vector work (two channel / query
+    // pairs, so that the unit has instruction-level parallelism of its own); inside a region the interleave
+    // MFMA, ~6 VALU, MFMA, ... is requested from the scheduler, region boundaries are fences.
+#define RG3 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0); SMML_SB
+#define RG2 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 24, 0); SMML_SB
+
+    // ---- chains X  D[out = ch(r)][query = c] = W2 h1 + b2,  T  h1^T (identity product),  Y  D^T[query][out = c]
+    //      |   layer-1 backward of key j - 1, positions and layer 1 of key j + 1 ----
+    floatx16 dx, ht, dy;
+    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
+    float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
+#define L1B(p) l1b_pair(p, hvx, dh, p0i, p1i, isc_p); l1b_pair(p + 1, hvx, dh, p0i, p1i, isc_p);                 \
+               PINV(dp0v) PINV(ab1[p]) PINV(aw1x[p]) PINV(ab1[p + 1]) PINV(aw1x[p + 1])
+    dx = mfma16(w2l[0], bh_c[0], b2x); PINA(dx)
+    ht = mfma16(bl_c[0], idb[0], (floatx16){0}); PINA(ht)
+    dy = mfma16(bh_c[0], w2l[0], (floatx16){0}); PINA(dy)     L1B(0) RG3
+    MF(dx, w2m[0], bl_c[0]) MF(ht, bh_c[0], idb[0]) MF(dy, bl_c[0], w2m[0])     L1B(2) RG3
+    MF(dx, w2m[0], bh_c[0]) MF(ht, bl_c[1], idb[1]) MF(dy, bh_c[0], w2m[0])     L1B(4) RG3
+    MF(dx, w2h[0], bl_c[0]) MF(ht, bh_c[1], idb[1]) MF(dy, bl_c[0], w2h[0])     L1B(6) RG3
+#undef L1B
+    float d0_n, d1_n, p0_n, p1_n;
+    MF(dx, w2h[0], bh_c[0]) MF(dy, bh_c[0], w2h[0])
+    dvs_store(j - 1, d0_p, d1_p, isc_p);
+    positions(vx_n, vy_n, d0_n, d1_n, p0_n, p1_n);
+    PINV(p0_n) PINV(p1_n) RG2
+    SMML_STAMP(1)
+#define L1(p) layer1_pair(p, p0_n, p1_n, hvx); layer1_pair(p + 1, p0_n, p1_n, hvx);                              \
+              PINV(hvx[2 * (p)]) PINV(hvx[2 * (p) + 1]) PINV(hvx[2 * (p) + 2]) PINV(hvx[2 * (p) + 3])
+    unsigned ghs[8], gls[8], g1s[8], g2s[8], g3s[8], ams[8];
+    // chain-2 operand elements 2 pp, 2 pp + 1 of K-block pp / 4: every non-zero element of the lane's operand is the
+    // one scaled d bias value (split once), selected by the layer-2 mask from chain X
+#define PM1(pp)                                                                                                 \
   {                                                                                                             \
     const unsigned pm = ((dx[2 * (pp)] > 0.f) ? 0x0000FFFFu : 0u) | ((dx[2 * (pp) + 1] > 0.f) ? 0xFFFF0000u : 0u); \
     ghs[pp] = sh2 & pm; gls[pp] = sl2 & pm;                                                                     \
-    PINV(ghs[pp]) PINV(gls[pp])                                                                                 \
   }
-#define GP(pp)                                                                                                  \
+#define PM(pp) PM1(pp) PM1(pp + 1) PINV(ghs[pp]) PINV(gls[pp]) PINV(ghs[pp + 1]) PINV(gls[pp + 1])
+    // g[in = c][query pair] = h1 . d bias in three bf16 terms (B operand of dW2)
+#define GP1(pp)                                                                                                 \
   {                                                                                                             \
     const float2v v = (float2v){ht[2 * (pp)], ht[2 * (pp) + 1]} * (float2v){dbq[2 * (pp)], dbq[2 * (pp) + 1]};   \
     const bf16x2 hh = __builtin_convertvector(v, bf16x2);                                                       \
@@ -924,50 +932,48 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     const bf16x2 ll = __builtin_convertvector(r2, bf16x2);                                                      \
     g1s[pp] = __builtin_bit_cast(unsigned, hh); g2s[pp] = __builtin_bit_cast(unsigned, mm);                     \
     g3s[pp] = __builtin_bit_cast(unsigned, ll);                                                                 \
-    PINV(g1s[pp]) PINV(g2s[pp]) PINV(g3s[pp])                                                                   \
   }
+#define GP(pp) GP1(pp) GP1(pp + 1) PINV(g1s[pp]) PINV(g2s[pp]) PINV(g3s[pp]) PINV(g1s[pp + 1]) PINV(g2s[pp + 1]) PINV(g3s[pp + 1])
     // layer-2 mask of channel c for query pair pp (exact 0 / 1 A operand of dW2), db2 and dW3 partial sums
-#define MP(pp)                                                                                                  \
+#define MP1(pp)                                                                                                 \
   {                                                                                                             \
     const bool on0 = dy[2 * (pp)] > nb2c, on1 = dy[2 * (pp) + 1] > nb2c;                                        \
     const float2v dbm = {on0 ? dbq[2 * (pp)] : 0.f, on1 ? dbq[2 * (pp) + 1] : 0.f};                             \
     s2 += dbm;                                                                                                  \
     s1 = (float2v){dy[2 * (pp)], dy[2 * (pp) + 1]} * dbm + s1;                                                  \
     ams[pp] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);                                              \
-    PINV(ams[pp]) PINV(s1) PINV(s2)                                                                             \
   }
-    MF(ht, bl_c[0], idb[0])      L1(0) SMML_SB
-    MF(dy, bh_c[0], w2l[0])      L1(1) SMML_SB
-    MF(ht, bh_c[0], idb[0])      L1(2) SMML_SB
-    MF(dy, bl_c[0], w2m[0])      L1(3) SMML_SB
-    MF(ht, bl_c[1], idb[1])      L1(4) SMML_SB
-    MF(dy, bh_c[0], w2m[0])      L1(5) SMML_SB
-    MF(ht, bh_c[1], idb[1])      L1(6) SMML_SB
-    MF(dy, bl_c[0], w2h[0])      L1(7) SMML_SB
-    MF(dy, bh_c[0], w2h[0])      PM(0) PM(1) SMML_SB
-    MF(dy, bh_c[1], w2l[1])      PM(2) PM(3) SMML_SB
-    MF(dy, bl_c[1], w2m[1])      PM(4) PM(5) GP(0) SMML_SB
-    MF(dy, bh_c[1], w2m[1])      PM(6) PM(7) GP(1) SMML_SB
-    MF(dy, bl_c[1], w2h[1])      GP(2) GP(3) SMML_SB
-    MF(dy, bh_c[1], w2h[1])      GP(4) GP(5) SMML_SB
+#define MP(pp) MP1(pp) MP1(pp + 1) PINV(ams[pp]) PINV(ams[pp + 1]) PINV(s1) PINV(s2)
+    MF(dx, w2l[1], bh_c[1]) MF(dy, bh_c[1], w2l[1])     L1(0) RG2
+    MF(dx, w2m[1], bl_c[1]) MF(dy, bl_c[1], w2m[1])     L1(2) RG2
+    MF(dx, w2m[1], bh_c[1]) MF(dy, bh_c[1], w2m[1])     L1(4) RG2
+    MF(dx, w2h[1], bl_c[1]) MF(dy, bl_c[1], w2h[1])     L1(6) RG2
+    MF(dx, w2h[1], bh_c[1]) MF(dy, bh_c[1], w2h[1])     GP(0) RG2
     SMML_STAMP(2)
-
-    // ---- phase 3: chain 2  dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias)   |   rest of the channel-major
-    //      stage; then dW2 += mask^T g (6 bf16 MFMAs)   |   operand split of key j + 1 ----
+    // ---- chain 2  dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias)   |   channel-major stage ----
+    GP(2) PM(0) SMML_SB
+    PM(2) GP(4) SMML_SB
     const half8 gh0 = __builtin_bit_cast(half8, (uint4v){ghs[0], ghs[1], ghs[2], ghs[3]});
     const half8 gl0 = __builtin_bit_cast(half8, (uint4v){gls[0], gls[1], gls[2], gls[3]});
+    dh = mfma16(w2tl[0], gh0, (floatx16){0}); PINA(dh)
+    MF(dh, w2tm[0], gl0)   PM(4) RG2
+    MF(dh, w2tm[0], gh0) MF(dh, w2th[0], gl0)   PM(6) RG2
     const half8 gh1 = __builtin_bit_cast(half8, (uint4v){ghs[4], ghs[5], ghs[6], ghs[7]});
     const half8 gl1 = __builtin_bit_cast(half8, (uint4v){gls[4], gls[5], gls[6], gls[7]});
-    dh = mfma16(w2tl[0], gh0, (floatx16){0}); PINA(dh)   GP(6) GP(7) SMML_SB
-    MF(dh, w2tm[0], gl0)   MP(0) MP(1) SMML_SB
-    MF(dh, w2tm[0], gh0)   MP(2) MP(3) SMML_SB
-    MF(dh, w2th[0], gl0)   MP(4) MP(5) SMML_SB
-    MF(dh, w2th[0], gh0)   MP(6) MP(7) SMML_SB
+    MF(dh, w2th[0], gh0) MF(dh, w2tl[1], gh1)   GP(6) RG2
+    MF(dh, w2tm[1], gl1) MF(dh, w2tm[1], gh1)   MP(0) RG2
+    MF(dh, w2th[1], gl1) MF(dh, w2th[1], gh1)   MP(2) RG2
+    SMML_STAMP(3)
+    // ---- dW2 += mask^T g (6 bf16 MFMAs)   |   rest of the masks, operand split of key j + 1 ----
+    MP(4) SMML_SB
+    MP(6) SMML_SB
 #undef L1
 #undef PM
+#undef PM1
 #undef GP
+#undef GP1
 #undef MP
-    SMML_STAMP(3)
+#undef MP1
     float x8a[8], x8b[8];
 #pragma unroll
     for (int jx = 0; jx < 8; ++jx) { x8a[jx] = hvx[jx]; x8b[jx] = hvx[8 + jx]; }
@@ -979,18 +985,12 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
     const bf16x8 g11 = __builtin_bit_cast(bf16x8, (uint4v){g1s[4], g1s[5], g1s[6], g1s[7]});
     const bf16x8 g21 = __builtin_bit_cast(bf16x8, (uint4v){g2s[4], g2s[5], g2s[6], g2s[7]});
     const bf16x8 g31 = __builtin_bit_cast(bf16x8, (uint4v){g3s[4], g3s[5], g3s[6], g3s[7]});
-    MF(dh, w2tl[1], gh1)   split8(x8a, bh_c[0], bl_c[0]); PINV(bh_c[0]) PINV(bl_c[0]) SMML_SB
-    MB(e, am0, g30)        SMML_SB
-    MF(dh, w2tm[1], gl1)   split8(x8b, bh_c[1], bl_c[1]); PINV(bh_c[1]) PINV(bl_c[1]) SMML_SB
-    MB(e, am0, g20)        SMML_SB
-    MF(dh, w2tm[1], gh1)   SMML_SB
-    MB(e, am0, g10)        SMML_SB
-    MF(dh, w2th[1], gl1)   SMML_SB
-    MB(e, am1, g31)        SMML_SB
-    MF(dh, w2th[1], gh1)   SMML_SB
-    MB(e, am1, g21)        SMML_SB
-    MB(e, am1, g11)        SMML_SB
+    MB(e, am0, g30) MB(e, am0, g20)   split8(x8a, bh_c[0], bl_c[0]); PINV(bh_c[0]) PINV(bl_c[0]) RG2
+    MB(e, am0, g10) MB(e, am1, g31)   split8(x8b, bh_c[1], bl_c[1]); PINV(bh_c[1]) PINV(bl_c[1]) RG2
+    MB(e, am1, g21) MB(e, am1, g11)   SMML_SB
     SMML_STAMP(4)
+#undef RG2
+#undef RG3
 
     // rotate the scalar pipeline state
     p0_p = p0_c; p1_p = p1_c; d0_p = d0_c; d1_p = d1_c; isc_p = isc;
@@ -1062,6 +1062,300 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
   for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
   SMML_STAMP_STORE
   // sample-position gradients: float atomics, contiguous rows
+  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
+  for (int i = tid; i < J * PD; i += 256) {
+    const int j = i / PD, comp = i - j * PD;
+    atomicAdd(&dVSb[i], dvs[2 * j + comp]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-waves-per-SIMD form of the position-bias backward (SMML_BWD_WPS = 2).  One wave issues a vector instruction
+// every ~5.2 cycles at best and ~8 (packed: 12) when it depends on the previous one (tests/microbench/valu_probe.hip),
+// so a single resident wave leaves a third of the issue slots empty; two waves fill each other's gaps, but must share
+// the SIMD's 512 registers: 256 each.  What makes that fit:
+//   * layer 1 itself runs on the matrix pipe: W1 p + b1 as one K = 16 split-fp16 product (13 slots: w1x, w1y in three
+//     terms x p in two, b1 in three) - a 4-register constant operand instead of 48 per-channel constants;
+//   * no software pipeline inside the wave (the sibling wave is the pipeline): nothing of the previous key is alive;
+//   * b2 and the layer-1 weights of the d vs product are read from a 512-byte LDS table when they are needed.
+// Same mathematics, layouts and slab format as cpb_bwd_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
+constexpr int CPB2_WAVE_LDS = CPB_XQ + 2 * CPB2_STG_KEYS * 65;      // floats
+constexpr int CPB2_TAB = 2 * 3 * 16;                                // {w1x, w1y, b2} of ch(r) for both lane halves
+
+template <int PD>
+__global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
+    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
+    float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // layout: tab[2][3][16] | dvs[J*2, padded to 4] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  float* tab = smem;
+  float* dvs = smem + CPB2_TAB;                             // [J][2]
+  float* wbase = dvs + ((2 * J + 3) & ~3);
+  float* xq = wbase + wave * CPB2_WAVE_LDS;                 // [2][32]
+  float2* stg = reinterpret_cast<float2*>(xq + CPB_XQ);     // [16 keys][65]
+  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
+  if (tid < 32) {                                           // tid = 16 half + r
+    const int ch = acc_row(tid & 15, tid >> 4);
+    tab[(tid >> 4) * 48 + (tid & 15)] = cp.w1[ch * PD];
+    tab[(tid >> 4) * 48 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    tab[(tid >> 4) * 48 + 32 + (tid & 15)] = cp.b2[ch];
+  }
+  const float* tabh = tab + hf * 48;
+
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // layer 1 as two bf16 MFMAs: x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch] with every factor split into three bf16
+  // terms (h + m + l = the fp32 value to 2^-24, fp32's exponent range).  Both lane halves feed the same 8 K slots
+  //   B:  p0_h  p1_h  p0_m  p1_m  p0_l  p1_l  1  0        (the three packed conversion results as they stand)
+  // against different constants, so that all products down to 2^-24 of the leading one are summed:
+  //   A (MFMA 1, half 0):  x_h  y_h  x_h  y_h  x_h  y_h  b_h  0      A (MFMA 1, half 1):  x_m  y_m  x_m  y_m  0  0  b_m  0
+  //   A (MFMA 2, half 0):  x_l  y_l   0    0    0    0   b_l  0      A (MFMA 2, half 1):  0
+  // fp32-grade pre-activations matter: the ReLU masks of the layer-1 backward flip wherever x is within its error of 0.
+  bf16x8 a1a, a1b;
+  {
+    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, bb = cp.b1[c];
+    const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
+    const __bf16 xl = (__bf16)(xr - (float)xm);
+    const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
+    const __bf16 yl = (__bf16)(yr - (float)ym);
+    const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
+    const __bf16 bl_ = (__bf16)(br - (float)bm);
+    const __bf16 z = (__bf16)0.f;
+    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, z, z, z, z, bl_, z}; }
+    else { a1a = (bf16x8){xm, ym, xm, ym, z, z, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+  }
+  const float nb2c = -cp.b2[c];
+  const float w3c = cp.w3[oi * CH + c];
+
+  half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
+  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
+  half8 idb[2];                        // identity: h1 (operand layout) . I = h1^T in accumulator layout
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float a[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = acc_row(8 * kb + j, hf);
+      a[j] = cp.w2[c * CH + ch];
+      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
+      idb[kb][j] = (ch == c) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
+    split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
+  }
+
+  floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
+  float2v aw1x[8], aw1y[8], ab1[8];    // channel pairs (registers 2 p, 2 p + 1)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { aw1x[p] = (float2v){0.f, 0.f}; aw1y[p] = aw1x[p]; ab1[p] = aw1x[p]; }
+  float ab3 = 0.f;
+  float2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+  __syncthreads();
+  const int qcol = qvalid ? (q0 + c) : q0;
+  float vx_n = VSb[0];
+  float vy_n = (PD == 2) ? VSb[1] : 0.f;
+  float db_n = dLTb[qcol];
+
+  for (int j = 0; j < J; ++j) {
+    const float vx = vx_n, vy = vy_n, dbias = qvalid ? db_n : 0.f;
+    {
+      const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
+      vx_n = VSb[(size_t)jn * PD];
+      if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
+      db_n = dLTb[(size_t)jn * NST + qcol];
+    }
+    float* xb = xq + (j & 1) * 32;
+    xb[c] = dbias;                                          // for the channel-major stage (both halves store the same value)
+    const float d0 = gq0 - vx, d1 = gq1 - vy;
+    const float p0 = slog1p(d0);
+    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
+
+    // ---- layer 1 on the matrix pipe ----
+    floatx16 xacc;
+    {
+      const float2v pv = {p0, p1};
+      const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
+      const float2v r1 = {pv[0] - (float)hh[0], pv[1] - (float)hh[1]};
+      const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+      const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};
+      const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+      const uint4v bw = {__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm), __builtin_bit_cast(unsigned, ll),
+                         0x00003F80u};
+      const bf16x8 b1op = __builtin_bit_cast(bf16x8, bw);
+      xacc = mfma16b(a1b, b1op, (floatx16){0});
+      xacc = mfma16b(a1a, b1op, xacc);
+    }
+    float hv[16];
+    bool on1[16];                       // layer-1 ReLU masks: live to the end of the trip as lane masks in SGPRs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hv[r] = fmaxf(xacc[r], 0.f); on1[r] = xacc[r] > 0.f; }
+
+    // ---- chains X, Y, T on the same operand registers ----
+    floatx16 dx = {0}, dy = {0}, ht = {0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float x8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
+      half8 bh, bl;
+      split8(x8, bh, bl);
+      dx = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, dx);       // D[out = ch(r)][query = c]  (b2 added at the mask)
+      dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
+      ht = mfma16(bl, idb[kb], ht);                                   // h1^T[query = acc_row(r, hf)][in = c]
+      ht = mfma16(bh, idb[kb], ht);
+    }
+
+    // ---- chain 2: dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias), d bias scaled per lane into [1, 2) ----
+    float sc = 1.f, isc = 1.f;
+    {
+      const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
+      if (eb != 0u && eb != 255u) { sc = __uint_as_float((254u - eb) << 23); isc = __uint_as_float(eb << 23); }
+    }
+    const float dbs = dbias * sc;
+    const _Float16 shh = (_Float16)dbs;
+    const _Float16 sll = (_Float16)(dbs - (float)shh);
+    const unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
+    const unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
+    floatx16 dh = {0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      uint4v ghw, glw;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = 8 * kb + 2 * p;
+        const float2 nb2 = *reinterpret_cast<const float2*>(tabh + 32 + r);      // b2[ch(r)], b2[ch(r + 1)] (broadcast)
+        const unsigned pm = ((dx[r] > -nb2.x) ? 0x0000FFFFu : 0u) | ((dx[r + 1] > -nb2.y) ? 0xFFFF0000u : 0u);
+        ghw[p] = sh2 & pm;
+        glw[p] = sl2 & pm;
+      }
+      const half8 gh = __builtin_bit_cast(half8, ghw), gl = __builtin_bit_cast(half8, glw);
+      dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
+    }
+    ab3 += (hf == 0) ? dbias : 0.f;
+
+    // ---- channel-major stage: dW2 += mask^T g, db2 / dW3 partial sums ----
+    float dbq[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
+      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float g8[8];
+      uint4v amw;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = 8 * t + 2 * p;
+        g8[2 * p] = ht[r] * dbq[r]; g8[2 * p + 1] = ht[r + 1] * dbq[r + 1];
+        const bool on0 = dy[r] > nb2c, on1 = dy[r + 1] > nb2c;
+        const float2v dbm = {on0 ? dbq[r] : 0.f, on1 ? dbq[r + 1] : 0.f};
+        s2 += dbm;
+        s1 = (float2v){dy[r], dy[r + 1]} * dbm + s1;
+        amw[p] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);
+      }
+      bf16x8 g1, g2, g3;
+      split8_bf3(g8, g1, g2, g3);
+      const bf16x8 am = __builtin_bit_cast(bf16x8, amw);
+      e = mfma16b(am, g3, e);
+      e = mfma16b(am, g2, e);
+      e = mfma16b(am, g1, e);
+    }
+
+    // ---- layer-1 backward, d vs ----
+    {
+      float2v dp0v = {0.f, 0.f}, dp1v = {0.f, 0.f};
+      const float p0i = p0 * isc, p1i = p1 * isc;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        float2v g1;
+        g1[0] = on1[2 * p] ? dh[2 * p] : 0.f;
+        g1[1] = on1[2 * p + 1] ? dh[2 * p + 1] : 0.f;
+        const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);               // broadcast reads
+        ab1[p] = g1 * (float2v){isc, isc} + ab1[p];
+        aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
+        dp0v = g1 * (float2v){wx.x, wx.y} + dp0v;
+        if (PD == 2) {
+          const float2 wy = *reinterpret_cast<const float2*>(tabh + 16 + 2 * p);
+          aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
+          dp1v = g1 * (float2v){wy.x, wy.y} + dp1v;
+        }
+      }
+      float2 v;
+      v.x = -(dp0v[0] + dp0v[1]) * isc * srcp(fabsf(d0) + 1.f);
+      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * isc * srcp(fabsf(d1) + 1.f) : 0.f;
+      stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
+    }
+    if ((j & (CPB2_STG_KEYS - 1)) == CPB2_STG_KEYS - 1 || j == J - 1) {   // uniform: flush the staging tile
+      asm volatile("" ::: "memory");
+      const int kk = lane & 31, nrow = (j & (CPB2_STG_KEYS - 1)) + 1;
+      float sx = 0.f, sy = 0.f;
+      if (kk < nrow) {
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const float2 t = stg[kk * 65 + 32 * hf + i];
+          sx += t.x; sy += t.y;
+        }
+      }
+      sx = xhalf_sum(sx); sy = xhalf_sum(sy);
+      if (hf == 0 && kk < nrow) {
+        const int key = (j & ~(CPB2_STG_KEYS - 1)) + kk;
+        atomicAdd(&dvs[2 * key], sx);
+        if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
+  __syncthreads();
+  float* red = wbase + WAVES * CPB2_WAVE_LDS;               // [CPB_SLAB] accumulators in LDS
+  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
+  __syncthreads();
+  {
+    const float s1s = s1[0] + s1[1], s2s = s2[0] + s2[1];
+    atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
+    atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2s, s1s));   // dW3[c] = sum relu(D + b2) . d bias
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hf);
+    atomicAdd(&red[row * CH + c], e[r] * cp.w3[oi * CH + row]);        // dW2[out = row][in = c]
+    float v;
+    v = ab1[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
+    v = aw1x[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
+    v = aw1y[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
+  }
+  {
+    float v = wave_sum(ab3);
+    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
+  }
+  __syncthreads();
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* sl = slab + (size_t)wg * CPB_SLAB;
+  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
   float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
   for (int i = tid; i < J * PD; i += 256) {
     const int j = i / PD, comp = i - j * PD;
@@ -1274,6 +1568,17 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
     if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
     float* slab = (float*)workspace;
+#if SMML_BWD_WPS == 2
+    const size_t lds = ((size_t)CPB2_TAB + ((2 * J + 3) & ~3) + WAVES * CPB2_WAVE_LDS + CPB_SLAB) * sizeof(float);
+    SMML_REQUIRE(lds <= 80 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
+    if (posdim == 2)
+      hipLaunchKernelGGL(cpb_bwd2_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
+                         J, H, G, nst);
+    else
+      hipLaunchKernelGGL(cpb_bwd2_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
+                         J, H, G, nst);
+#else
     const size_t lds = ((size_t)((2 * J + 3) & ~3) + WAVES * CPB_WAVE_LDS + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
@@ -1283,6 +1588,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
                          J, H, G, nst);
+#endif
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;
