@@ -119,6 +119,28 @@ __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, h
   return mfma16(wh, bh, d);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// x = a + b + c with three bf16 terms (round-to-nearest each): residual <= 2^-24 |x|, fp32's exponent range
+__device__ __forceinline__ void split8_bf3(const float (&x)[8], bf16x8& a, bf16x8& b, bf16x8& c) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2v v = {x[2 * i], x[2 * i + 1]};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const float2v r1 = {v[0] - (float)h[0], v[1] - (float)h[1]};
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const float2v r2 = {r1[0] - (float)m[0], r1[1] - (float)m[1]};
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    a[2 * i] = h[0]; a[2 * i + 1] = h[1];
+    b[2 * i] = m[0]; b[2 * i + 1] = m[1];
+    c[2 * i] = l[0]; c[2 * i + 1] = l[1];
+  }
+}
+
 // Attention dropout (nn.Dropout on the softmax'd probabilities, DeformableAttention2D.py:309): a counter-based
 // keep decision per (b, h, query, key) from a 64-bit seed - the same element gets the same decision in the
 // forward and in both backward passes, no mask is stored.  keep_scale = 1 / (1 - p); thresh = p * 2^32.
@@ -158,7 +180,9 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
   __shared__ float biasT[WAVES][KT][QT];     // per-wave bias tile [key][query]
+#if !SMML_CPB_F16
   __shared__ float4 tabB[CH];                // {w1x, w1y, b1, -} per hidden channel
+#endif
   __shared__ float Qs[WAVES][DH][QT];        // per-wave scaled Q tile, d-major
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -183,17 +207,45 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
 
-  // CPB constants: W2 (A operand, k-step layout), b2 / w3 (accumulator layout) in VGPRs; the layer-1
-  // weights {w1x, w1y, b1} of channel 16 hf + s are broadcast-read from an LDS table
-  float w2a[16], w3v[16];
+  // CPB constants: b2 / w3 in accumulator layout (VGPRs)
+  float w3v[16];
   floatx16 b2acc;                               // b2 in accumulator layout: the chain's initial C operand
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    w2a[s] = cp.w2[c * CH + 16 * hf + s];       // A[i = out = c][k = in = 16 hf + s]
     const int oc = acc_row(s, hf);              // output channel held in accumulator register s
     b2acc[s] = cp.b2[oc];
     w3v[s] = cp.w3[oi * CH + oc];
   }
+#if SMML_CPB_F16
+  // Layer 1 runs on the matrix pipe as two bf16 MFMAs (operands as in cpb_bwd2_kernel: every factor in three bf16 terms,
+  // fp32-grade pre-activations, identical to what the backward recomputes); the result arrives in accumulator layout,
+  // so operand slot (K-block kb, element j) of the 32x32 layer carries hidden channel acc_row(8 kb + j, hf).
+  bf16x8 a1a, a1b;
+  {
+    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, bb = cp.b1[c];
+    const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
+    const __bf16 xl = (__bf16)(xr - (float)xm);
+    const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
+    const __bf16 yl = (__bf16)(yr - (float)ym);
+    const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
+    const __bf16 bl_ = (__bf16)(br - (float)bm);
+    const __bf16 z = (__bf16)0.f;
+    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, z, z, z, z, bl_, z}; }
+    else { a1a = (bf16x8){xm, ym, xm, ym, z, z, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+  }
+  // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
+  half8 w2h[2], w2m[2], w2l[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
+    split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
+  }
+#else
+  float w2a[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w2a[s] = cp.w2[c * CH + 16 * hf + s];       // A[i = out = c][k = in = 16 hf + s]
   if (tid < 32) {
     float4 t;
     t.x = cp.w1[tid * PD];
@@ -201,16 +253,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     t.z = cp.b1[tid];
     t.w = 0.f;
     tabB[tid] = t;
-  }
-#if SMML_CPB_F16
-  // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = 16 kb + 8 hf + j
-  half8 w2h[2], w2m[2], w2l[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float wv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + 16 * kb + 8 * hf + j];
-    split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
   }
 #endif
   const float b3 = cp.b3[oi];
@@ -260,17 +302,26 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
 #if SMML_CPB_F16
-      // layer 1 for this lane's 16 channels (two K-blocks of 8), split into fp16 hi / lo, three MFMAs per block
+      // layer 1 on the matrix pipe, ReLU, fp16 hi / lo split, five MFMAs per K-block
+      floatx16 xacc;
+      {
+        const float2v pv = {p0, p1};
+        const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
+        const float2v r1 = {pv[0] - (float)hh[0], pv[1] - (float)hh[1]};
+        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+        const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};
+        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+        const uint4v bw = {__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm),
+                           __builtin_bit_cast(unsigned, ll), 0x00003F80u};
+        const bf16x8 b1op = __builtin_bit_cast(bf16x8, bw);
+        xacc = mfma16b(a1b, b1op, (floatx16){0});
+        xacc = mfma16b(a1a, b1op, xacc);
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float hv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 t = tabB[16 * kb + 8 * hf + j];
-          float x = fmaf(t.x, p0, t.z);
-          if (PD == 2) x = fmaf(t.y, p1, x);
-          hv[j] = fmaxf(x, 0.f);
-        }
+        for (int j = 0; j < 8; ++j) hv[j] = fmaxf(xacc[8 * kb + j], 0.f);
         half8 bh, bl;
         split8(hv, bh, bl);
         d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
@@ -653,27 +704,6 @@ constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
 constexpr int CPB_XQ = 2 * 32;                            // double-buffered d bias of the wave's 32 queries
 constexpr int CPB_WAVE_LDS = CPB_XQ + 2 * 32 * 65;        // + staging tile of the d vs partials; multiple of 4
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// x = a + b + c with three bf16 terms (round-to-nearest each): residual <= 2^-24 |x|, fp32's exponent range
-__device__ __forceinline__ void split8_bf3(const float (&x)[8], bf16x8& a, bf16x8& b, bf16x8& c) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float2v v = {x[2 * i], x[2 * i + 1]};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    const float2v r1 = {v[0] - (float)h[0], v[1] - (float)h[1]};
-    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-    const float2v r2 = {r1[0] - (float)m[0], r1[1] - (float)m[1]};
-    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-    a[2 * i] = h[0]; a[2 * i + 1] = h[1];
-    b[2 * i] = m[0]; b[2 * i + 1] = m[1];
-    c[2 * i] = l[0]; c[2 * i + 1] = l[1];
-  }
-}
 // D += h . W with the split ACTIVATION as the A operand (transposed product of mfma16_split)
 __device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh, half8 wm, half8 wl, floatx16 d) {
   d = mfma16(bh, wl, d);
@@ -1218,31 +1248,23 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
       ht = mfma16(bh, idb[kb], ht);
     }
 
-    // ---- chain 2: dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias), d bias scaled per lane into [1, 2) ----
-    float sc = 1.f, isc = 1.f;
-    {
-      const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
-      if (eb != 0u && eb != 255u) { sc = __uint_as_float((254u - eb) << 23); isc = __uint_as_float(eb << 23); }
-    }
-    const float dbs = dbias * sc;
-    const _Float16 shh = (_Float16)dbs;
-    const _Float16 sll = (_Float16)(dbs - (float)shh);
-    const unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
-    const unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
+    // ---- chain 2: dh1[in = ch(r)][query = c] = d bias[query] . (W2 w3)^T mask.  The mask is an exact fp16 operand and the
+    //      constant is split exactly into three terms: three MFMAs per K-block give the fp32-exact column sums, the
+    //      lane's d bias multiplies its column afterwards (no scaling of the gradient range needed) ----
     floatx16 dh = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      uint4v ghw, glw;
+      uint4v mw;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = 8 * kb + 2 * p;
-        const float2 nb2 = *reinterpret_cast<const float2*>(tabh + 32 + r);      // b2[ch(r)], b2[ch(r + 1)] (broadcast)
-        const unsigned pm = ((dx[r] > -nb2.x) ? 0x0000FFFFu : 0u) | ((dx[r + 1] > -nb2.y) ? 0xFFFF0000u : 0u);
-        ghw[p] = sh2 & pm;
-        glw[p] = sl2 & pm;
+        const float2 b2r = *reinterpret_cast<const float2*>(tabh + 32 + r);      // b2[ch(r)], b2[ch(r + 1)] (broadcast)
+        mw[p] = ((dx[r] > -b2r.x) ? 0x00003C00u : 0u) | ((dx[r + 1] > -b2r.y) ? 0x3C000000u : 0u);   // fp16 1.0 / 0
       }
-      const half8 gh = __builtin_bit_cast(half8, ghw), gl = __builtin_bit_cast(half8, glw);
-      dh = mfma16_split(w2th[kb], w2tm[kb], w2tl[kb], gh, gl, dh);
+      const half8 mk = __builtin_bit_cast(half8, mw);
+      dh = mfma16(w2tl[kb], mk, dh);
+      dh = mfma16(w2tm[kb], mk, dh);
+      dh = mfma16(w2th[kb], mk, dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
 
@@ -1278,14 +1300,14 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
     // ---- layer-1 backward, d vs ----
     {
       float2v dp0v = {0.f, 0.f}, dp1v = {0.f, 0.f};
-      const float p0i = p0 * isc, p1i = p1 * isc;
+      const float p0i = p0 * dbias, p1i = p1 * dbias;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         float2v g1;
         g1[0] = on1[2 * p] ? dh[2 * p] : 0.f;
         g1[1] = on1[2 * p + 1] ? dh[2 * p + 1] : 0.f;
         const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);               // broadcast reads
-        ab1[p] = g1 * (float2v){isc, isc} + ab1[p];
+        ab1[p] = g1 * (float2v){dbias, dbias} + ab1[p];
         aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
         dp0v = g1 * (float2v){wx.x, wx.y} + dp0v;
         if (PD == 2) {
@@ -1295,8 +1317,8 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
         }
       }
       float2 v;
-      v.x = -(dp0v[0] + dp0v[1]) * isc * srcp(fabsf(d0) + 1.f);
-      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * isc * srcp(fabsf(d1) + 1.f) : 0.f;
+      v.x = -(dp0v[0] + dp0v[1]) * dbias * srcp(fabsf(d0) + 1.f);
+      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbias * srcp(fabsf(d1) + 1.f) : 0.f;
       stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
     }
     if ((j & (CPB2_STG_KEYS - 1)) == CPB2_STG_KEYS - 1 || j == J - 1) {   // uniform: flush the staging tile
