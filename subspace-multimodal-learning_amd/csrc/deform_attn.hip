@@ -1107,19 +1107,21 @@ __global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
 //   * layer 1 itself runs on the matrix pipe: W1 p + b1 as one K = 16 split-fp16 product (13 slots: w1x, w1y in three
 //     terms x p in two, b1 in three) - a 4-register constant operand instead of 48 per-channel constants;
 //   * no software pipeline inside the wave (the sibling wave is the pipeline): nothing of the previous key is alive;
-//   * b2 and the layer-1 weights of the d vs product are read from a 512-byte LDS table when they are needed.
+//   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed;
+//   * the layer-2 pre-activations are computed once, channel-major; the query-major copy of their ReLU mask that chain 2
+//     needs is produced by the matrix pipe (mask . I).
 // Same mathematics, layouts and slab format as cpb_bwd_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
 constexpr int CPB2_WAVE_LDS = CPB_XQ + 2 * CPB2_STG_KEYS * 65;      // floats
-constexpr int CPB2_TAB = 2 * 3 * 16;                                // {w1x, w1y, b2} of ch(r) for both lane halves
+constexpr int CPB2_TAB = 2 * 2 * 16;                                // {w1x, w1y} of ch(r) for both lane halves
 
 template <int PD>
 __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
     float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: tab[2][3][16] | dvs[J*2, padded to 4] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
+  // layout: tab[2][2][16] | dvs[J*2, padded to 4] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
@@ -1135,11 +1137,10 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
   for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
   if (tid < 32) {                                           // tid = 16 half + r
     const int ch = acc_row(tid & 15, tid >> 4);
-    tab[(tid >> 4) * 48 + (tid & 15)] = cp.w1[ch * PD];
-    tab[(tid >> 4) * 48 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
-    tab[(tid >> 4) * 48 + 32 + (tid & 15)] = cp.b2[ch];
+    tab[(tid >> 4) * 32 + (tid & 15)] = cp.w1[ch * PD];
+    tab[(tid >> 4) * 32 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
   }
-  const float* tabh = tab + hf * 48;
+  const float* tabh = tab + hf * 32;
 
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
@@ -1170,6 +1171,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
   half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
   half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
   half8 idb[2];                        // identity: h1 (operand layout) . I = h1^T in accumulator layout
+  bf16x8 idq[2];                       // the same identity in bf16: mask (operand layout, lane = channel) . I = mask^T
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     float a[8], t[8];
@@ -1179,6 +1181,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
       a[j] = cp.w2[c * CH + ch];
       t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
       idb[kb][j] = (ch == c) ? (_Float16)1.0f : (_Float16)0.0f;
+      idq[kb][j] = (ch == c) ? (__bf16)1.0f : (__bf16)0.0f;
     }
     split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
     split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
@@ -1233,8 +1236,8 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hv[r] = fmaxf(xacc[r], 0.f); on1[r] = xacc[r] > 0.f; }
 
-    // ---- chains X, Y, T on the same operand registers ----
-    floatx16 dx = {0}, dy = {0}, ht = {0};
+    // ---- chains Y and T on the same operand registers ----
+    floatx16 dy = {0}, ht = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float x8[8];
@@ -1242,59 +1245,67 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
       for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
       half8 bh, bl;
       split8(x8, bh, bl);
-      dx = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, dx);       // D[out = ch(r)][query = c]  (b2 added at the mask)
       dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
       ht = mfma16(bl, idb[kb], ht);                                   // h1^T[query = acc_row(r, hf)][in = c]
       ht = mfma16(bh, idb[kb], ht);
     }
 
-    // ---- chain 2: dh1[in = ch(r)][query = c] = d bias[query] . (W2 w3)^T mask.  The mask is an exact fp16 operand and the
-    //      constant is split exactly into three terms: three MFMAs per K-block give the fp32-exact column sums, the
-    //      lane's d bias multiplies its column afterwards (no scaling of the gradient range needed) ----
-    floatx16 dh = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      uint4v mw;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int r = 8 * kb + 2 * p;
-        const float2 b2r = *reinterpret_cast<const float2*>(tabh + 32 + r);      // b2[ch(r)], b2[ch(r + 1)] (broadcast)
-        mw[p] = ((dx[r] > -b2r.x) ? 0x00003C00u : 0u) | ((dx[r + 1] > -b2r.y) ? 0x3C000000u : 0u);   // fp16 1.0 / 0
-      }
-      const half8 mk = __builtin_bit_cast(half8, mw);
-      dh = mfma16(w2tl[kb], mk, dh);
-      dh = mfma16(w2tm[kb], mk, dh);
-      dh = mfma16(w2th[kb], mk, dh);
-    }
-    ab3 += (hf == 0) ? dbias : 0.f;
-
-    // ---- channel-major stage: dW2 += mask^T g, db2 / dW3 partial sums ----
+    // ---- channel-major stage, part 1: layer-2 mask of channel c for the lane's 16 queries (exact 0 / 1 bf16 operand),
+    //      db2 / dW3 partial sums ----
     float dbq[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
       dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
     }
+    bf16x8 am[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float g8[8];
       uint4v amw;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = 8 * t + 2 * p;
-        g8[2 * p] = ht[r] * dbq[r]; g8[2 * p + 1] = ht[r + 1] * dbq[r + 1];
         const bool on0 = dy[r] > nb2c, on1 = dy[r + 1] > nb2c;
         const float2v dbm = {on0 ? dbq[r] : 0.f, on1 ? dbq[r + 1] : 0.f};
         s2 += dbm;
         s1 = (float2v){dy[r], dy[r + 1]} * dbm + s1;
         amw[p] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);
       }
+      am[t] = __builtin_bit_cast(bf16x8, amw);
+    }
+    // ---- chain 2: dh1[in = ch(r)][query = c] = d bias[query] . (W2 w3)^T mask.  Chain 2 wants the mask query-major: the
+    //      matrix pipe transposes it (mask . I, the same trick as h1^T), exact 0 / 1 values that convert to fp16 pairs.
+    //      With an exact mask operand and the constant split exactly into three terms, three MFMAs per K-block give the
+    //      fp32-exact column sums; the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
+    floatx16 mt = mfma16b(am[0], idq[0], (floatx16){0});
+    mt = mfma16b(am[1], idq[1], mt);                         // mask[out = ch(r)][query = c] as 0.0 / 1.0
+    floatx16 dh = {0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      half8 mk;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float2v v = {mt[8 * kb + 2 * p], mt[8 * kb + 2 * p + 1]};
+        const half2v hh = __builtin_convertvector(v, half2v);
+        mk[2 * p] = hh[0]; mk[2 * p + 1] = hh[1];
+      }
+      dh = mfma16(w2tl[kb], mk, dh);
+      dh = mfma16(w2tm[kb], mk, dh);
+      dh = mfma16(w2th[kb], mk, dh);
+    }
+    ab3 += (hf == 0) ? dbias : 0.f;
+
+    // ---- channel-major stage, part 2: dW2 += mask^T g with g = h1 . d bias in three bf16 terms ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float g8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) g8[jx] = ht[8 * t + jx] * dbq[8 * t + jx];
       bf16x8 g1, g2, g3;
       split8_bf3(g8, g1, g2, g3);
-      const bf16x8 am = __builtin_bit_cast(bf16x8, amw);
-      e = mfma16b(am, g3, e);
-      e = mfma16b(am, g2, e);
-      e = mfma16b(am, g1, e);
+      e = mfma16b(am[t], g3, e);
+      e = mfma16b(am[t], g2, e);
+      e = mfma16b(am[t], g1, e);
     }
 
     // ---- layer-1 backward, d vs ----
