@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   const float* B = g.B + b0 * g.sb0 + b1 * g.sb1;
   float* C = g.C + b0 * g.sc0 + b1 * g.sc1;
   const int m0 = (g.swap_xy ? blockIdx.y : blockIdx.x) * FBM, n0 = (g.swap_xy ? blockIdx.x : blockIdx.y) * BN_;
-  const int ktiles = g.K / FBK;
+  const int ktiles = (g.K + FBK - 1) / FBK;         // a K tail is zero-filled at load time
   const int tps = (ktiles + g.splitk - 1) / g.splitk;
   const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
 
@@ -164,12 +164,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
       if (A_KC) {
         const int row = (tid >> 2) + 64 * i, kq = tid & 3;
         const long long gm = min(m0 + row, g.M - 1);
-        ra[i] = *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq);
+        ra[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         const int k = (tid >> 5) + 8 * i, mq = tid & 31;
         const int gm = m0 + 4 * mq;
-        const float* p = A + (long long)(k0 + k) * g.sak;
-        if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
+        const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
+        if (k0 + k >= g.K) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
         else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
       }
     }
@@ -178,13 +180,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
       if (B_KC) {
         const int row = (tid >> 2) + 64 * i, kq = tid & 3;
         const long long gn = min(n0 + row, g.N - 1);
-        rb[i] = *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq);
+        rb[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         constexpr int NQ = BN_ / 4;                            // float4 per k-row
         const int idx = tid + 256 * i, k = idx / NQ, nq = idx - k * NQ;
         const int gn = n0 + 4 * nq;
-        const float* p = B + (long long)(k0 + k) * g.sbk;
-        if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
+        const float* p = B + (long long)min(k0 + k, g.K - 1) * g.sbk;
+        if (k0 + k >= g.K) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
         else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
       }
     }
@@ -304,15 +308,18 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
              sa0, sa1, sb0, sb1, sc0, sc1, sbias0, sbias1, bias_mode, rows_per_bias > 0 ? rows_per_bias : 1,
              bias_ld, act, splitk, alpha, beta, atomic, swap_xy};
   SMML_REQUIRE(!bias_mode || bias, "smml_gemm_f32: bias_mode set but bias is null");
-  // fast path: aligned operands with a unit stride on k or on the row index, K a multiple of 16
+  // fast path: aligned operands with a unit stride on k (then K a multiple of 4: float4 loads along k) or on the row
+  // index (any K); the K tail of the last 16-wide tile is zero-filled
   auto al4 = [](long long v) { return (v & 3) == 0; };
   auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
   const bool a_kc = (sak == 1), a_mc = (sam == 1 && sak != 1);
   const bool b_kc = (sbk == 1 && sbn != 1), b_nc = (sbn == 1);
   const bool a_ok = al16(A) && al4(sa0) && al4(sa1) && ((a_kc && al4(sam)) || (a_mc && al4(sak)));
   const bool b_ok = al16(B) && al4(sb0) && al4(sb1) && ((b_kc && al4(sbn)) || (b_nc && al4(sbk)));
-  if (a_ok && b_ok && (K % 16) == 0 && !g_force_generic) {
-    const int bn = (N > 64) ? 128 : 64;
+  const bool k_ok = (!a_kc && !b_kc) || (K % 4) == 0;
+  if (a_ok && b_ok && k_ok && !g_force_generic) {
+    // 128-wide column tiles only when they still fill the chip a few times over (2 workgroups per CU resident)
+    const int bn = (N > 64 && gx * ((N + 127) / 128) * gz >= 1024) ? 128 : 64;
     const long long fy = (N + bn - 1) / bn;
     const int fswap = fy > 65535;
     SMML_REQUIRE((fswap ? gx : fy) <= 65535, "smml_gemm_f32: grid too large");

@@ -73,7 +73,7 @@ def _gemm(A, B, C, *, M, N, K, sam, sak, sbk, sbn, ldc, bias=None, bias_mode=0, 
 def _splitk_for(out_rows: int, out_cols: int, k: int, batches: int = 1) -> int:
     tiles = ((out_rows + 127) // 128) * ((out_cols + 63) // 64) * batches
     want = max(1, 1024 // max(tiles, 1))
-    return int(max(1, min(want, (k + 511) // 512, 65535 // max(batches, 1))))
+    return int(max(1, min(want, (k + 255) // 256, 65535 // max(batches, 1))))
 
 
 def colsum(x2d_or_3d: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
