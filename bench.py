@@ -179,13 +179,13 @@ def main():
             # terms, fp32-grade result); what bounds the kernel is the fp32 vector work around them (ReLU masks, operand
             # splits, layer-1 backward) at two waves per SIMD.  Priced as algorithmic fp32 flops against the fp32 peak
             # (matrix = vector = 157.3 TF).
-            kname = "cpb_bwd2_kernel<2>"
+            kname = "cpb_bwd_kernel<2>"
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                "traffic": measured_traffic(kname, B) if (S, in_dim) == (100, 512) else None,
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                "note": "algorithmic fp32 flops (4480 per pair, recompute not counted) / fp32 matrix = vector "
-                                       "peak; executed as 42 fp16 / bf16 MFMAs + ~450 vector instructions per (key, 32 queries)"}
+                                       "peak; executed as 26 fp16 / bf16 MFMAs + ~400 vector instructions per (key, 32 queries)"}
         if "deform_attn_fwd" in kt:
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)

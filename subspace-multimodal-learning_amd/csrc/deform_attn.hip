@@ -27,8 +27,12 @@
 #ifndef SMML_FWD_WPS
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
-#ifndef SMML_BWD_WPS
-#define SMML_BWD_WPS 2      // position-bias backward: 2 = two waves per SIMD (cpb_bwd2_kernel), 1 = one software-pipelined wave
+#ifndef SMML_SPLIT_TERMS
+#define SMML_SPLIT_TERMS 3    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer: 3 = wh hh + wh hl + wm hh (what is
+                              // dropped is <= 2^-21 |w||h| per product, the size of the rounding an fp32 dot product of 32 terms
+                              // accumulates anyway); 5 adds wm hl + wl hh (<= 2^-23).  Measured against the fp64 oracle
+                              // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
+                              // 4 of 12 (forward) / 30 (backward) MFMAs per key
 #endif
 #ifndef SMML_CPB_F16
 #define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
@@ -37,27 +41,6 @@
 #endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
-#endif
-
-// diagnostic build only (-DSMML_STAMPS): s_memtime shares of the position-bias backward's loop phases, written into
-// the unused tail of the first workgroup's slab; never enabled in the shipped library
-#ifdef SMML_STAMPS
-#define SMML_STAMP_DECL unsigned long long st_[5] = {0, 0, 0, 0, 0}, sp_ = 0;
-#define SMML_STAMP(i)                                                                                     \
-  {                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    unsigned long long t_;                                                                                \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if (i > 0) st_[i] += t_ - sp_; else if (j > 0) st_[0] += t_ - sp_;                                    \
-    sp_ = t_;                                                                                             \
-  }
-#define SMML_STAMP_STORE                                                                                  \
-  if (tid == 0) { for (int i_ = 0; i_ < 5; ++i_) sl[1186 + i_] = (float)st_[i_] / (float)J; }
-#else
-#define SMML_STAMP_DECL
-#define SMML_STAMP(i)
-#define SMML_STAMP_STORE
 #endif
 
 namespace {
@@ -112,8 +95,10 @@ __device__ __forceinline__ void split8_3(const float (&x)[8], half8& hi, half8& 
 }
 // D += W . h with W = wh + wm + wl (exact) and h = bh + bl: all products down to 2^-22 of the leading one
 __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, half8 bh, half8 bl, floatx16 d) {
+#if SMML_SPLIT_TERMS == 5
   d = mfma16(wl, bh, d);
   d = mfma16(wm, bl, d);
+#endif
   d = mfma16(wm, bh, d);
   d = mfma16(wh, bl, d);
   return mfma16(wh, bh, d);
@@ -217,7 +202,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     w3v[s] = cp.w3[oi * CH + oc];
   }
 #if SMML_CPB_F16
-  // Layer 1 runs on the matrix pipe as two bf16 MFMAs (operands as in cpb_bwd2_kernel: every factor in three bf16 terms,
+  // Layer 1 runs on the matrix pipe as two bf16 MFMAs (operands as in cpb_bwd_kernel: every factor in three bf16 terms,
   // fp32-grade pre-activations, identical to what the backward recomputes); the result arrives in accumulator layout,
   // so operand slot (K-block kb, element j) of the 32x32 layer carries hidden channel acc_row(8 kb + j, hf).
   bf16x8 a1a, a1b;
@@ -681,443 +666,48 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 
 // ------------------------------------------------------------------------------------------------
 // backward of the continuous position bias: given dS^T (= d bias) recompute the MLP per (key, 32 queries) and
-// accumulate dW1, db1, dW2, db2, dW3, db3 and d vs.  Every 32x32 contraction runs on the 16-bit matrix pipe
-// (which, unlike v_mfma_f32_32x32x2_f32, does not share the fp32 ALUs with the vector work); the two register
-// layouts an MFMA can deliver are both used so that no operand is transposed through LDS:
+// accumulate dW1, db1, dW2, db2, dW3, db3 and d vs.  Every contraction runs on the 16-bit matrix pipe; the two
+// register layouts an MFMA can deliver are both used so that no operand is transposed through LDS:
 //
 //   "query-major"   lane = query, registers = channels        "channel-major"  lane = channel, registers = queries
-//   D   = W2 h1 + b2   (chain X, mask of layer 2)              D^T = h1^T W2^T    (chain Y: the SAME operand
-//   dh1 = (W2 w3)^T (mask . d bias)   (chain 2)                      registers, A and B swapped)
-//   layer-1 backward, d vs                                      db2, dW3: two scalars per lane
-//                                                               dW2 = w3 . mask^T g,  g = h1 . d bias
+//   h1  = relu(W1 p + b1)          (layer 1: two bf16 MFMAs)   D^T = h1^T W2^T      (chain Y; ReLU mask of layer 2)
+//   dh1 = d bias . (W2 w3)^T mask  (chain 2, exact)            h1^T = h1 . I        (chain T: the pipe transposes)
+//   layer-1 backward, d vs                                     db2, dW3: two scalars per lane
+//                                                              dW2 = w3 . mask^T g,  g = h1 . d bias (bf16 x 3)
+//   mask^T = mask . I  brings the layer-2 mask back to the query-major side for chain 2.
 //
-// Accuracy: chains X / Y / 2 are split-fp16 products (constant operand = hi + mid + lo exactly, activation =
-// hi + lo, 5 MFMAs per K-block, <= 2^-22 relative); chain 2's activation is d bias itself, scaled per lane by the
-// power of two that brings it into [1, 2) (exact, un-scaled on the result).  dW2 multiplies the exact 0 / 1 mask
-// with g split into three bf16 terms (fp32's exponent range, residual <= 2^-24): fp32-accurate without scaling.
-// h1 reaches the channel-major side through the matrix pipe as well (h1 . I = h1^T in accumulator layout), d bias
-// through a 128-byte LDS broadcast tile.  Per-lane partial sums are reduced per workgroup into a slab
-// [numWG][CPB_SLAB] that two small kernels add up in a fixed order (deterministic).
-// slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
+// What measurement says about gfx950 (tests/microbench/{valu,overlap,mfma}_probe.hip): a single wave issues one vector
+// instruction per ~5.2 cycles (8 when it depends on the previous one, 12 for packed forms); two waves per SIMD double that
+// rate; and an MFMA - the 16-bit forms included - occupies the SIMD for its whole duration (~32 cycles per
+// 32x32x16), it does not run beside other waves' vector work.  So the kernel is written for two resident waves (256
+// registers each) and for the fewest MFMAs + vector instructions per key: 26 + ~400.
+// Per-lane partial sums are reduced per workgroup into a slab [numWG][CPB_SLAB] that two small kernels add up in a
+// fixed order (deterministic).   slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
 // ------------------------------------------------------------------------------------------------
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
 constexpr int CPB_XQ = 2 * 32;                            // double-buffered d bias of the wave's 32 queries
-constexpr int CPB_WAVE_LDS = CPB_XQ + 2 * 32 * 65;        // + staging tile of the d vs partials; multiple of 4
-
 // D += h . W with the split ACTIVATION as the A operand (transposed product of mfma16_split)
 __device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh, half8 wm, half8 wl, floatx16 d) {
+#if SMML_SPLIT_TERMS == 5
   d = mfma16(bh, wl, d);
   d = mfma16(bl, wm, d);
+#endif
   d = mfma16(bh, wm, d);
   d = mfma16(bl, wh, d);
   return mfma16(bh, wh, d);
 }
 
-template <int PD>
-__global__ __launch_bounds__(256, 1) void cpb_bwd_kernel(
-    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
-    float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: dvs[J*2, padded to 4] | per wave: xq[2][32], stg[32][65] float2 | red[CPB_SLAB]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
-  const int o = H / G, g = h / o, oi = h - g * o;
-  const bool qvalid = (q0 + c) < N;
-  const int qi = qvalid ? (q0 + c) : (N - 1);
-
-  float* dvs = smem;                                        // [J][2]
-  float* wbase = dvs + ((2 * J + 3) & ~3);
-  float* xq = wbase + wave * CPB_WAVE_LDS;                  // [2][32]
-  float2* stg = reinterpret_cast<float2*>(xq + CPB_XQ);     // [32 keys][65]  per-lane d vs partials of the last <= 32 keys
-  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
-
-  const float gq0 = GQ[(size_t)qi * PD];
-  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
-
-  // query-major constants: this lane evaluates layer 1 for the 16 channels ch(r) = acc_row(r, hf); operand slot
-  // (K-block kb, element j) <-> channel ch(8 kb + j), i.e. the channels a lane feeds into chains X / Y / 2 are the
-  // accumulator rows chains X and 2 hand back to it (ReLU masks straight from registers)
-  float2v cw1x[8], cw1y[8], cb1[8];                        // channel pairs (registers 2 p, 2 p + 1)
-  floatx16 b2x;                                             // initial accumulator of chain X
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ch = acc_row(r, hf);
-    cw1x[r >> 1][r & 1] = cp.w1[ch * PD];
-    cw1y[r >> 1][r & 1] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
-    cb1[r >> 1][r & 1] = cp.b1[ch];
-    b2x[r] = cp.b2[ch];
-  }
-  // channel-major constants: one channel per lane
-  const float nb2c = -cp.b2[c];
-  const float w3c = cp.w3[oi * CH + c];
-
-  half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
-  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float a[8], t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = acc_row(8 * kb + j, hf);
-      a[j] = cp.w2[c * CH + ch];
-      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
-    }
-    split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
-    split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
-  }
-  // identity as a B operand: h1 (operand layout, lane = query) . I = h1^T in accumulator layout (lane = channel) -
-  // the matrix pipe transposes the activations for the dW2 product
-  half8 idb[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) idb[kb][j] = (acc_row(8 * kb + j, hf) == c) ? (_Float16)1.0f : (_Float16)0.0f;
-
-  floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
-  float2v aw1x[8], aw1y[8], ab1[8];    // channel pairs (registers 2 p, 2 p + 1)
-#pragma unroll
-  for (int p = 0; p < 8; ++p) { aw1x[p] = (float2v){0.f, 0.f}; aw1y[p] = aw1x[p]; ab1[p] = aw1x[p]; }
-  float ab3 = 0.f;
-  float2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};   // s1 = sum D^T . masked d bias, s2 = sum masked d bias (channel-major lane)
-
-  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
-  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
-  __syncthreads();
-  const int qcol = qvalid ? (q0 + c) : q0;                  // lanes past the bag end read a valid column and are zeroed
-  SMML_STAMP_DECL
-
-  // ---- the units the schedule below is built from ----
-  // positions of one key for this lane's query
-  auto positions = [&](float vx, float vy, float& d0, float& d1, float& p0, float& p1) {
-    d0 = gq0 - vx; d1 = gq1 - vy;
-    p0 = slog1p(d0);
-    p1 = (PD == 2) ? slog1p(d1) : 0.f;
-  };
-  // layer 1 of channel pair p (query-major)
-  auto layer1_pair = [&](int p, float p0, float p1, float (&hv)[16]) {
-    float2v x = cw1x[p] * (float2v){p0, p0} + cb1[p];
-    if (PD == 2) x = cw1y[p] * (float2v){p1, p1} + x;
-    hv[2 * p] = fmaxf(x[0], 0.f); hv[2 * p + 1] = fmaxf(x[1], 0.f);
-  };
-  auto split_kb = [&](int kb, const float (&hv)[16], half8& bh, half8& bl) {
-    float x8[8];
-#pragma unroll
-    for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
-    split8(x8, bh, bl);
-  };
-  // layer-1 backward of channel pair p for the previous key; the chain-2 result still carries the lane's power-of-two
-  // scale, which is folded into the multipliers (isc) instead of un-scaling the 16 values
-  float2v dp0v, dp1v;
-  auto l1b_pair = [&](int p, const float (&hvk)[16], const floatx16& dhk, float p0i, float p1i, float isck) {
-    float2v g1;
-    g1[0] = (hvk[2 * p] > 0.f) ? dhk[2 * p] : 0.f;
-    g1[1] = (hvk[2 * p + 1] > 0.f) ? dhk[2 * p + 1] : 0.f;
-    ab1[p] = g1 * (float2v){isck, isck} + ab1[p];
-    aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
-    dp0v = g1 * cw1x[p] + dp0v;
-    if (PD == 2) {
-      aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
-      dp1v = g1 * cw1y[p] + dp1v;
-    }
-  };
-  // d vs of one (query, key): per-lane partials go to the staging tile (row = key % 32)
-  auto dvs_store = [&](int jk, float d0k, float d1k, float isck) {
-    float2 v;
-    v.x = -(dp0v[0] + dp0v[1]) * isck * srcp(fabsf(d0k) + 1.f);
-    v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * isck * srcp(fabsf(d1k) + 1.f) : 0.f;
-    stg[(jk & 31) * 65 + lane] = v;
-  };
-  // every 32 keys each lane sums one (key, half) of the staging tile and lanes 0..31 add the totals to the accumulator
-  auto dvs_flush = [&](int jk) {
-    asm volatile("" ::: "memory");
-    const int kk = lane & 31, nrow = (jk & 31) + 1;
-    float sx = 0.f, sy = 0.f;
-    if (kk < nrow) {
-#pragma unroll 8
-      for (int i = 0; i < 32; ++i) {
-        const float2 t = stg[kk * 65 + 32 * hf + i];
-        sx += t.x; sy += t.y;
-      }
-    }
-    sx = xhalf_sum(sx); sy = xhalf_sum(sy);
-    if (hf == 0 && kk < nrow) {
-      const int key = (jk & ~31) + kk;
-      atomicAdd(&dvs[2 * key], sx);
-      if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
-    }
-    asm volatile("" ::: "memory");
-  };
-
-  // ---- pipeline state: key j ("c": layer 1 done one iteration ahead), key j - 1 ("p": waits for its layer-1 backward) ----
-  // The layer-1 activations of two keys are alive at any time (their ReLU masks feed the layer-1 backward two trips
-  // after they were computed): two buffers that swap roles every trip - the loop is unrolled by two by hand.
-  float hvA[16], hvB[16];
-  half8 bh_c[2], bl_c[2];
-  floatx16 dh = {0};                   // chain 2 of the previous key; overwritten by this key's chain 2 in phase 3
-  float p0_c, p1_c, d0_c, d1_c, p0_p = 0.f, p1_p = 0.f, d0_p = 0.f, d1_p = 0.f, isc_p = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) hvA[r] = 0.f;
-  positions(VSb[0], (PD == 2) ? VSb[1] : 0.f, d0_c, d1_c, p0_c, p1_c);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) layer1_pair(p, p0_c, p1_c, hvB);
-  split_kb(0, hvB, bh_c[0], bl_c[0]);
-  split_kb(1, hvB, bh_c[1], bl_c[1]);
-  float db_n = dLTb[qcol];
-
-#define SMML_SB __builtin_amdgcn_sched_barrier(0);
-  // To the compiler MFMAs and vector arithmetic are pure values: left alone they sink to their consumers, below any
-  // scheduling fence.  An empty asm that "modifies" the result pins each piece of work at its place in the stream.
-#ifndef SMML_PIN_ACC
-#define SMML_PIN_ACC "+a"
-#endif
-#define PINA(acc) asm volatile("" : SMML_PIN_ACC(acc));
-#define PINV(x) asm volatile("" : "+v"(x));
-#define MF(acc, a, b) acc = mfma16(a, b, acc); PINA(acc)
-#define MB(acc, a, b) acc = mfma16b(a, b, acc); PINA(acc)
-  // One key per trip.  The 16-bit matrix pipe runs beside the VALU, but a wave issues in order and the pipe takes one
-  // MFMA per 32 cycles: every MFMA below is followed by a unit of independent vector work and a fence, so that MFMAs
-  // never queue up behind each other with the VALU idle.
-  // hvx: in = layer-1 activations of key j - 1, out = those of key j + 1
-  auto step = [&](const int j, float (&hvx)[16]) __attribute__((always_inline)) {
-    const float dbias = qvalid ? db_n : 0.f;
-    const int jn = min(j + 1, J - 1);                       // branch-free prefetch of the next key's operands
-    db_n = dLTb[(size_t)jn * NST + qcol];
-    const float vx_n = VSb[(size_t)jn * PD];
-    const float vy_n = (PD == 2) ? VSb[(size_t)jn * PD + 1] : 0.f;
-    SMML_STAMP(0)
-    // publish this query's d bias for the channel-major stage (one wave: LDS is in order, no barrier; both halves
-    // store the same value)
-    float* xb = xq + (j & 1) * 32;
-    xb[c] = dbias;
-    // d bias spans many binades across queries: each lane (= query = one column of chain 2) scales its column by the
-    // power of two that brings |d bias| into [1, 2) and un-scales its column of the result - exact, fp16-range safe
-    float sc = 1.f, isc = 1.f;
-    {
-      const unsigned eb = (__float_as_uint(dbias) >> 23) & 0xFFu;
-      if (eb != 0u && eb != 255u) { sc = __uint_as_float((254u - eb) << 23); isc = __uint_as_float(eb << 23); }
-    }
-    const float dbs = dbias * sc;
-    const _Float16 shh = (_Float16)dbs;
-    const _Float16 sll = (_Float16)(dbs - (float)shh);
-    unsigned sh2 = (unsigned)__builtin_bit_cast(unsigned short, shh) * 0x00010001u;
-    unsigned sl2 = (unsigned)__builtin_bit_cast(unsigned short, sll) * 0x00010001u;
-    ab3 += (hf == 0) ? dbias : 0.f;
-    float dbq[16];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
-      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
-    }
-    SMML_SB
-
-    // The trip is cut into regions of 2 - 3 MFMAs plus one unit of independent vector work (two channel / query
-    // pairs, so that the unit has instruction-level parallelism of its own); inside a region the interleave
-    // MFMA, ~6 VALU, MFMA, ... is requested from the scheduler, region boundaries are fences.
-#define RG3 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0); SMML_SB
-#define RG2 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 24, 0); SMML_SB
-
-    // ---- chains X  D[out = ch(r)][query = c] = W2 h1 + b2,  T  h1^T (identity product),  Y  D^T[query][out = c]
-    //      |   layer-1 backward of key j - 1, positions and layer 1 of key j + 1 ----
-    floatx16 dx, ht, dy;
-    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
-    float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
-#define L1B(p) l1b_pair(p, hvx, dh, p0i, p1i, isc_p); l1b_pair(p + 1, hvx, dh, p0i, p1i, isc_p);                 \
-               PINV(dp0v) PINV(ab1[p]) PINV(aw1x[p]) PINV(ab1[p + 1]) PINV(aw1x[p + 1])
-    dx = mfma16(w2l[0], bh_c[0], b2x); PINA(dx)
-    ht = mfma16(bl_c[0], idb[0], (floatx16){0}); PINA(ht)
-    dy = mfma16(bh_c[0], w2l[0], (floatx16){0}); PINA(dy)     L1B(0) RG3
-    MF(dx, w2m[0], bl_c[0]) MF(ht, bh_c[0], idb[0]) MF(dy, bl_c[0], w2m[0])     L1B(2) RG3
-    MF(dx, w2m[0], bh_c[0]) MF(ht, bl_c[1], idb[1]) MF(dy, bh_c[0], w2m[0])     L1B(4) RG3
-    MF(dx, w2h[0], bl_c[0]) MF(ht, bh_c[1], idb[1]) MF(dy, bl_c[0], w2h[0])     L1B(6) RG3
-#undef L1B
-    float d0_n, d1_n, p0_n, p1_n;
-    MF(dx, w2h[0], bh_c[0]) MF(dy, bh_c[0], w2h[0])
-    dvs_store(j - 1, d0_p, d1_p, isc_p);
-    positions(vx_n, vy_n, d0_n, d1_n, p0_n, p1_n);
-    PINV(p0_n) PINV(p1_n) RG2
-    SMML_STAMP(1)
-#define L1(p) layer1_pair(p, p0_n, p1_n, hvx); layer1_pair(p + 1, p0_n, p1_n, hvx);                              \
-              PINV(hvx[2 * (p)]) PINV(hvx[2 * (p) + 1]) PINV(hvx[2 * (p) + 2]) PINV(hvx[2 * (p) + 3])
-    unsigned ghs[8], gls[8], g1s[8], g2s[8], g3s[8], ams[8];
-    // chain-2 operand elements 2 pp, 2 pp + 1 of K-block pp / 4: every non-zero element of the lane's operand is the
-    // one scaled d bias value (split once), selected by the layer-2 mask from chain X
-#define PM1(pp)                                                                                                 \
-  {                                                                                                             \
-    const unsigned pm = ((dx[2 * (pp)] > 0.f) ? 0x0000FFFFu : 0u) | ((dx[2 * (pp) + 1] > 0.f) ? 0xFFFF0000u : 0u); \
-    ghs[pp] = sh2 & pm; gls[pp] = sl2 & pm;                                                                     \
-  }
-#define PM(pp) PM1(pp) PM1(pp + 1) PINV(ghs[pp]) PINV(gls[pp]) PINV(ghs[pp + 1]) PINV(gls[pp + 1])
-    // g[in = c][query pair] = h1 . d bias in three bf16 terms (B operand of dW2)
-#define GP1(pp)                                                                                                 \
-  {                                                                                                             \
-    const float2v v = (float2v){ht[2 * (pp)], ht[2 * (pp) + 1]} * (float2v){dbq[2 * (pp)], dbq[2 * (pp) + 1]};   \
-    const bf16x2 hh = __builtin_convertvector(v, bf16x2);                                                       \
-    const float2v r1 = {v[0] - (float)hh[0], v[1] - (float)hh[1]};                                              \
-    const bf16x2 mm = __builtin_convertvector(r1, bf16x2);                                                      \
-    const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};                                            \
-    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);                                                      \
-    g1s[pp] = __builtin_bit_cast(unsigned, hh); g2s[pp] = __builtin_bit_cast(unsigned, mm);                     \
-    g3s[pp] = __builtin_bit_cast(unsigned, ll);                                                                 \
-  }
-#define GP(pp) GP1(pp) GP1(pp + 1) PINV(g1s[pp]) PINV(g2s[pp]) PINV(g3s[pp]) PINV(g1s[pp + 1]) PINV(g2s[pp + 1]) PINV(g3s[pp + 1])
-    // layer-2 mask of channel c for query pair pp (exact 0 / 1 A operand of dW2), db2 and dW3 partial sums
-#define MP1(pp)                                                                                                 \
-  {                                                                                                             \
-    const bool on0 = dy[2 * (pp)] > nb2c, on1 = dy[2 * (pp) + 1] > nb2c;                                        \
-    const float2v dbm = {on0 ? dbq[2 * (pp)] : 0.f, on1 ? dbq[2 * (pp) + 1] : 0.f};                             \
-    s2 += dbm;                                                                                                  \
-    s1 = (float2v){dy[2 * (pp)], dy[2 * (pp) + 1]} * dbm + s1;                                                  \
-    ams[pp] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);                                              \
-  }
-#define MP(pp) MP1(pp) MP1(pp + 1) PINV(ams[pp]) PINV(ams[pp + 1]) PINV(s1) PINV(s2)
-    MF(dx, w2l[1], bh_c[1]) MF(dy, bh_c[1], w2l[1])     L1(0) RG2
-    MF(dx, w2m[1], bl_c[1]) MF(dy, bl_c[1], w2m[1])     L1(2) RG2
-    MF(dx, w2m[1], bh_c[1]) MF(dy, bh_c[1], w2m[1])     L1(4) RG2
-    MF(dx, w2h[1], bl_c[1]) MF(dy, bl_c[1], w2h[1])     L1(6) RG2
-    MF(dx, w2h[1], bh_c[1]) MF(dy, bh_c[1], w2h[1])     GP(0) RG2
-    SMML_STAMP(2)
-    // ---- chain 2  dh1[in = ch(r)][query = c] = (W2 w3)^T (mask . d bias)   |   channel-major stage ----
-    GP(2) PM(0) SMML_SB
-    PM(2) GP(4) SMML_SB
-    const half8 gh0 = __builtin_bit_cast(half8, (uint4v){ghs[0], ghs[1], ghs[2], ghs[3]});
-    const half8 gl0 = __builtin_bit_cast(half8, (uint4v){gls[0], gls[1], gls[2], gls[3]});
-    dh = mfma16(w2tl[0], gh0, (floatx16){0}); PINA(dh)
-    MF(dh, w2tm[0], gl0)   PM(4) RG2
-    MF(dh, w2tm[0], gh0) MF(dh, w2th[0], gl0)   PM(6) RG2
-    const half8 gh1 = __builtin_bit_cast(half8, (uint4v){ghs[4], ghs[5], ghs[6], ghs[7]});
-    const half8 gl1 = __builtin_bit_cast(half8, (uint4v){gls[4], gls[5], gls[6], gls[7]});
-    MF(dh, w2th[0], gh0) MF(dh, w2tl[1], gh1)   GP(6) RG2
-    MF(dh, w2tm[1], gl1) MF(dh, w2tm[1], gh1)   MP(0) RG2
-    MF(dh, w2th[1], gl1) MF(dh, w2th[1], gh1)   MP(2) RG2
-    SMML_STAMP(3)
-    // ---- dW2 += mask^T g (6 bf16 MFMAs)   |   rest of the masks, operand split of key j + 1 ----
-    MP(4) SMML_SB
-    MP(6) SMML_SB
-#undef L1
-#undef PM
-#undef PM1
-#undef GP
-#undef GP1
-#undef MP
-#undef MP1
-    float x8a[8], x8b[8];
-#pragma unroll
-    for (int jx = 0; jx < 8; ++jx) { x8a[jx] = hvx[jx]; x8b[jx] = hvx[8 + jx]; }
-    const bf16x8 am0 = __builtin_bit_cast(bf16x8, (uint4v){ams[0], ams[1], ams[2], ams[3]});
-    const bf16x8 am1 = __builtin_bit_cast(bf16x8, (uint4v){ams[4], ams[5], ams[6], ams[7]});
-    const bf16x8 g10 = __builtin_bit_cast(bf16x8, (uint4v){g1s[0], g1s[1], g1s[2], g1s[3]});
-    const bf16x8 g20 = __builtin_bit_cast(bf16x8, (uint4v){g2s[0], g2s[1], g2s[2], g2s[3]});
-    const bf16x8 g30 = __builtin_bit_cast(bf16x8, (uint4v){g3s[0], g3s[1], g3s[2], g3s[3]});
-    const bf16x8 g11 = __builtin_bit_cast(bf16x8, (uint4v){g1s[4], g1s[5], g1s[6], g1s[7]});
-    const bf16x8 g21 = __builtin_bit_cast(bf16x8, (uint4v){g2s[4], g2s[5], g2s[6], g2s[7]});
-    const bf16x8 g31 = __builtin_bit_cast(bf16x8, (uint4v){g3s[4], g3s[5], g3s[6], g3s[7]});
-    MB(e, am0, g30) MB(e, am0, g20)   split8(x8a, bh_c[0], bl_c[0]); PINV(bh_c[0]) PINV(bl_c[0]) RG2
-    MB(e, am0, g10) MB(e, am1, g31)   split8(x8b, bh_c[1], bl_c[1]); PINV(bh_c[1]) PINV(bl_c[1]) RG2
-    MB(e, am1, g21) MB(e, am1, g11)   SMML_SB
-    SMML_STAMP(4)
-#undef RG2
-#undef RG3
-
-    // rotate the scalar pipeline state
-    p0_p = p0_c; p1_p = p1_c; d0_p = d0_c; d1_p = d1_c; isc_p = isc;
-    p0_c = p0_n; p1_c = p1_n; d0_c = d0_n; d1_c = d1_n;
-    if (j > 0 && ((j - 1) & 31) == 31) dvs_flush(j - 1);      // uniform branch, once per 32 keys
-  };
-  {
-    int j = 0;
-    for (; j + 1 < J; j += 2) { step(j, hvA); step(j + 1, hvB); }
-    if (j < J) step(j, hvA);
-  }
-  // drain: layer-1 backward of the last key
-  {
-    dp0v = (float2v){0.f, 0.f}; dp1v = dp0v;
-    const float p0i = p0_p * isc_p, p1i = p1_p * isc_p;
-    if ((J - 1) & 1) {                 // key J - 1 odd: its activations were written by the even trip J - 2 into hvA
-#pragma unroll
-      for (int p = 0; p < 8; ++p) l1b_pair(p, hvA, dh, p0i, p1i, isc_p);
-    } else {
-#pragma unroll
-      for (int p = 0; p < 8; ++p) l1b_pair(p, hvB, dh, p0i, p1i, isc_p);
-    }
-    dvs_store(J - 1, d0_p, d1_p, isc_p);
-    dvs_flush(J - 1);
-  }
-#undef PINA
-#undef PINV
-#undef MF
-#undef MB
-#undef SMML_SB
-
-  // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
-  __syncthreads();
-  float* red = wbase + WAVES * CPB_WAVE_LDS;                // [CPB_SLAB] accumulators in LDS
-  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
-  __syncthreads();
-  // channel-major scalars: both halves of the wave hold partial sums (their 16 queries each) of channel c
-  {
-    const float s1s = s1[0] + s1[1], s2s = s2[0] + s2[1];
-    atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
-    atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2s, s1s));   // dW3[c] = sum relu(D + b2) . d bias
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, hf);
-    atomicAdd(&red[row * CH + c], e[r] * cp.w3[oi * CH + row]);        // dW2[out = row][in = c]
-    // per-channel partials: sum over the 32 query lanes of this half
-    float v;
-    v = ab1[r >> 1][r & 1];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
-    v = aw1x[r >> 1][r & 1];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
-    v = aw1y[r >> 1][r & 1];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
-  }
-  {
-    float v = wave_sum(ab3);
-    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
-  }
-  __syncthreads();
-  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  float* sl = slab + (size_t)wg * CPB_SLAB;
-  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
-  SMML_STAMP_STORE
-  // sample-position gradients: float atomics, contiguous rows
-  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
-  for (int i = tid; i < J * PD; i += 256) {
-    const int j = i / PD, comp = i - j * PD;
-    atomicAdd(&dVSb[i], dvs[2 * j + comp]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two-waves-per-SIMD form of the position-bias backward (SMML_BWD_WPS = 2).  One wave issues a vector instruction
-// every ~5.2 cycles at best and ~8 (packed: 12) when it depends on the previous one (tests/microbench/valu_probe.hip),
-// so a single resident wave leaves a third of the issue slots empty; two waves fill each other's gaps, but must share
-// the SIMD's 512 registers: 256 each.  What makes that fit:
-//   * layer 1 itself runs on the matrix pipe: W1 p + b1 as one K = 16 split-fp16 product (13 slots: w1x, w1y in three
-//     terms x p in two, b1 in three) - a 4-register constant operand instead of 48 per-channel constants;
+// Register budget (256 per wave, two waves per SIMD):
+//   * layer 1 itself runs on the matrix pipe: W1 p + b1 as a K = 8 bf16 product with every factor in three terms - a
+//     pair of 4-register constant operands instead of 48 per-channel constants;
 //   * no software pipeline inside the wave (the sibling wave is the pipeline): nothing of the previous key is alive;
-//   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed;
-//   * the layer-2 pre-activations are computed once, channel-major; the query-major copy of their ReLU mask that chain 2
-//     needs is produced by the matrix pipe (mask . I).
-// Same mathematics, layouts and slab format as cpb_bwd_kernel.
-// ------------------------------------------------------------------------------------------------
+//   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed.
 constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
 constexpr int CPB2_WAVE_LDS = CPB_XQ + 2 * CPB2_STG_KEYS * 65;      // floats
 constexpr int CPB2_TAB = 2 * 2 * 16;                                // {w1x, w1y} of ch(r) for both lane halves
 
 template <int PD>
-__global__ __launch_bounds__(256, 2) void cpb_bwd2_kernel(
+__global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
     float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1601,19 +1191,8 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
     if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
     float* slab = (float*)workspace;
-#if SMML_BWD_WPS == 2
     const size_t lds = ((size_t)CPB2_TAB + ((2 * J + 3) & ~3) + WAVES * CPB2_WAVE_LDS + CPB_SLAB) * sizeof(float);
     SMML_REQUIRE(lds <= 80 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
-    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
-    if (posdim == 2)
-      hipLaunchKernelGGL(cpb_bwd2_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
-                         J, H, G, nst);
-    else
-      hipLaunchKernelGGL(cpb_bwd2_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
-                         J, H, G, nst);
-#else
-    const size_t lds = ((size_t)((2 * J + 3) & ~3) + WAVES * CPB_WAVE_LDS + CPB_SLAB) * sizeof(float);
-    SMML_REQUIRE(lds <= 160 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
       hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
@@ -1621,7 +1200,6 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
                          J, H, G, nst);
-#endif
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;

@@ -89,14 +89,5 @@ int main(int argc, char** argv) {
          VARIANT, B, N, J, drop_p, fwd_ms, pairs * 2496 / (fwd_ms * 1e-3) / 1e12, cpb_ms, pairs * 4480 / (cpb_ms * 1e-3) / 1e12, bwd_ms,
          checksum(out, (size_t)B * N * HD), checksum(dw2, 1024), checksum(dvs, (size_t)B * G * J * PD),
          checksum(dq, (size_t)B * N * HD));
-#ifdef SMML_STAMPS
-  {
-    float st[5];
-    hipMemcpy(st, ws + 1186, sizeof(st), hipMemcpyDeviceToHost);
-    printf("    cycles per key (wave 0 of WG 0): [4->0 loop/prefetch] %.0f  [0->1 layer 1 + chains X/Y/T issue] %.0f  [1->2 layer-1 bwd of the previous key] %.0f  "
-           "[2->3 channel-major stage + dW2] %.0f  [3->4 chain 2] %.0f  total %.0f\n", st[0], st[1], st[2], st[3], st[4],
-           st[0] + st[1] + st[2] + st[3] + st[4]);
-  }
-#endif
   return 0;
 }
