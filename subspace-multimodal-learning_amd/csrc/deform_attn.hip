@@ -1,5 +1,5 @@
 // Fused deformable cross-attention core for gfx950 (MI355X): QK^T + continuous position bias (CPB)
-// + softmax + PV, forward and backward, exact fp32 on the f32 matrix cores.
+// + softmax + PV, forward and backward; fp32 results, the position-bias MLP as split products on the 16-bit matrix pipe.
 //
 // Replaces the op sequence of the reference at
 //   models/DeformableAttention2D.py:284-312 (sim, rel_pos_bias, softmax, attn @ v) and :120-157 (CPB)
@@ -13,14 +13,16 @@
 //   logits_t / dlogits_t [B, H, J, NST]  (scores incl. bias, key-major so that a wave's 32 queries
 //   are contiguous; NST = N rounded up to 32)            PD = 2 (2-D module) or 1 (1-D module)
 //
-// Matrix-core mapping (v_mfma_f32_32x32x2_f32, one wave = 32 queries on the lane axis):
-//   S^T[key,query]  = K . Q^T            A = K tile from LDS,  B = Q rows held in 32 VGPRs
-//   D[out,query]    = W2 . relu(W1 p+b1) one 16-MFMA chain per (key, 32 queries); W2 lives in VGPRs,
-//                                        layer 1 is evaluated straight into the B operand
-//   O^T[d,query]   += V^T . P^T          the softmax'd accumulator registers are the B operand as they
-//                                        stand (the sum runs over the accumulator's row index)
-// The 32x32 CPB layer is 2048 of the 2240 flop per (query, key) pair, i.e. the kernel is bound by the
-// f32 MFMA rate (157.3 TFLOP/s peak): roofline "mfma".
+// Matrix-core mapping (one wave = 32 queries on the lane axis):
+//   S^T[key,query]  = K . Q^T            v_mfma_f32_32x32x2_f32; A = K tile from LDS, B = Q tile from LDS
+//   h1[ch,query]    = relu(W1 p + b1)    two v_mfma_f32_32x32x16_bf16 (every factor in three bf16 terms)
+//   D[out,query]    = W2 . h1 + b2       split-fp16 product on v_mfma_f32_32x32x16_f16, W2 (hi / mid / lo) in VGPRs,
+//                                        h1 (hi / lo) converted straight into the B operand
+//   O^T[d,query]   += V^T . P^T          v_mfma_f32_32x32x2_f32; the softmax'd accumulator registers are the B operand
+//                                        as they stand (the sum runs over the accumulator's row index)
+// The 32x32 CPB layer is 2048 of the 2240 flop per (query, key) pair.  On gfx950 MFMA time and vector time of a SIMD add
+// up (tests/microbench/overlap_probe.hip), so the kernels minimise both instruction counts; results are fp32-grade
+// (DESIGN.md section 4 for the error bounds and the measurements behind them).
 #include "smml_common.h"
 
 // tuning knobs (defaults = the configuration measured fastest on MI355X; tests/microbench sweeps them)
