@@ -106,11 +106,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal hooks for a one-GPU box (the N > 1 path with every rank on cuda:0 over gloo; RCCL refuses two ranks per
+    # device): SMML_BENCH_ONE_DEVICE=1 SMML_DIST_BACKEND=gloo.  Never set by the driver.
+    if os.environ.get("SMML_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("SMML_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     pkg = importlib.import_module(PKG)

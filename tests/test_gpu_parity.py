@@ -83,10 +83,12 @@ def test_gemm_layouts_and_epilogues(cuda):
 
 
 def test_gemm_fast_path_matches_generic(cuda):
-    """Aligned shapes take the tiled fast kernel; all four operand layouts, ragged M / N edges, split-K, epilogues."""
+    """Aligned shapes take the tiled fast kernel; all four operand layouts, ragged M / N edges, K tails (zero-filled last
+    tile: any K for row-contiguous operands, K % 4 == 0 for k-contiguous ones, else the generic kernel), split-K, epilogues."""
     torch.manual_seed(3)
     L = smml.lib()
-    for (M, N, K) in [(300, 200, 64), (129, 65, 16), (1000, 64, 512), (77, 130, 32)]:
+    for (M, N, K) in [(300, 200, 64), (129, 65, 16), (1000, 64, 512), (77, 130, 32), (64, 16, 2500), (132, 72, 20),
+                      (260, 128, 44), (96, 64, 18)]:
         A = torch.randn(M, K); At = A.t().contiguous(); Bm = torch.randn(K, N); Bt = Bm.t().contiguous()
         bias = torch.randn(N); res = torch.randn(M, N)
         ref = torch.relu(0.5 * (A @ Bm) + bias) + 2.0 * res
