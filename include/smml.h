@@ -53,6 +53,8 @@ int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
 /* test hook: 1 routes every product through the generic (any stride / any K) kernel instead of the tiled
  * fast path (K % 16 == 0, 16-byte aligned operands with a unit stride on k or on the row index). */
 void smml_gemm_force_generic(int on);
+/* test / tuning hook: 0 automatic (default), 1 fp32-MFMA tiled kernel only, 2 split-bf16 kernel wherever it applies */
+void smml_gemm_set_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.

@@ -24,6 +24,7 @@ SIGNATURES = {
     "smml_gemm_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _i, _i, _ll, _ll, _ll, _ll,
                            _ll, _ll, _ll, _ll, _i, _i, _ll, _i, _i, _i, _fl, _fl, _f]),
     "smml_gemm_force_generic": (None, [_i]),
+    "smml_gemm_set_mode": (None, [_i]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),
     "smml_layernorm_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _ll, _i, _ll, _fl, _i, _f]),
     "smml_colsum_f32": (_i, [_f, _f, _i, _ll, _i, _fl, _f]),

@@ -116,6 +116,26 @@ def test_gemm_fast_path_matches_generic(cuda):
     finally:
         L.smml_gemm_force_generic(0)
     _assert_close("fast vs generic", C1, C2, 1e-6)
+    # the split-bf16 kernel (three bf16 terms per operand, six products) against the fp32-MFMA kernel: all four layouts,
+    # ragged edges, a K tail, split-K
+    for (M, N, K) in [(300, 200, 96), (260, 128, 44), (1024, 130, 2500)]:
+        A = torch.randn(M, K); At = A.t().contiguous(); Bm = torch.randn(K, N); Bt = Bm.t().contiguous()
+        ref = (A.double() @ Bm.double()).float()
+        for a_kc in (True, False):
+            for b_kc in (True, False):
+                if (not a_kc and M % 4) or (not b_kc and N % 4) or ((a_kc or b_kc) and K % 4):
+                    continue
+                Ad = (A if a_kc else At).to(cuda); Bd = (Bt if b_kc else Bm).to(cuda)
+                for mode in (1, 2):
+                    L.smml_gemm_set_mode(mode)
+                    try:
+                        C = torch.zeros(M, N, device=cuda)
+                        Fh._gemm(Ad, Bd, C, M=M, N=N, K=K, sam=(K if a_kc else 1), sak=(1 if a_kc else M),
+                                 sbk=(1 if b_kc else N), sbn=(K if b_kc else 1), ldc=N, splitk=2 if K > 1000 else 1,
+                                 accumulate=1 if K > 1000 else 0)
+                    finally:
+                        L.smml_gemm_set_mode(0)
+                    _assert_close(f"mode {mode} {M}x{N}x{K} a_kc={a_kc} b_kc={b_kc}", C, ref, 2e-6)
 
 
 def test_linear_layernorm_autograd(cuda):
