@@ -550,13 +550,19 @@ constexpr int DKV_KEYS = KT * WAVES;
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dKp,
-    float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, DropCfg dc) {
+    float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, int nparts, int Bn, DropCfg dc) {
   __shared__ __attribute__((aligned(16))) float Qs[2][QT][QLD];
   __shared__ __attribute__((aligned(16))) float dOs[2][QT][QLD];
   __shared__ __attribute__((aligned(16))) float nls[2][QT];   // -lse (times log2 e on the fast path) of the tile's queries
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kg = blockIdx.x % nkg, part = blockIdx.x / nkg;
+  // XCD-aware block order: workgroups go to the 8 XCDs (each with its own L2) round-robin by linear id.  The nkg key groups
+  // of one (query slice, head, bag) read the same Q / dO tiles, so they are given ids that differ by multiples of 8:
+  // id = 8 nkg * chunk + 8 kg + x  <->  slice = 8 chunk + x.
+  const int nslices = nparts * H * Bn;
+  const int chunk = blockIdx.x / (8 * nkg), rem = blockIdx.x - chunk * (8 * nkg);
+  const int kg = rem >> 3, slice = chunk * 8 + (rem & 7);
+  if (slice >= nslices) return;                         // padding of the last chunk (whole workgroup, before any barrier)
+  const int part = slice % nparts, h = (slice / nparts) % H, b = slice / (nparts * H);
   const int j0 = kg * DKV_KEYS + wave * KT;
   const int HD = H * DH;
   const int nk = min(KT, J - j0);                       // <= 0: this wave has no keys (it still stages tiles)
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
   }
   // accumulators hold [d = acc_row(r, hf) (+32)][key = c]: each lane writes its key's 4-float runs
   if (kvalid) {
-    const size_t off = (((size_t)part * gridDim.z + b) * J + (j0 + c)) * HD + h * DH;
+    const size_t off = (((size_t)part * Bn + b) * J + (j0 + c)) * HD + h * DH;
     float* kp = dKp + off;
     float* vp = dVp + off;
 #pragma unroll
@@ -1179,8 +1185,9 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   {
     const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
     const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
-    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3(nkg * parts, H, B), block, 0, st, q, dout, lse, logits_t,
-                       dlogits_t, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, dc);
+    const int nslices = parts * H * B;
+    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3(((nslices + 7) / 8) * 8 * nkg), block, 0, st, q, dout, lse,
+                       logits_t, dlogits_t, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dkv");
     const size_t n4 = (size_t)B * J * H * DH / 4;
     hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,
