@@ -500,8 +500,24 @@ class _MatMul(torch.autograd.Function):
             Rc = _c(R)
             if Rc.shape != Cm.shape:
                 raise RuntimeError("matmul4: residual must have the output's shape")
-        _gemm(A, B, Cm, M=M, N=N, K=K, sam=sam, sak=sak, sbk=sbk, sbn=sbn, ldc=ldc, residual=Rc, ldr=ldc, nb0=nb0,
-              nb1=nb1, sa0=sa0, sa1=sa1, sb0=sb0, sb1=sb1, sc0=sc0, sc1=sc1, alpha=alpha, beta=beta)
+        # few output tiles and a long reduction (attn3 @ v: 256 x 64 outputs over n' keys): the K range is cut into S slices
+        # that run as an extra batch dimension into a partial-sum buffer, added up in a fixed order afterwards (no atomics:
+        # identical inputs give bit-identical outputs)
+        nbt = nb0 * nb1
+        full = (A.shape[0] == nb0 and A.shape[1] == nb1 and B.shape[0] == nb0 and B.shape[1] == nb1)
+        S = _splitk_for(M, N, K, nbt) if (Rc is None and not merged and full and K >= 1024) else 1
+        while S > 1 and (K % S or (K // S) % 4):
+            S -= 1
+        if S > 1:
+            Kc = K // S
+            part = torch.empty(S, nb0, nb1, M, N, device=A.device, dtype=torch.float32)
+            _gemm(A, B, part, M=M, N=N, K=Kc, sam=sam, sak=sak, sbk=sbk, sbn=sbn, ldc=N, nb0=nbt, nb1=S,
+                  sa0=A.shape[2] * A.shape[3], sa1=Kc * sak, sb0=B.shape[2] * B.shape[3], sb1=Kc * sbk,
+                  sc0=M * N, sc1=nbt * M * N, alpha=alpha)
+            torch.sum(part, dim=0, out=Cm)
+        else:
+            _gemm(A, B, Cm, M=M, N=N, K=K, sam=sam, sak=sak, sbk=sbk, sbn=sbn, ldc=ldc, residual=Rc, ldr=ldc, nb0=nb0,
+                  nb1=nb1, sa0=sa0, sa1=sa1, sb0=sb0, sb1=sb1, sc0=sc0, sc1=sc1, alpha=alpha, beta=beta)
         ctx.cfg = (ta, tb, float(alpha), float(beta), merged, nb0, nb1, M, N, K, R is not None)
         ctx.save_for_backward(A, B)
         return Cm

@@ -67,15 +67,15 @@ class NystromAttention(nn.Module):
             x = F.pad(x, (0, 0, pad, 0), value=0)              # zero rows in FRONT (:82)
         npad = n + pad
         l = math.ceil(n / m)
-        x4 = x.reshape(b, 1, npad, dim)
-        wq, wk, wv = (w.reshape(1, h, d, dim) for w in self.to_qkv.weight.chunk(3, dim=0))
-        q = Fh.matmul4(x4, wq, tb=True, alpha=self.scale)      # [b, h, n', d], already scaled (:98)
-        k = Fh.matmul4(x4, wk, tb=True)
-        v = Fh.matmul4(x4, wv, tb=True)
-        ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)  # landmarks (:102-118)
-        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True))       # [b, h, n', m]
-        a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True))      # [b, h, m, m]
-        a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True))       # [b, h, m, n']
+        # one projection GEMM for q, k and v (M = b n', N = 3 inner), then one strided copy into the head-major layout the
+        # batched products read; the softmax scale (:98) rides on the three similarity products as alpha
+        qkv = Fh.linear(x, self.to_qkv.weight)                                   # [b, n', 3 h d]
+        q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)   # each [b, h, n', d]
+        ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)  # landmarks (:102-118); ql unscaled
+        sc = self.scale
+        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True, alpha=sc))       # [b, h, n', m]
+        a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))      # [b, h, m, m]
+        a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True, alpha=sc))       # [b, h, m, n']
         z = moore_penrose_iter_pinv(a2, self.pinv_iterations)
         left = Fh.matmul4(a1, z)                               # [b, h, n', m]
         right = Fh.matmul4(a3, v)                              # [b, h, m, d]
