@@ -144,27 +144,43 @@ __global__ __launch_bounds__(256) void resconv_bwd_data_kernel(const float* __re
   *reinterpret_cast<float4*>(dv + (((long long)b * Hh + h) * n + t) * D + d4 * 4) = acc;
 }
 
-// dw[h, k] += sum_{b, t, d} dout[b, t, h*D + d] * v[b, h, t + k - KW/2, d]; one block per (h, b, chunk of t)
+// dw[h, k] += sum_{b, t, d} dout[b, t, h*D + d] * v[b, h, t + k - KW/2, d]; one block per (h, b, 64 tokens): the dout tile
+// [64][D] and the v rows it meets [64 + KW - 1][D] are staged in LDS once, thread (tap = tid / 8, sub = tid % 8) owns one tap
+// and every 8th float4 of d (float4 LDS reads; D % 4 == 0, D <= 64, KW <= 64)
+constexpr int RCW_T = 64;
 __global__ __launch_bounds__(256) void resconv_bwd_weight_kernel(const float* __restrict__ dout, const float* __restrict__ v,
-                                                                 float* __restrict__ dw, int B, int Hh, int n, int D, int KW,
-                                                                 int tchunk) {
-  __shared__ float red[64];
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int t0 = blockIdx.x * tchunk, t1 = min(n, t0 + tchunk);
-  const int tid = threadIdx.x;
-  const int half = KW / 2;
-  if (tid < 64) red[tid] = 0.f;
-  __syncthreads();
+                                                                 float* __restrict__ dw, int B, int Hh, int n, int D, int KW) {
+  extern __shared__ __attribute__((aligned(16))) float rcw[];
+  const int RCW_LD = D + 4, DQ = D >> 2;
+  float* ds = rcw;                              // [RCW_T][RCW_LD]
+  float* vs = rcw + RCW_T * RCW_LD;             // [RCW_T + KW - 1][RCW_LD]
+  float* red = vs + (RCW_T + KW - 1) * RCW_LD;  // [64]
+  const int h = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * RCW_T;
+  const int tid = threadIdx.x, half = KW / 2;
   const float* vb = v + (((long long)b * Hh + h) * n) * D;
   const float* db = dout + ((long long)b * n) * (Hh * D) + h * D;
-  // thread -> (tap k = tid % KWp, lane group): each thread owns one tap and strides over (t, d)
+  if (tid < 64) red[tid] = 0.f;
+  for (int i = tid; i < RCW_T * DQ; i += 256) {                 // DQ float4 per row
+    const int r = i / DQ, q4 = (i - r * DQ) * 4, t = t0 + r;
+    *reinterpret_cast<float4*>(&ds[r * RCW_LD + q4]) =
+        (t < n) ? *reinterpret_cast<const float4*>(db + (long long)t * (Hh * D) + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = tid; i < (RCW_T + KW - 1) * DQ; i += 256) {
+    const int r = i / DQ, q4 = (i - r * DQ) * 4, t = t0 + r - half;
+    *reinterpret_cast<float4*>(&vs[r * RCW_LD + q4]) =
+        (t >= 0 && t < n) ? *reinterpret_cast<const float4*>(vb + (long long)t * D + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int sub = tid & 7;
   for (int k = tid >> 3; k < KW; k += 32) {
     float s = 0.f;
-    const int sub = tid & 7;            // 8 threads per tap split d
-    for (int t = t0; t < t1; ++t) {
-      const int tt = t + k - half;
-      if (tt < 0 || tt >= n) continue;
-      for (int d = sub; d < D; d += 8) s = fmaf(db[(long long)t * (Hh * D) + d], vb[(long long)tt * D + d], s);
+#pragma unroll 4
+    for (int r = 0; r < RCW_T; ++r) {
+      for (int q = sub; q < DQ; q += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(&ds[r * RCW_LD + 4 * q]);
+        const float4 w = *reinterpret_cast<const float4*>(&vs[(r + k) * RCW_LD + 4 * q]);
+        s = fmaf(a.x, w.x, s); s = fmaf(a.y, w.y, s); s = fmaf(a.z, w.z, s); s = fmaf(a.w, w.w, s);
+      }
     }
     atomicAdd(&red[k], s);
   }
@@ -303,9 +319,11 @@ int smml_resconv_bwd_f32(const float* dout_merged, const float* v, const float* 
   hipLaunchKernelGGL(resconv_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout_merged, w, dv, B,
                      H, n, D, KW);
   SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/data");
-  const int tchunk = 64;
-  hipLaunchKernelGGL(resconv_bwd_weight_kernel, dim3((n + tchunk - 1) / tchunk, H, B), dim3(256), 0, st, dout_merged, v, dw,
-                     B, H, n, D, KW, tchunk);
+  SMML_REQUIRE((D % 4) == 0 && D <= 64 && KW <= 64,
+               "smml_resconv_bwd_f32: the weight-gradient kernel needs dim_head % 4 == 0, dim_head <= 64 and <= 64 taps");
+  const size_t lds = ((size_t)(2 * RCW_T + KW - 1) * (D + 4) + 64) * sizeof(float);
+  hipLaunchKernelGGL(resconv_bwd_weight_kernel, dim3((n + RCW_T - 1) / RCW_T, H, B), dim3(256), lds, st, dout_merged, v, dw,
+                     B, H, n, D, KW);
   SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/weight");
   return SMML_OK;
 }

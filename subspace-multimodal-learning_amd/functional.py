@@ -535,30 +535,30 @@ class _MatMul(torch.autograd.Function):
         _, _, b_sr, b_sc, sb0, sb1 = _op_view(B, tb)       # strides of op(B)[k, n]
         dA = dB = dR = None
 
-        def run(out, Mx, Nx, Kx, Xa, xa, Xb, xb, ld_out, bcast):
+        def run(like, Mx, Nx, Kx, Xa, xa, Xb, xb, ld_out, bcast):
             nb = nb0 * nb1
             splitk = _splitk_for(Mx, Nx, Kx, nb)
             acc = 1 if (bcast or splitk > 1) else 0
+            out = torch.zeros_like(like) if acc else torch.empty_like(like)   # zero-fill only what atomics accumulate into
             _gemm(Xa, Xb, out, M=Mx, N=Nx, K=Kx, sam=xa[0], sak=xa[1], sbk=xb[0], sbn=xb[1], ldc=ld_out, nb0=nb0, nb1=nb1,
                   sa0=xa[2], sa1=xa[3], sb0=xb[2], sb1=xb[3],
                   sc0=(out.shape[1] * out.shape[2] * out.shape[3] if out.shape[0] > 1 else 0),
                   sc1=(out.shape[2] * out.shape[3] if out.shape[1] > 1 else 0), alpha=alpha, splitk=splitk,
                   accumulate=acc)
+            return out
 
         if ctx.needs_input_grad[0]:
             bcast = (A.shape[0] < nb0) or (A.shape[1] < nb1)
-            dA = torch.zeros_like(A)
             if not ta:   # dA[m, k] = sum_n dC[m, n] opB[k, n]
-                run(dA, M, K, N, dC, (ldc, 1, sc0, sc1), B, (b_sc, b_sr, sb0, sb1), A.shape[3], bcast)
+                dA = run(A, M, K, N, dC, (ldc, 1, sc0, sc1), B, (b_sc, b_sr, sb0, sb1), A.shape[3], bcast)
             else:        # A stored [K, M]: dA[k, m] = sum_n opB[k, n] dC[m, n]
-                run(dA, K, M, N, B, (b_sr, b_sc, sb0, sb1), dC, (1, ldc, sc0, sc1), A.shape[3], bcast)
+                dA = run(A, K, M, N, B, (b_sr, b_sc, sb0, sb1), dC, (1, ldc, sc0, sc1), A.shape[3], bcast)
         if ctx.needs_input_grad[1]:
             bcast = (B.shape[0] < nb0) or (B.shape[1] < nb1)
-            dB = torch.zeros_like(B)
             if not tb:   # B stored [K, N]: dB[k, n] = sum_m opA[m, k] dC[m, n]
-                run(dB, K, N, M, A, (a_sc, a_sr, sa0, sa1), dC, (ldc, 1, sc0, sc1), B.shape[3], bcast)
+                dB = run(B, K, N, M, A, (a_sc, a_sr, sa0, sa1), dC, (ldc, 1, sc0, sc1), B.shape[3], bcast)
             else:        # B stored [N, K]: dB[n, k] = sum_m dC[m, n] opA[m, k]
-                run(dB, N, K, M, dC, (1, ldc, sc0, sc1), A, (a_sr, a_sc, sa0, sa1), B.shape[3], bcast)
+                dB = run(B, N, K, M, dC, (1, ldc, sc0, sc1), A, (a_sr, a_sc, sa0, sa1), B.shape[3], bcast)
         if has_r and ctx.needs_input_grad[2]:
             dR = dC * beta if beta != 1.0 else dC
         return dA, dB, dR, None, None, None, None, None
