@@ -18,6 +18,12 @@ SHAPES = [
     ("nystrom a1 z       a1 z", 64, 4096, 256, 256, True, False),
     ("pinv 256^3         x z", 64, 256, 256, 256, True, False),
     ("square 4096", 1, 4096, 4096, 4096, True, False),
+    # Nystrom QK / AV products at N = 10 000 (n' = 10 240), 4 bags x 8 heads
+    ("nystrom N=10k q kl^T", 32, 10240, 256, 64, True, True),
+    ("nystrom N=10k ql k^T", 32, 256, 10240, 64, True, True),
+    ("nystrom N=10k a1 z", 32, 10240, 256, 256, True, False),
+    ("nystrom N=10k a3 v", 32, 256, 64, 10240, True, False),
+    ("nystrom N=10k (a1 z)(a3 v)", 32, 10240, 64, 256, True, False),
 ]
 for name, nb, M, N, K, a_kc, b_kc in SHAPES:
     A = torch.randn(nb, M, K, device=cuda) if a_kc else torch.randn(nb, K, M, device=cuda)
