@@ -36,11 +36,6 @@
                               // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
                               // 4 of 12 (forward) / 30 (backward) MFMAs per key
 #endif
-#ifndef SMML_CPB_F16
-#define SMML_CPB_F16 1      // 1: the 32x32 position-bias layer runs on the 16-bit matrix pipe as a split-fp16 product
-                            //    (W = Wh + Wl, h1 = hh + hl; Wh hh + Wh hl + Wl hh, ~22 mantissa bits) that overlaps the
-                            //    VALU; 0: exact fp32 v_mfma_f32_32x32x2_f32 (shares the fp32 ALUs with the VALU)
-#endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
 #endif
@@ -167,9 +162,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
   __shared__ float biasT[WAVES][KT][QT];     // per-wave bias tile [key][query]
-#if !SMML_CPB_F16
-  __shared__ float4 tabB[CH];                // {w1x, w1y, b1, -} per hidden channel
-#endif
   __shared__ float Qs[WAVES][DH][QT];        // per-wave scaled Q tile, d-major
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -203,7 +195,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     b2acc[s] = cp.b2[oc];
     w3v[s] = cp.w3[oi * CH + oc];
   }
-#if SMML_CPB_F16
   // Layer 1 runs on the matrix pipe as two bf16 MFMAs (operands as in cpb_bwd_kernel: every factor in three bf16 terms,
   // fp32-grade pre-activations, identical to what the backward recomputes); the result arrives in accumulator layout,
   // so operand slot (K-block kb, element j) of the 32x32 layer carries hidden channel acc_row(8 kb + j, hf).
@@ -229,19 +220,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
     split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
   }
-#else
-  float w2a[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) w2a[s] = cp.w2[c * CH + 16 * hf + s];       // A[i = out = c][k = in = 16 hf + s]
-  if (tid < 32) {
-    float4 t;
-    t.x = cp.w1[tid * PD];
-    t.y = (PD == 2) ? cp.w1[tid * PD + 1] : 0.f;
-    t.z = cp.b1[tid];
-    t.w = 0.f;
-    tabB[tid] = t;
-  }
-#endif
   const float b3 = cp.b3[oi];
 
   floatx16 oacc0 = {0}, oacc1 = {0};
@@ -288,7 +266,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       const float p0 = slog1p(gq0 - vsl[jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
-#if SMML_CPB_F16
       // layer 1 on the matrix pipe, ReLU, fp16 hi / lo split, five MFMAs per K-block
       floatx16 xacc;
       {
@@ -313,15 +290,6 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
         split8(hv, bh, bl);
         d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
       }
-#else
-#pragma unroll
-      for (int sp = 0; sp < 16; ++sp) {
-        const float4 t = tabB[16 * hf + sp];
-        float hv = fmaf(t.x, p0, t.z);
-        if (PD == 2) hv = fmaf(t.y, p1, hv);
-        d = mfma32(w2a[sp], fmaxf(hv, 0.f), d);
-      }
-#endif
       float t3 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t3 = fmaf(fmaxf(d[r], 0.f), w3v[r], t3);
