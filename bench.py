@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bags", type=int, default=4, help="bags per GPU per step")
+    ap.add_argument("--bags", type=int, default=8, help="bags per GPU per step (the reference trains with batch_size 8 per rank, config/config_mine.yaml:38)")
     ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
