@@ -91,12 +91,13 @@ int smml_offsets_out_len(int s, int ks, int r);
 int smml_offsets_fwd_f32(const float* q, const float* w0, const float* b0, const float* w2, float* vgrid,
                          float* vs, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
                          float offset_scale, void* stream);
-/* upstream gradient = dvgrid (direct, nullable) + 2/max(t-1,1) * dvs (nullable); dq is accumulated
- * into (float atomics); dw0 / db0 / dw2 accumulated into. */
+/* upstream gradient = dvgrid (direct, nullable) + 2/max(t-1,1) * dvs (nullable); dq, dw0, db0, dw2 are overwritten
+ * (gather formulation, no atomics); workspace: smml_offsets_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
+size_t smml_offsets_bwd_workspace_bytes(int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim);
 int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const float* w2,
                          const float* dvgrid, const float* dvs, float* dq, float* dw0, float* db0,
-                         float* dw2, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
-                         float offset_scale, void* stream);
+                         float* dw2, void* workspace, size_t workspace_bytes, int B, int Hh, int Ww, int G, int dg,
+                         int ks, int r, int posdim, float offset_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear sampling = F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) of the

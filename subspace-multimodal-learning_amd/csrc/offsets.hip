@@ -50,13 +50,21 @@ __global__ __launch_bounds__(256) void offsets_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ w0, const float* __restrict__ b0,
     const float* __restrict__ w2, float* __restrict__ vgrid, float* __restrict__ vs, int B, int Hh, int Ww, int G,
     int kh, int kw, int rh, int rw, int ph, int pw, int th, int tw, int PD, float offset_scale) {
+  // depthwise weights transposed to [tap][channel] in LDS: the per-tap read of a wave is then one contiguous row instead
+  // of a cache line per lane
+  extern __shared__ float w0s[];
+  const int dg = 64 * CPL, inner = G * dg, KK = kh * kw;
+  for (int i = threadIdx.x; i < dg * KK; i += blockDim.x) {
+    const int ch = i / KK, t = i - ch * KK;
+    w0s[t * dg + ch] = w0[i];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int J = th * tw, npts = B * G * J;
   if (wid >= npts) return;
   const int bg = wid / J, j = wid - bg * J, b = bg / G, g = bg - b * G;
   const int ty = j / tw, tx = j - ty * tw;
-  const int dg = 64 * CPL, inner = G * dg;
   float o0 = 0.f, o1 = 0.f;
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256) void offsets_fwd_kernel(
       for (int kx = 0; kx < kw; ++kx) {
         const int ix = tx * rw - pw + kx;
         if (ix < 0 || ix >= Ww) continue;
-        acc = fmaf(w0[(ch * kh + ky) * kw + kx], q[(((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch], acc);
+        acc = fmaf(w0s[(ky * kw + kx) * dg + ch], q[(((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch], acc);
       }
     }
     const float ge = gelu_erf(acc);
@@ -95,14 +103,19 @@ __global__ __launch_bounds__(256) void offsets_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// offsets backward: d vgrid (direct) + d vs  ->  dq (atomic scatter-add), dw0, db0, dw2
-// each wave walks points with a grid stride and keeps its weight-gradient partials in registers
+// offsets backward: d vgrid (direct) + d vs  ->  dq, dw0, db0, dw2, in three deterministic passes (no global atomics):
+//   1. point pass: each wave walks sampled points with a grid stride, recomputes the forward, stores the gradient
+//      dy[point][channel] of the depthwise conv's output and keeps its weight-gradient partials in registers; the
+//      workgroup's partials are summed in LDS and written to a slab [workgroup][nred]
+//   2. gather pass: every q element sums dy . w0 over the (at most ceil(k / r)^2 = 4) windows that cover it
+//      (the scatter form needed 2304 float atomics per point: 92 M per step at B = 8, L2-atomic bound)
+//   3. slab reduction in a fixed order
 // ---------------------------------------------------------------------------------------------
 template <int CPL, int KH, int KW>
 __global__ __launch_bounds__(256) void offsets_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ w0, const float* __restrict__ b0,
     const float* __restrict__ w2, const float* __restrict__ dvgrid, const float* __restrict__ dvs,
-    float* __restrict__ dq, float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw2, int B, int Hh,
+    float* __restrict__ dyb, float* __restrict__ slab, int B, int Hh,
     int Ww, int G, int rh, int rw, int ph, int pw, int th, int tw, int PD, float offset_scale) {
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
         dge = fmaf(ds1, w2[dg + ch], dge);
       }
       const float dy = dge * gelu_erf_grad(y[u]);
+      dyb[(size_t)wid * dg + ch] = dy;
       ab0[u] += dy;
 #pragma unroll
       for (int ky = 0; ky < KH; ++ky) {
@@ -176,14 +190,12 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
           if (iy >= 0 && iy < Hh && ix >= 0 && ix < Ww) {
             const size_t qi = (((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch;
             aw0[u][ky * KW + kx] = fmaf(dy, q[qi], aw0[u][ky * KW + kx]);
-            atomicAdd(&dq[qi], dy * w0[(ch * KH + ky) * KW + kx]);
           }
         }
       }
     }
   }
-  // weight-gradient partials: sum the workgroup's waves in LDS, then ONE contiguous row of float atomics per
-  // workgroup (per-lane atomics at a 144-B stride from every wave ran an order of magnitude slower)
+  // weight-gradient partials: sum the workgroup's waves in LDS, then one contiguous slab row per workgroup
   __shared__ float red[128 * (KH * KW + 3)];
   constexpr int KK = KH * KW;
   const int nred = dg * (KK + 1 + 2);
@@ -199,12 +211,57 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
     if (PD == 2) atomicAdd(&red[dg * (KK + 2) + ch], aw2[u][1]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nred; i += blockDim.x) {
-    const float v = red[i];
-    if (i < dg * KK) atomicAdd(&dw0[i], v);
-    else if (i < dg * (KK + 1)) atomicAdd(&db0[i - dg * KK], v);
-    else if (i < dg * (KK + 1 + PD)) atomicAdd(&dw2[i - dg * (KK + 1)], v);
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) slab[(size_t)blockIdx.x * nred + i] = red[i];
+}
+
+// dq[b, y, x, g*dg + ch] = sum over the windows (ty, tx) covering (y, x) of dy[(b, g, ty, tx)][ch] * w0[ch][ky][kx];
+// one block row per (b, y), a thread per (x, 4 channels): float4 loads of dy, float4 store of dq
+__global__ __launch_bounds__(256) void offsets_bwd_gather_kernel(const float* __restrict__ dyb, const float* __restrict__ w0,
+                                                                 float* __restrict__ dq, int Hh, int Ww, int G, int dg, int KH,
+                                                                 int KW, int rh, int rw, int ph, int pw, int th, int tw) {
+  const int inner = G * dg, iq = inner >> 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Ww * iq) return;
+  const int x = t / iq, c4 = (t - x * iq) * 4, g = c4 / dg, ch = c4 - g * dg;
+  const int y = blockIdx.y % Hh, b = blockIdx.y / Hh;
+  const int ty1 = min(th - 1, (y + ph) / rh), ty0 = max(0, (y + ph - (KH - 1) + rh - 1) / rh);
+  const int tx1 = min(tw - 1, (x + pw) / rw), tx0 = max(0, (x + pw - (KW - 1) + rw - 1) / rw);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int KK = KH * KW;
+  for (int ty = ty0; ty <= ty1; ++ty) {
+    const int ky = y + ph - ty * rh;
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int kx = x + pw - tx * rw;
+      const float4 d = *reinterpret_cast<const float4*>(dyb + ((size_t)(b * G + g) * th * tw + ty * tw + tx) * dg + ch);
+      const float* w = w0 + ch * KK + ky * KW + kx;
+      acc.x = fmaf(d.x, w[0], acc.x); acc.y = fmaf(d.y, w[KK], acc.y);
+      acc.z = fmaf(d.z, w[2 * KK], acc.z); acc.w = fmaf(d.w, w[3 * KK], acc.w);
+    }
   }
+  *reinterpret_cast<float4*>(dq + (((size_t)b * Hh + y) * Ww + x) * inner + c4) = acc;
+}
+
+// column sums of a slab [nrows][nred] in two fixed-order stages: part[p][i] = sum of rows p*chunk .. ; then the final sum
+// scattered into dw0 | db0 | dw2
+constexpr int OFF_RED_PARTS = 32;
+__global__ void offsets_bwd_partial_kernel(const float* __restrict__ slab, int nrows, int nred, int chunk,
+                                           float* __restrict__ part) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nred) return;
+  const int r0 = blockIdx.y * chunk, r1 = min(nrows, r0 + chunk);
+  float v = 0.f;
+  for (int k = r0; k < r1; ++k) v += slab[(size_t)k * nred + i];
+  part[(size_t)blockIdx.y * nred + i] = v;
+}
+__global__ void offsets_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int nred, int dg, int KK, int PD,
+                                          float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nred) return;
+  float v = 0.f;
+  for (int k = 0; k < nparts; ++k) v += part[(size_t)k * nred + i];
+  if (i < dg * KK) dw0[i] = v;
+  else if (i < dg * (KK + 1)) db0[i - dg * KK] = v;
+  else if (i < dg * (KK + 1 + PD)) dw2[i - dg * (KK + 1)] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,44 +380,72 @@ int smml_offsets_fwd_f32(const float* q, const float* w0, const float* b0, const
   const int npts = B * G * th * tw;
   dim3 grid((npts + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)dg * kh * ks * sizeof(float);
   if (dg == 64)
-    hipLaunchKernelGGL(offsets_fwd_kernel<1>, grid, block, 0, st, q, w0, b0, w2, vgrid, vs, B, Hh, Ww, G, kh, ks, rh,
+    hipLaunchKernelGGL(offsets_fwd_kernel<1>, grid, block, lds, st, q, w0, b0, w2, vgrid, vs, B, Hh, Ww, G, kh, ks, rh,
                        r, ph, pw, th, tw, posdim, offset_scale);
   else
-    hipLaunchKernelGGL(offsets_fwd_kernel<2>, grid, block, 0, st, q, w0, b0, w2, vgrid, vs, B, Hh, Ww, G, kh, ks, rh,
+    hipLaunchKernelGGL(offsets_fwd_kernel<2>, grid, block, lds, st, q, w0, b0, w2, vgrid, vs, B, Hh, Ww, G, kh, ks, rh,
                        r, ph, pw, th, tw, posdim, offset_scale);
   SMML_LAUNCH_CHECK("smml_offsets_fwd_f32");
   return SMML_OK;
 }
 
-// dq is accumulated into (atomics); dw0 / db0 / dw2 must be zeroed by the caller.
+static int offsets_bwd_blocks(int npts) { return min((npts + 3) / 4, 2048); }
+
+// scratch of the backward: dy [points][dg] + weight-gradient slabs [workgroups][dg * (kh*ks + 3)]
+size_t smml_offsets_bwd_workspace_bytes(int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim) {
+  int kh, rh, ph, th, tw;
+  if (offsets_geometry("smml_offsets_bwd_workspace_bytes", Hh, Ww, dg, ks, r, posdim, &kh, &rh, &ph, &th, &tw)) return 0;
+  const size_t npts = (size_t)B * G * th * tw;
+  return (npts * dg + (size_t)(offsets_bwd_blocks((int)npts) + OFF_RED_PARTS) * dg * (kh * ks + 3)) * sizeof(float);
+}
+
+// dq, dw0, db0, dw2 are overwritten (no atomics, run-to-run identical).
 int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const float* w2, const float* dvgrid,
-                         const float* dvs, float* dq, float* dw0, float* db0, float* dw2, int B, int Hh, int Ww,
-                         int G, int dg, int ks, int r, int posdim, float offset_scale, void* stream) {
-  SMML_REQUIRE(q && w0 && b0 && w2 && dq && dw0 && db0 && dw2, "smml_offsets_bwd_f32: null pointer");
+                         const float* dvs, float* dq, float* dw0, float* db0, float* dw2, void* workspace,
+                         size_t workspace_bytes, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
+                         float offset_scale, void* stream) {
+  SMML_REQUIRE(q && w0 && b0 && w2 && dq && dw0 && db0 && dw2 && workspace, "smml_offsets_bwd_f32: null pointer");
   SMML_REQUIRE(dvgrid || dvs, "smml_offsets_bwd_f32: no upstream gradient");
   SMML_REQUIRE(ks == 6, "smml_offsets_bwd_f32: only offset_kernel_size = 6 is instantiated (got %d)", ks);
   int kh, rh, ph, th, tw;
   int rc = offsets_geometry("smml_offsets_bwd_f32", Hh, Ww, dg, ks, r, posdim, &kh, &rh, &ph, &th, &tw);
   if (rc) return rc;
+  SMML_REQUIRE(workspace_bytes >= smml_offsets_bwd_workspace_bytes(B, Hh, Ww, G, dg, ks, r, posdim),
+               "smml_offsets_bwd_f32: workspace too small");
   const int pw = (ks - r) / 2;
   const int npts = B * G * th * tw;
-  const int nblk = min((npts + 3) / 4, 512);
+  const int nblk = offsets_bwd_blocks(npts);
+  const int nred = dg * (kh * ks + 3);
+  float* dyb = (float*)workspace;
+  float* slab = dyb + (size_t)npts * dg;
   dim3 grid(nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (posdim == 2 && dg == 64)
-    hipLaunchKernelGGL((offsets_bwd_kernel<1, 6, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dq, dw0, db0, dw2,
+    hipLaunchKernelGGL((offsets_bwd_kernel<1, 6, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dyb, slab,
                        B, Hh, Ww, G, rh, r, ph, pw, th, tw, posdim, offset_scale);
   else if (posdim == 2 && dg == 128)
-    hipLaunchKernelGGL((offsets_bwd_kernel<2, 6, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dq, dw0, db0, dw2,
+    hipLaunchKernelGGL((offsets_bwd_kernel<2, 6, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dyb, slab,
                        B, Hh, Ww, G, rh, r, ph, pw, th, tw, posdim, offset_scale);
   else if (posdim == 1 && dg == 64)
-    hipLaunchKernelGGL((offsets_bwd_kernel<1, 1, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dq, dw0, db0, dw2,
+    hipLaunchKernelGGL((offsets_bwd_kernel<1, 1, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dyb, slab,
                        B, Hh, Ww, G, rh, r, ph, pw, th, tw, posdim, offset_scale);
   else
-    hipLaunchKernelGGL((offsets_bwd_kernel<2, 1, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dq, dw0, db0, dw2,
+    hipLaunchKernelGGL((offsets_bwd_kernel<2, 1, 6>), grid, block, 0, st, q, w0, b0, w2, dvgrid, dvs, dyb, slab,
                        B, Hh, Ww, G, rh, r, ph, pw, th, tw, posdim, offset_scale);
-  SMML_LAUNCH_CHECK("smml_offsets_bwd_f32");
+  SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/points");
+  SMML_REQUIRE((dg % 4) == 0, "smml_offsets_bwd_f32: channels per group must be a multiple of 4");
+  hipLaunchKernelGGL(offsets_bwd_gather_kernel, dim3((Ww * (G * dg / 4) + 255) / 256, B * Hh), block, 0, st, dyb, w0, dq, Hh,
+                     Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
+  SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/gather");
+  float* part = slab + (size_t)nblk * nred;
+  const int chunk = (nblk + OFF_RED_PARTS - 1) / OFF_RED_PARTS;
+  hipLaunchKernelGGL(offsets_bwd_partial_kernel, dim3((nred + 255) / 256, OFF_RED_PARTS), block, 0, st, slab, nblk, nred, chunk,
+                     part);
+  hipLaunchKernelGGL(offsets_bwd_reduce_kernel, dim3((nred + 255) / 256), block, 0, st, part, OFF_RED_PARTS, nred, dg, kh * ks,
+                     posdim, dw0, db0, dw2);
+  SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/reduce");
   return SMML_OK;
 }
 

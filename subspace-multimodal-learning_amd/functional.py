@@ -266,14 +266,17 @@ class _Offsets(torch.autograd.Function):
         groups, ks, r, posdim, offset_scale = ctx.cfg
         B, Hh, Ww, inner = q.shape
         dg = inner // groups
-        dq = torch.zeros_like(q)
-        dw0, db0, dw2 = torch.zeros_like(w0), torch.zeros_like(b0), torch.zeros_like(w2)
+        dq = torch.empty_like(q)
+        dw0, db0, dw2 = torch.empty_like(w0), torch.empty_like(b0), torch.empty_like(w2)
         dvgrid = _c(dvgrid) if dvgrid is not None else None
         dvs = _c(dvs) if dvs is not None else None
-        capi.check(capi.lib().smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
-                                                   capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
-                                                   capi.fptr(db0), capi.fptr(dw2), B, Hh, Ww, groups, dg, ks, r, posdim,
-                                                   offset_scale, capi.stream()), "offsets_bwd")
+        L = capi.lib()
+        wsb = L.smml_offsets_bwd_workspace_bytes(B, Hh, Ww, groups, dg, ks, r, posdim)
+        ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
+        capi.check(L.smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
+                                          capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
+                                          capi.fptr(db0), capi.fptr(dw2), capi.fptr(ws), wsb, B, Hh, Ww, groups, dg, ks, r,
+                                          posdim, offset_scale, capi.stream()), "offsets_bwd")
         return dq, dw0, db0, dw2, None, None, None, None, None
 
 
