@@ -65,7 +65,6 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-typedef float float2v __attribute__((ext_vector_type(2)));
 // split 8 fp32 values into fp16 hi + fp16 lo, both round-to-nearest: x - hi is exact in fp32, so hi + lo carries
 // ~23 mantissa bits (residual <= 2^-24 |x|)
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
@@ -99,28 +98,6 @@ __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, h
   d = mfma16(wm, bh, d);
   d = mfma16(wh, bl, d);
   return mfma16(wh, bh, d);
-}
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// x = a + b + c with three bf16 terms (round-to-nearest each): residual <= 2^-24 |x|, fp32's exponent range
-__device__ __forceinline__ void split8_bf3(const float (&x)[8], bf16x8& a, bf16x8& b, bf16x8& c) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float2v v = {x[2 * i], x[2 * i + 1]};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    const float2v r1 = {v[0] - (float)h[0], v[1] - (float)h[1]};
-    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-    const float2v r2 = {r1[0] - (float)m[0], r1[1] - (float)m[1]};
-    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-    a[2 * i] = h[0]; a[2 * i + 1] = h[1];
-    b[2 * i] = m[0]; b[2 * i + 1] = m[1];
-    c[2 * i] = l[0]; c[2 * i + 1] = l[1];
-  }
 }
 
 // Attention dropout (nn.Dropout on the softmax'd probabilities, DeformableAttention2D.py:309): a counter-based
@@ -362,11 +339,16 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // backward pass 1 (query owners): dS^T = P^T (dP^T - delta), dQ = scale * dS K
-//   reads logits_t, writes dlogits_t (same layout) and dq.  K / V tiles are double-buffered in LDS and the next
-//   tile's K, V and logits loads are in flight while the current tile's 64 MFMAs run (one barrier per tile).
+//   reads logits_t, writes dlogits_t (same layout) and dq.  Both contractions run on the 16-bit matrix pipe as
+//   three-term bf16 products (fp32-grade, 48 MFMAs of 32 cycles per 32-key tile instead of 64 of 64): K / V tiles are
+//   split when they are staged (three bf16 planes each, double-buffered, the next tile's K, V and logits loads in flight
+//   during the MFMAs; one barrier per tile), dO once per wave, dS^T per tile.
+//   V planes [key][72]: the dP^T A operand (lane = key, 8 consecutive d) is one ds_read_b128.
+//   K planes [key][96]: dQ^T needs K^T (lane = d, 8 keys): two ds_read_b64_tr_b16 per fragment; 192-byte rows keep the
+//   four key rows of a transposed read on disjoint banks.
 // ------------------------------------------------------------------------------------------------
-constexpr int VLD = DH + 4;   // V tile [key][d]: 16-B aligned rows, ds_read_b128 across 16 keys conflict-free (slot = key mod 16)
-constexpr int KLD = KT + 4;   // K^T tile [d][key]: same for 16 d-rows (slot = 9 d mod 16)
+constexpr int VBLD = DH + 8;    // halves per row of a V plane
+constexpr int KBLD = DH + 32;   // halves per row of a K plane
 constexpr float LOG2E = 1.4426950408889634f;
 
 #if SMML_FAST_MATH
@@ -383,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
     float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST,
     float scale, DropCfg dc) {
-  __shared__ __attribute__((aligned(16))) float Vr[2][KT][VLD];   // A operand of dP^T = V . dO^T
-  __shared__ __attribute__((aligned(16))) float Kt[2][DH][KLD];   // A operand of dQ^T = K^T . dS^T
+  __shared__ __attribute__((aligned(16))) __bf16 Vp[2][3][KT * VBLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Kp[2][3][KT * KBLD];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -394,17 +376,18 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const int qi = qvalid ? (q0 + c) : (N - 1);
   const int qcol = qvalid ? (q0 + c) : 0;            // column of this lane in the key-major score rows
 
-  float doreg[32];
+  // dO of this lane's query as the B operand of dP^T = V . dO^T: K-block kb holds d = 16 kb + 8 hf + j
+  bf16x8 doh[4], dom[4], dol[4];
   float delta = 0.f;
   {
-    const size_t off = ((size_t)b * N + qi) * HD + h * DH + hf * 32;
-    const float4* dp = reinterpret_cast<const float4*>(dO + off);
-    const float4* op = reinterpret_cast<const float4*>(O + off);
+    const size_t off = ((size_t)b * N + qi) * HD + h * DH + hf * 8;
 #pragma unroll
-    for (int s4 = 0; s4 < 8; ++s4) {
-      const float4 t = dp[s4], u = op[s4];
-      doreg[4 * s4 + 0] = t.x; doreg[4 * s4 + 1] = t.y; doreg[4 * s4 + 2] = t.z; doreg[4 * s4 + 3] = t.w;
-      delta += t.x * u.x + t.y * u.y + t.z * u.z + t.w * u.w;
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 t0 = *reinterpret_cast<const float4*>(dO + off + 16 * kb), t1 = *reinterpret_cast<const float4*>(dO + off + 16 * kb + 4);
+      const float4 u0 = *reinterpret_cast<const float4*>(O + off + 16 * kb), u1 = *reinterpret_cast<const float4*>(O + off + 16 * kb + 4);
+      delta += t0.x * u0.x + t0.y * u0.y + t0.z * u0.z + t0.w * u0.w + t1.x * u1.x + t1.y * u1.y + t1.z * u1.z + t1.w * u1.w;
+      const float x8[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      split8_bf3(x8, doh[kb], dom[kb], dol[kb]);
     }
   }
   delta = xhalf_sum(delta);
@@ -418,6 +401,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 
   // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
   const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  // transposed-read lane map (lane 4 q + p of a 16-lane group: row q, columns 4 p .. 4 p + 3)
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   float4 kreg[2], vreg[2];
   float lt[16];
   auto fetch = [&](int j0, float4 (&kr)[2], float4 (&vr)[2], float (&l)[16]) {
@@ -445,9 +430,15 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = skey + 16 * i;
-      *reinterpret_cast<float4*>(&Vr[buf][key][sd4]) = vreg[i];
-      Kt[buf][sd4 + 0][key] = kreg[i].x; Kt[buf][sd4 + 1][key] = kreg[i].y;
-      Kt[buf][sd4 + 2][key] = kreg[i].z; Kt[buf][sd4 + 3][key] = kreg[i].w;
+      uint2v hh, mm, ll;
+      split4_bf3(vreg[i], hh, mm, ll);
+      *reinterpret_cast<uint2v*>(&Vp[buf][0][key * VBLD + sd4]) = hh;
+      *reinterpret_cast<uint2v*>(&Vp[buf][1][key * VBLD + sd4]) = mm;
+      *reinterpret_cast<uint2v*>(&Vp[buf][2][key * VBLD + sd4]) = ll;
+      split4_bf3(kreg[i], hh, mm, ll);
+      *reinterpret_cast<uint2v*>(&Kp[buf][0][key * KBLD + sd4]) = hh;
+      *reinterpret_cast<uint2v*>(&Kp[buf][1][key * KBLD + sd4]) = mm;
+      *reinterpret_cast<uint2v*>(&Kp[buf][2][key * KBLD + sd4]) = ll;
     }
     __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2, which every wave left before this barrier's
                             // predecessor: one barrier per tile is enough
@@ -459,15 +450,15 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     // dP^T[key, query] = V . dO^T
     floatx16 dp = {0};
 #pragma unroll
-    for (int s4 = 0; s4 < 8; ++s4) {
-      const float4 a = *reinterpret_cast<const float4*>(&Vr[buf][c][32 * hf + 4 * s4]);
-      dp = mfma32(a.x, doreg[4 * s4 + 0], dp);
-      dp = mfma32(a.y, doreg[4 * s4 + 1], dp);
-      dp = mfma32(a.z, doreg[4 * s4 + 2], dp);
-      dp = mfma32(a.w, doreg[4 * s4 + 3], dp);
+    for (int kb = 0; kb < 4; ++kb) {
+      const int o = c * VBLD + 16 * kb + 8 * hf;
+      const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&Vp[buf][0][o]);
+      const bf16x8 vm = *reinterpret_cast<const bf16x8*>(&Vp[buf][1][o]);
+      const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&Vp[buf][2][o]);
+      dp = mfma16b_x6(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
     }
 
-    floatx16 ds;
+    float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = acc_row(r, hf);
@@ -481,15 +472,24 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       }
       ds[r] = v;
     }
-    // dQ^T[d, query] += K^T . dS^T
+    // dQ^T[d, query] += K^T . dS^T: accumulator register 8 kb + j of dS^T is element j of K-block kb (keys 16 kb + 4 hf + 0..3
+    // and 16 kb + 8 + 4 hf + 0..3), the K^T fragment is gathered for the same keys by two transposed reads
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 a0 = *reinterpret_cast<const float4*>(&Kt[buf][c][8 * rg + 4 * hf]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&Kt[buf][32 + c][8 * rg + 4 * hf]);
-      dq0 = mfma32(a0.x, ds[4 * rg + 0], dq0); dq1 = mfma32(a1.x, ds[4 * rg + 0], dq1);
-      dq0 = mfma32(a0.y, ds[4 * rg + 1], dq0); dq1 = mfma32(a1.y, ds[4 * rg + 1], dq1);
-      dq0 = mfma32(a0.z, ds[4 * rg + 2], dq0); dq1 = mfma32(a1.z, ds[4 * rg + 2], dq1);
-      dq0 = mfma32(a0.w, ds[4 * rg + 3], dq0); dq1 = mfma32(a1.w, ds[4 * rg + 3], dq1);
+    for (int kb = 0; kb < 2; ++kb) {
+      float x8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) x8[jx] = ds[8 * kb + jx];
+      bf16x8 sh, sm, sl;
+      split8_bf3(x8, sh, sm, sl);
+      const int ro = (16 * kb + 4 * hf + trq) * KBLD + trc;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const bf16x8 kh = lds_frag_tr(&Kp[buf][0][ro + 32 * db], &Kp[buf][0][ro + 32 * db + 8 * KBLD]);
+        const bf16x8 km = lds_frag_tr(&Kp[buf][1][ro + 32 * db], &Kp[buf][1][ro + 32 * db + 8 * KBLD]);
+        const bf16x8 kl = lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]);
+        if (db == 0) dq0 = mfma16b_x6(kh, km, kl, sh, sm, sl, dq0);
+        else dq1 = mfma16b_x6(kh, km, kl, sh, sm, sl, dq1);
+      }
     }
   }
   if (qvalid) {
@@ -508,19 +508,21 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward pass 2 (key owners): dV = P_dropped^T dO, dK = scale * dS^T Q.  A workgroup owns 128 keys (one 32-key
 // tile per wave) and one slice of the query tiles; its four waves consume the same Q / dO tile from LDS (staged
-// once per workgroup, double-buffered, the next tile's global loads in flight during the 64 MFMAs).  The partial
-// sums of the query slices go to slabs [nparts][B, J, H*64] that dkv_reduce_kernel adds up in a fixed order
-// (no atomics: run-to-run identical results).
+// once per workgroup as three bf16 planes each, double-buffered, the next tile's global loads in flight during the
+// MFMAs).  Both contractions are three-term bf16 products on the 16-bit matrix pipe (48 MFMAs per tile): the A operands
+// Q^T / dO^T (lane = d, 8 queries) are gathered from the row-major planes by ds_read_b64_tr_b16, the B operands P and
+// dS are split from registers.  The partial sums of the query slices go to slabs [nparts][B, J, H*64] that
+// dkv_reduce_kernel adds up in a fixed order (no atomics: run-to-run identical results).
 // ------------------------------------------------------------------------------------------------
-constexpr int QLD = DH + 8;    // Q / dO tile row stride: rows 4 apart (the two lane halves) land 32 banks apart
+constexpr int QBLD = DH + 32;  // halves per row of a Q / dO plane: 192-byte rows (four rows of a transposed read on disjoint banks)
 constexpr int DKV_KEYS = KT * WAVES;
 
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dKp,
     float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, int nparts, int Bn, DropCfg dc) {
-  __shared__ __attribute__((aligned(16))) float Qs[2][QT][QLD];
-  __shared__ __attribute__((aligned(16))) float dOs[2][QT][QLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Qp[2][3][QT * QBLD];
+  __shared__ __attribute__((aligned(16))) __bf16 dOp[2][3][QT * QBLD];
   __shared__ __attribute__((aligned(16))) float nls[2][QT];   // -lse (times log2 e on the fast path) of the tile's queries
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   // XCD-aware block order: workgroups go to the 8 XCDs (each with its own L2) round-robin by linear id.  The nkg key groups
@@ -545,6 +547,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
 
   // staging map: thread -> rows (tid >> 4) and (tid >> 4) + 16 of the 32-query tile, 4 consecutive d
   const int srow = tid >> 4, sd4 = (tid & 15) * 4;
+  // transposed-read lane map (lane 4 q + p of a 16-lane group: row q, columns 4 p .. 4 p + 3)
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   float4 qreg[2], doreg[2], ltr[4], dlr[4];
   float lsereg = 0.f;
 #pragma unroll
@@ -572,8 +576,16 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const int q0 = qt * QT, buf = (qt - qt_begin) & 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&Qs[buf][srow + 16 * i][sd4]) = qreg[i];
-      *reinterpret_cast<float4*>(&dOs[buf][srow + 16 * i][sd4]) = doreg[i];
+      const int o = (srow + 16 * i) * QBLD + sd4;
+      uint2v hh, mm, ll;
+      split4_bf3(qreg[i], hh, mm, ll);
+      *reinterpret_cast<uint2v*>(&Qp[buf][0][o]) = hh;
+      *reinterpret_cast<uint2v*>(&Qp[buf][1][o]) = mm;
+      *reinterpret_cast<uint2v*>(&Qp[buf][2][o]) = ll;
+      split4_bf3(doreg[i], hh, mm, ll);
+      *reinterpret_cast<uint2v*>(&dOp[buf][0][o]) = hh;
+      *reinterpret_cast<uint2v*>(&dOp[buf][1][o]) = mm;
+      *reinterpret_cast<uint2v*>(&dOp[buf][2][o]) = ll;
     }
     if (tid < QT) nls[buf][tid] = prob_bias(lsereg);
     __syncthreads();        // one barrier per tile (double buffer, see pass 1)
@@ -598,14 +610,29 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
         p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
         ds[r] = ok ? dsv[r] : 0.f;
       }
-      // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS
+      // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS.  Register 8 kb + j of p / ds is element j of K-block kb (queries
+      // 16 kb + 4 hf + 0..3 and 16 kb + 8 + 4 hf + 0..3); the A fragments are gathered for the same queries
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, hf);
-        dv0 = mfma32(dOs[buf][row][c], p[r], dv0);
-        dv1 = mfma32(dOs[buf][row][32 + c], p[r], dv1);
-        dk0 = mfma32(Qs[buf][row][c], ds[r], dk0);
-        dk1 = mfma32(Qs[buf][row][32 + c], ds[r], dk1);
+      for (int kb = 0; kb < 2; ++kb) {
+        float x8[8], y8[8];
+#pragma unroll
+        for (int jx = 0; jx < 8; ++jx) { x8[jx] = p[8 * kb + jx]; y8[jx] = ds[8 * kb + jx]; }
+        bf16x8 ph, pm, pl, sh, sm, sl;
+        split8_bf3(x8, ph, pm, pl);
+        split8_bf3(y8, sh, sm, sl);
+        const int ro = (16 * kb + 4 * hf + trq) * QBLD + trc;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int o = ro + 32 * db;
+          const bf16x8 ah = lds_frag_tr(&dOp[buf][0][o], &dOp[buf][0][o + 8 * QBLD]);
+          const bf16x8 am = lds_frag_tr(&dOp[buf][1][o], &dOp[buf][1][o + 8 * QBLD]);
+          const bf16x8 al = lds_frag_tr(&dOp[buf][2][o], &dOp[buf][2][o + 8 * QBLD]);
+          const bf16x8 qh = lds_frag_tr(&Qp[buf][0][o], &Qp[buf][0][o + 8 * QBLD]);
+          const bf16x8 qm = lds_frag_tr(&Qp[buf][1][o], &Qp[buf][1][o + 8 * QBLD]);
+          const bf16x8 ql = lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]);
+          if (db == 0) { dv0 = mfma16b_x6(ah, am, al, ph, pm, pl, dv0); dk0 = mfma16b_x6(qh, qm, ql, sh, sm, sl, dk0); }
+          else { dv1 = mfma16b_x6(ah, am, al, ph, pm, pl, dv1); dk1 = mfma16b_x6(qh, qm, ql, sh, sm, sl, dk1); }
+        }
       }
     }
   }

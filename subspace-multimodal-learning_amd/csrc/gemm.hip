@@ -292,34 +292,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 //   row-contiguous operand [k][rows + 32]    as it comes from memory (plain 8-byte stores); the MFMA fragment is gathered
 //                                            by two ds_read_b64_tr_b16 (hardware transpose, tests/microbench/tr_probe.hip)
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// four fp32 -> three planes of four bf16 (round-to-nearest each)
-__device__ __forceinline__ void split4_bf3(const float4 v, uint2v& h, uint2v& m, uint2v& l) {
-  const float2v a = {v.x, v.y}, b = {v.z, v.w};
-  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
-  const float2v ra = {a[0] - (float)ha[0], a[1] - (float)ha[1]}, rb = {b[0] - (float)hb[0], b[1] - (float)hb[1]};
-  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
-  const float2v sa = {ra[0] - (float)ma[0], ra[1] - (float)ma[1]}, sb = {rb[0] - (float)mb[0], rb[1] - (float)mb[1]};
-  const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
-  h = (uint2v){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
-  m = (uint2v){__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
-  l = (uint2v){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
-}
-__device__ __forceinline__ bf16x8 lds_frag_tr(const __bf16* p0, const __bf16* p1) {
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const bf16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-  const bf16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
-  return (bf16x8){r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-}
-
 template <int BN_, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
   constexpr int FBM = 128, FBK = 32, NI = BN_ / 64;            // NI 32-column blocks per wave

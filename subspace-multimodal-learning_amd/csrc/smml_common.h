@@ -40,6 +40,59 @@ __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
 // row of the 32x32 accumulator tile held in register r of a lane in half hf
 __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
+// ---- 16-bit matrix pipe helpers (v_mfma_f32_32x32x16_bf16) and the three-term bf16 split of fp32 data ----
+//   A operand: lane l holds A[i = l & 31][k = 8 (l >> 5) + j], B operand: B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7;
+//   C/D as for the f32 form.  x = h + m + l with three round-to-nearest bf16 terms reproduces fp32 x to 2^-24 with fp32's
+//   exponent range; the six products h h, h m, m h, h l, l h, m m of two such splits give a product to <= 2^-23.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx16 mfma16b(bf16x8 a, bf16x8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// all six kept products of a (ah, am, al) x (bh, bm, bl) block, smallest terms first
+__device__ __forceinline__ floatx16 mfma16b_x6(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, floatx16 d) {
+  d = mfma16b(am, bm, d);
+  d = mfma16b(al, bh, d);
+  d = mfma16b(ah, bl, d);
+  d = mfma16b(am, bh, d);
+  d = mfma16b(ah, bm, d);
+  return mfma16b(ah, bh, d);
+}
+// four fp32 -> three planes of four bf16 (8 bytes each)
+__device__ __forceinline__ void split4_bf3(const float4 v, uint2v& h, uint2v& m, uint2v& l) {
+  const float2v a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const float2v ra = {a[0] - (float)ha[0], a[1] - (float)ha[1]}, rb = {b[0] - (float)hb[0], b[1] - (float)hb[1]};
+  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+  const float2v sa = {ra[0] - (float)ma[0], ra[1] - (float)ma[1]}, sb = {rb[0] - (float)mb[0], rb[1] - (float)mb[1]};
+  const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
+  h = (uint2v){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  m = (uint2v){__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+  l = (uint2v){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+// eight fp32 -> three bf16x8 operands
+__device__ __forceinline__ void split8_bf3(const float (&x)[8], bf16x8& a, bf16x8& b, bf16x8& c) {
+  uint2v h0, m0, l0, h1, m1, l1;
+  split4_bf3(make_float4(x[0], x[1], x[2], x[3]), h0, m0, l0);
+  split4_bf3(make_float4(x[4], x[5], x[6], x[7]), h1, m1, l1);
+  a = __builtin_bit_cast(bf16x8, (uint4v){h0[0], h0[1], h1[0], h1[1]});
+  b = __builtin_bit_cast(bf16x8, (uint4v){m0[0], m0[1], m1[0], m1[1]});
+  c = __builtin_bit_cast(bf16x8, (uint4v){l0[0], l0[1], l1[0], l1[1]});
+}
+// MFMA fragment of an operand stored k-major in LDS ([k][rows], 16-bit): two hardware-transposed reads
+// (ds_read_b64_tr_b16; lane 4 q + p of each 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a 4 x 16 block and
+// receives its own column of the 4 rows - tests/microbench/tr_probe.hip).  p0 / p1: this lane's addresses in the two 4-row blocks.
+__device__ __forceinline__ bf16x8 lds_frag_tr(const __bf16* p0, const __bf16* p1) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+  const bf16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+  return (bf16x8){r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+}
+
 #ifndef SMML_DPP_REDUCE
 #define SMML_DPP_REDUCE 1   // cross-lane sums on the VALU (v_permlane32_swap / DPP) instead of ds_bpermute through LDS
 #endif
