@@ -188,12 +188,16 @@ def main():
             # splits, layer-1 backward) at two waves per SIMD.  Priced as algorithmic fp32 flops against the fp32 peak
             # (matrix = vector = 157.3 TF).
             kname = "cpb_bwd_kernel<2>"
+            # share of the 16-bit matrix pipe's time: 26 MFMAs of 32 cycles per (key, 32 queries) on 1024 SIMDs at 2.4 GHz
+            pipe = (pairs / 32.0) * 26 * 32 / (1024 * ms * 1e-3 * 2.4e9)
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                "traffic": measured_traffic(kname, B) if (S, in_dim) == (100, 512) else None,
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                "note": "algorithmic fp32 flops (4480 per pair, recompute not counted) / fp32 matrix = vector "
-                                       "peak; executed as 26 fp16 / bf16 MFMAs + ~400 vector instructions per (key, 32 queries)"}
+                                       "peak; executed as 26 fp16 / bf16 MFMAs + ~400 vector instructions per (key, 32 queries): "
+                                       f"the 16-bit matrix pipe is busy {100 * pipe:.0f} % of the kernel's time, the rest is "
+                                       "vector issue (on gfx950 the two add up, DESIGN.md section 4)"}
         if "deform_attn_fwd" in kt:
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
@@ -201,9 +205,9 @@ def main():
             out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
                                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                    "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                                   "note": "position-bias layer as split-fp16 products on the 16-bit matrix pipe (2.5 PF peak, "
-                                           f"{100 * ach / F16_MFMA_PEAK_TFLOPS:.1f} % of it); the kernel is bound by the fp32 "
-                                           "vector work (layer 1, ReLUs, splits), priced here against the 157.3 TF fp32 peak"}
+                                   "note": "priced against the fp32 peak although the position-bias layers run as split products on the "
+                                           "16-bit matrix pipe (one 32x32x16 MFMA does the work of eight fp32 ones), hence frac > 1 is "
+                                           "possible; 8 MFMAs + ~130 vector instructions per (key, 32 queries) + the fp32 QK^T / PV MFMAs"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, in_dim)
         print(json.dumps(out))
