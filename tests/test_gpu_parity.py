@@ -356,6 +356,31 @@ def test_mil_branch_larger_grid_vs_oracle(cuda):
     _compare_param_grads(mil, r32[3], r64[3], skip=ZERO_GRADS + ("cls_token",))
 
 
+def test_mil_branch_full_size_vs_oracle(cuda):
+    """BASELINE's headline shape itself: one DeformCrossTransMIL branch on the 100 x 100 grid (N = 10 000, 625 sampled keys,
+    512-wide bag features), outputs and every parameter gradient against the CPU oracle (fp32 run, tolerances calibrated
+    by an fp64 run of the same oracle: about a minute of host time)."""
+    args = pathomic_args(input_path_dim=512, return_vgrid=True)
+    mil = smml.DeformCrossTransMIL(args)
+    params = params_for(mil, 5, "mil100")
+    mil = _load(mil, params, cuda)
+    B, S = 1, 100
+    path = synth.bag(B, S * S, 512, 5, "mil100:bag"); omic = torch.relu(synth.normal((B, 128), 5, "mil100:omic"))
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        enc_r, log_r, _, vg_r = deform_cross_trans_mil(path.to(dt), omic.to(dt), pref, grid_hw=(S, S))
+        (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
+        run[dt] = (enc_r, log_r, vg_r, pref)
+    r32, r64 = run[torch.float32], run[torch.float64]
+    enc, logits, _, omic_t, vg = mil(path.to(cuda), omic.to(cuda))
+    (enc.sum() + (logits * logits).sum() + vg.pow(2).sum() * 1e-3).backward()
+    assert vg.shape == (B * 8, 2, 25, 25)
+    for name, got, i in (("encoded", enc, 0), ("logits", logits, 1), ("vgrid", vg, 2)):
+        _calibrated(name, got, r32[i], r64[i])
+    _compare_param_grads(mil, r32[3], r64[3], skip=ZERO_GRADS + ("cls_token",))
+
+
 def test_size_independent_properties_full_size(cuda):
     """N = 10 000 (100 x 100 grid, 625 keys): properties that need no oracle run -
     (1) attention rows are convex combinations: with v = 1 the core returns exactly-normalised ones;
