@@ -36,6 +36,9 @@
                               // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
                               // 4 of 12 (forward) / 30 (backward) MFMAs per key
 #endif
+#ifndef SMML_G_TERMS
+#define SMML_G_TERMS 3        // bf16 terms of g = h1 . d bias in the dW2 product of the position-bias backward (3: fp32-grade)
+#endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
 #endif
@@ -894,11 +897,26 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       float g8[8];
 #pragma unroll
       for (int jx = 0; jx < 8; ++jx) g8[jx] = ht[8 * t + jx] * dbq[8 * t + jx];
+#if SMML_G_TERMS == 3
       bf16x8 g1, g2, g3;
       split8_bf3(g8, g1, g2, g3);
       e = mfma16b(am[t], g3, e);
       e = mfma16b(am[t], g2, e);
       e = mfma16b(am[t], g1, e);
+#else
+      // two bf16 terms: 16 mantissa bits per summand (<= 2^-17 relative, unbiased round-to-nearest) against the exact mask
+      uint4v g1w, g2w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2v v = {g8[2 * i], g8[2 * i + 1]};
+        const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+        const float2v r1 = {v[0] - (float)hh[0], v[1] - (float)hh[1]};
+        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+        g1w[i] = __builtin_bit_cast(unsigned, hh); g2w[i] = __builtin_bit_cast(unsigned, mm);
+      }
+      e = mfma16b(am[t], __builtin_bit_cast(bf16x8, g2w), e);
+      e = mfma16b(am[t], __builtin_bit_cast(bf16x8, g1w), e);
+#endif
     }
 
     // ---- layer-1 backward, d vs ----
