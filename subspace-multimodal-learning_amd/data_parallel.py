@@ -33,6 +33,7 @@ class _Bucket:
             self.offsets.append(o)
             o += p.numel()
         self.flat = None
+        self.views = None
         self.pending = 0
         self.ready = [False] * len(params)
         self.work = None
@@ -94,23 +95,33 @@ class BagDataParallel(nn.Module):
         ref = b.params[0]
         if b.flat is None or b.flat.device != ref.device:
             b.flat = torch.zeros(b.numel, dtype=ref.dtype, device=ref.device)
-        for p, o, r in zip(b.params, b.offsets, b.ready):
-            dst = b.flat[o:o + p.numel()]
-            if r and p.grad is not None:
-                dst.copy_(p.grad.reshape(-1))
-            else:
-                dst.zero_()
+            b.views = [b.flat[o:o + p.numel()].view_as(p) for p, o in zip(b.params, b.offsets)]
+        # gather the gradients into the flat bucket with ONE multi-tensor copy (a copy kernel per parameter would add
+        # ~100 launches per step); a gradient that already is the bucket's view (kept from the previous step) needs none
+        live = [(v, p.grad) for v, p, r in zip(b.views, b.params, b.ready) if r and p.grad is not None]
+        todo = [(v, g) for v, g in live if g.data_ptr() != v.data_ptr()]
+        if len(live) < len(b.params):           # slots of parameters without a gradient this step contribute zeros
+            if len(todo) == len(live):
+                b.flat.zero_()
+            else:                               # some gradients live in the bucket already: zero only the empty slots
+                for v, p, r in zip(b.views, b.params, b.ready):
+                    if not (r and p.grad is not None):
+                        v.zero_()
+        if todo:
+            torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _finalize(self):
-        # runs at the end of backward(): flush incomplete buckets (grad-less parameters), then wait and write back
+        # runs at the end of backward(): flush incomplete buckets (grad-less parameters), then wait, average in place and
+        # hand every parameter the bucket's view as its .grad (no copy back)
         for b in self._buckets:
             if b.work is None:
                 self._launch(b)
         inv = 1.0 / self.world
         for b in self._buckets:
             b.work.wait()
-            for p, o, r in zip(b.params, b.offsets, b.ready):
+            b.flat.mul_(inv)
+            for p, v, r in zip(b.params, b.views, b.ready):
                 if r and p.grad is not None:
-                    p.grad.copy_(b.flat[o:o + p.numel()].view_as(p.grad)).mul_(inv)
+                    p.grad = v
         self._armed = False
