@@ -49,6 +49,11 @@ def _worker(rank, world, port, q):
         # gradients are final as soon as backward() returns (train_test.py:158 reads .grad right away)
         out[f"ga{step}"] = net.a.weight.grad.clone()
     out["unused_none"] = net.unused.weight.grad is None
+    # a third step that keeps the gradient tensors (zero_grad(set_to_none=False)): they are the bucket's views by now, autograd
+    # accumulates into them in place and the wrapper must neither copy nor clear them
+    net.zero_grad(set_to_none=False)
+    dp(xs[rank]).pow(2).sum().backward()
+    out["ga2"] = net.a.weight.grad.clone()
     # single-process reference: mean over ranks of the per-rank gradients with rank 0's weights
     ref = _Toy()
     g = []
@@ -96,7 +101,7 @@ def test_world_size_2_gloo():
     for r in range(world):
         o = res[r]
         assert o["has_module"] and o["unused_none"]
-        for step in range(2):
+        for step in range(3):
             assert torch.allclose(o[f"ga{step}"], o["ref"], rtol=1e-5, atol=1e-6), f"rank {r} step {step}"
         assert torch.allclose(o["bl"], o["bl_ref"], rtol=1e-5)
         assert torch.allclose(o["domic"], o["domic_ref"], rtol=1e-5, atol=1e-7)
