@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
     const __bf16 bl_ = (__bf16)(br - (float)bm);
     const __bf16 z = (__bf16)0.f;
-    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, z, z, z, z, bl_, z}; }
-    else { a1a = (bf16x8){xm, ym, xm, ym, z, z, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
+    else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
   }
   // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
   half8 w2h[2], w2m[2], w2l[2];
@@ -744,9 +744,10 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   // layer 1 as two bf16 MFMAs: x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch] with every factor split into three bf16
   // terms (h + m + l = the fp32 value to 2^-24, fp32's exponent range).  Both lane halves feed the same 8 K slots
   //   B:  p0_h  p1_h  p0_m  p1_m  p0_l  p1_l  1  0        (the three packed conversion results as they stand)
-  // against different constants, so that all products down to 2^-24 of the leading one are summed:
-  //   A (MFMA 1, half 0):  x_h  y_h  x_h  y_h  x_h  y_h  b_h  0      A (MFMA 1, half 1):  x_m  y_m  x_m  y_m  0  0  b_m  0
-  //   A (MFMA 2, half 0):  x_l  y_l   0    0    0    0   b_l  0      A (MFMA 2, half 1):  0
+  // against different constants, so that all products down to 2^-32 of the leading one are summed:
+  //   A (MFMA 1, half 0):  x_h  y_h  x_h  y_h  x_h  y_h  b_h  0      A (MFMA 1, half 1):  x_m  y_m  x_m  y_m  x_m  y_m  b_m  0
+  //   A (MFMA 2, half 0):  x_l  y_l  x_l  y_l   0    0   b_l  0      A (MFMA 2, half 1):  0
+  // i.e. eight of the nine cross products (only l l, <= 2^-32, is left out)
   // fp32-grade pre-activations matter: the ReLU masks of the layer-1 backward flip wherever x is within its error of 0.
   bf16x8 a1a, a1b;
   {
@@ -758,8 +759,8 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
     const __bf16 bl_ = (__bf16)(br - (float)bm);
     const __bf16 z = (__bf16)0.f;
-    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, z, z, z, z, bl_, z}; }
-    else { a1a = (bf16x8){xm, ym, xm, ym, z, z, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
+    else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
   }
   const float nb2c = -cp.b2[c];
   const float w3c = cp.w3[oi * CH + c];
@@ -793,7 +794,8 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
   __syncthreads();
-  const int qcol = qvalid ? (q0 + c) : q0;
+  const int qcol = qvalid ? (q0 + c) : 0;               // lanes past the bag end read column 0 (always in bounds) and are zeroed;
+                                                       // q0 itself can lie beyond the padded row (waves of the last workgroup)
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
   float db_n = dLTb[qcol];

@@ -407,3 +407,80 @@ def test_fails_loudly_on_cpu_tensors(cuda):
     mod = smml.DeformCrossAttention2D(dim=128).eval()
     with pytest.raises(RuntimeError):
         mod(torch.randn(1, 128, 144), torch.randn(1, 128, 144))
+
+
+def _core_reference(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, keep=None, keep_scale=1.0):
+    """dropout(softmax(scale q k^T + CPB(gq - vs))) v in plain torch (any dtype / device): the fused core's contract."""
+    B, N, _ = q.shape
+    J, PD, o = k.shape[1], vs.shape[-1], heads // groups
+    pos = gq[None, :, None, :] - vs.view(B * groups, 1, J, PD)
+    p = torch.sign(pos) * torch.log(pos.abs() + 1)
+    h2 = torch.relu(torch.relu(p @ w1.T + b1) @ w2.T + b2)
+    bias = (h2 @ w3.T + b3).view(B, groups, N, J, o).permute(0, 1, 4, 2, 3).reshape(B, heads, N, J)
+    d = q.shape[-1] // heads
+    qh = q.view(B, N, heads, d).permute(0, 2, 1, 3) * scale
+    kh = k.view(B, J, heads, d).permute(0, 2, 1, 3)
+    vh = v.view(B, J, heads, d).permute(0, 2, 1, 3)
+    attn = torch.softmax(qh @ kh.transpose(-1, -2) + bias, dim=-1)
+    if keep is not None:
+        attn = attn * (keep.to(attn.dtype) * keep_scale)
+    return (attn @ vh).permute(0, 2, 1, 3).reshape(B, N, heads * d)
+
+
+def test_fused_core_random_shapes(cuda):
+    """The fused attention core (forward + all three backward passes) on random ragged shapes: N and J that are not
+    multiples of the 32 / 128-wide tiles, one or two heads per offset group, 1-D and 2-D positions, with and without
+    dropout - against a plain torch evaluation in fp64 (tolerance calibrated by the same evaluation in fp32)."""
+    gen = torch.Generator().manual_seed(1234)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    forced = [(1, 1, 65, 8, 1, 0.0), (2, 33, 5, 4, 2, 0.25), (1, 129, 33, 8, 2, 0.0)]   # single query (every wave but one past the
+    for case in range(14 + len(forced)):                                               # bag end), ragged tiles
+        B, N, J = ri(1, 3), ri(1, 300), ri(1, 90)
+        groups = (4, 8)[ri(0, 1)]
+        heads, PD, p_drop = 8, ri(1, 2), (0.0, 0.25)[ri(0, 1)]
+        if case >= 14:
+            B, N, J, groups, PD, p_drop = forced[case - 14]
+        rn = lambda *s: torch.randn(*s, generator=gen)
+        t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+                 gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+                 w3=rn(heads // groups, 32) * 0.3, b3=rn(heads // groups) * 0.1)
+        wo = rn(B, N, 512)
+        dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+        seed = 17 + case
+        out = Fh.deform_attention(*(dev[n] for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")), heads=heads,
+                                  groups=groups, scale=0.125, dropout_p=p_drop, dropout_seed=seed)
+        (out * wo.to(cuda)).sum().backward()
+        keep = Fh.deform_attention_dropout_mask(B, N, J, heads, p_drop, seed, cuda) if p_drop else None
+        refs = {}
+        for dt in (torch.float32, torch.float64):
+            r = {n: x.to(cuda, dt).requires_grad_() for n, x in t.items()}
+            o = _core_reference(*(r[n] for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")), heads, groups, 0.125,
+                                keep, 1.0 / (1.0 - p_drop))
+            (o * wo.to(cuda, dt)).sum().backward()
+            refs[dt] = (o, r)
+        with torch.no_grad():                               # smallest |pre-activation| of the two ReLU layers, exact arithmetic
+            r64 = refs[torch.float64][1]
+            pos = r64["gq"][None, :, None, :] - r64["vs"].view(B * groups, 1, J, PD)
+            x1 = (torch.sign(pos) * torch.log(pos.abs() + 1)) @ r64["w1"].T + r64["b1"]
+            x2 = torch.relu(x1) @ r64["w2"].T + r64["b2"]
+            margin = min(float(x1.abs().min()), float(x2.abs().min()))
+        tag = f"case {case}: B={B} N={N} J={J} G={groups} PD={PD} p={p_drop}"
+        _calibrated(tag + " out", out, refs[torch.float32][0], refs[torch.float64][0])
+        for n in t:
+            if n in ("gq", "b3"):
+                continue                                   # the query grid is a constant; d b3 is identically zero (softmax shift)
+            g, g32, g64 = dev[n].grad, refs[torch.float32][1][n].grad, refs[torch.float64][1][n].grad
+            if float(g64.abs().max()) < 1e-9:               # identically zero in exact arithmetic (one key: dS = P (dP - delta) = 0);
+                # what is left is the rounding of dP - delta, i.e. ~1e-6 of |dP| ~ |v| |d out| d = O(100)
+                assert float(g.abs().max()) < 1e-3, f"{tag} d{n}: expected ~0, got {float(g.abs().max()):.3e}"
+                continue
+            if n in ("q", "k", "v"):
+                _calibrated(tag + " d" + n, g, g32, g64)
+            else:
+                # gradients that pass through the ReLUs of the position-bias MLP, compared in the l2 norm.  Where the exact
+                # (fp64) pre-activation of some (query, key, unit) lies within fp32 rounding of zero, no fp32 evaluation can
+                # determine that unit's mask - a flip moves single elements by 1e-4 ... 1e-2 of the tensor's scale in these
+                # small problems - so such a case only gets a sanity bound
+                l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+                tol = max(TOL, 8.0 * l2(g32, g64)) if margin > 2e-6 else 5e-2
+                assert l2(g, g64) <= tol, f"{tag} d{n}: l2 err {l2(g, g64):.3e} > {tol:.3e} (margin {margin:.1e})"
