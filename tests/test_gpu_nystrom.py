@@ -140,3 +140,31 @@ def test_nystrom_long_bag_self_consistency(cuda):
     assert torch.equal(out[0], out[1])
     out.pow(2).mean().backward()
     assert torch.isfinite(x.grad).all() and float((x.grad[0] - x.grad[1]).abs().max()) <= 1e-6 * float(x.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,n,dim,dh,m", [(2, 100, 64, 8, 32), (1, 500, 128, 16, 64), (3, 33, 64, 8, 16), (1, 64, 64, 8, 64),
+                                          (2, 1000, 512, 64, 256)])
+def test_nystrom_vs_oracle_shapes(cuda, B, n, dim, dh, m):
+    """Shapes outside the golden set: n below / equal / far above the landmark count, front padding of every size,
+    the reference's dim_head 64 / 256 landmarks with a long reduction (deterministic split-K path); outputs and all
+    gradients against the oracle (fp32 run, fp64-calibrated tolerance)."""
+    tag = f"nys:{B}:{n}:{dim}:{m}"
+    mod = smml.NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, pinv_iterations=6, residual=True, dropout=0.1)
+    params = params_for(mod, 11, tag)
+    mod = _load(mod, params, cuda)
+    x = synth.normal((B, n, dim), 11, tag + ":x") * 0.5
+    wo = synth.normal((B, n, dim), 11, tag + ":wo")
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        xr = x.clone().to(dt).requires_grad_()
+        o = nystrom_attention(xr, pr, heads=8, dim_head=dh, num_landmarks=m)
+        (o * wo.to(dt)).sum().backward()
+        run[dt] = (o, xr.grad, pr)
+    xd = x.to(cuda).requires_grad_()
+    out = mod(xd)
+    (out * wo.to(cuda)).sum().backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    _calibrated("out", out, r32[0], r64[0]); _calibrated("dx", xd.grad, r32[1], r64[1])
+    for k, p in mod.named_parameters():
+        _calibrated("d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)

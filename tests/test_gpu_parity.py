@@ -155,7 +155,7 @@ def test_linear_layernorm_autograd(cuda):
         _assert_close(n, a, r, 2e-5)
 
 
-@pytest.mark.parametrize("B,Hh,Ww", [(2, 12, 12), (1, 20, 20), (2, 14, 23), (1, 38, 38)])
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 12, 12), (1, 20, 20), (2, 14, 23), (1, 38, 38), (1, 6, 6), (2, 5, 9), (1, 31, 7)])
 def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     """Small grids incl. non-square, N not a multiple of 128, J not a multiple of 32 (ragged tiles)."""
     C, N = 128, Hh * Ww
@@ -484,3 +484,36 @@ def test_fused_core_random_shapes(cuda):
                 l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
                 tol = max(TOL, 8.0 * l2(g32, g64)) if margin > 2e-6 else 5e-2
                 assert l2(g, g64) <= tol, f"{tag} d{n}: l2 err {l2(g, g64):.3e} > {tol:.3e} (margin {margin:.1e})"
+
+
+def test_gemm_random_shapes(cuda):
+    """smml_gemm_f32 on random shapes, operand layouts (k- or row-contiguous, padded leading dimensions that keep or break
+    the 16-byte alignment of the tiled kernels), batch dimensions, split-K and epilogues, against torch in fp64."""
+    gen = torch.Generator().manual_seed(99)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    for case in range(40):
+        M, N, K = ri(1, 300), ri(1, 200), ri(1, 260)
+        nb0, nb1 = ri(1, 2), ri(1, 3)
+        a_kc, b_kc = bool(ri(0, 1)), bool(ri(0, 1))
+        pa, pb = (0, 4, 3)[ri(0, 2)], (0, 4, 1)[ri(0, 2)]                 # leading-dimension padding: aligned / unaligned
+        A = torch.randn(nb0, nb1, M, K, generator=gen); Bm = torch.randn(nb0, nb1, K, N, generator=gen)
+        lda = (K if a_kc else M) + pa; ldb = (K if b_kc else N) + pb
+        As = torch.zeros(nb0, nb1, (M if a_kc else K), lda); As[..., :(K if a_kc else M)] = A if a_kc else A.transpose(-1, -2)
+        Bs = torch.zeros(nb0, nb1, (N if b_kc else K), ldb); Bs[..., :(K if b_kc else N)] = Bm.transpose(-1, -2) if b_kc else Bm
+        mode = ri(0, 3)                                                    # 0 plain, 1 bias+relu, 2 alpha/beta residual, 3 split-K accumulate
+        alpha = 1.0 if mode in (0, 1, 3) else 0.7
+        ref = alpha * (A.double() @ Bm.double())
+        kw = dict(M=M, N=N, K=K, sam=(lda if a_kc else 1), sak=(1 if a_kc else lda), sbk=(1 if b_kc else ldb), sbn=(ldb if b_kc else 1),
+                  ldc=N, nb0=nb0, nb1=nb1, sa0=As.stride(0), sa1=As.stride(1), sb0=Bs.stride(0), sb1=Bs.stride(1), sc0=nb1 * M * N,
+                  sc1=M * N, alpha=alpha)
+        C = torch.zeros(nb0, nb1, M, N, device=cuda)
+        if mode == 1:
+            bias = torch.randn(N, generator=gen)
+            ref = torch.relu(ref + bias.double()); kw.update(bias=bias.to(cuda), bias_mode=1, act=1)
+        elif mode == 2:
+            res = torch.randn(nb0, nb1, M, N, generator=gen)
+            ref = ref + 1.5 * res.double(); kw.update(residual=res.to(cuda), ldr=N, beta=1.5)
+        elif mode == 3:
+            kw.update(splitk=ri(2, 5), accumulate=1)
+        Fh._gemm(As.to(cuda), Bs.to(cuda), C, **kw)
+        _assert_close(f"gemm case {case}: {nb0}x{nb1} {M}x{N}x{K} a_kc={a_kc} b_kc={b_kc} pads {pa},{pb} mode {mode}", C, ref.float(), 1e-5)
