@@ -63,7 +63,19 @@ def _dropout_args(mod):
     return {"dropout_p": p, "dropout_seed": seed}
 
 
+_GRID_CACHE = {}
+
+
 def _grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
+    """Cached per (rows, cols, device): a constant of the token grid (eight small kernels per forward otherwise)."""
+    key = (Hh, Ww, str(device))
+    g = _GRID_CACHE.get(key)
+    if g is None:
+        g = _GRID_CACHE[key] = _build_grid_queries_2d(Hh, Ww, device)
+    return g
+
+
+def _build_grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
     """Normalised query grid [N, 2] = (x, y) per token, restating create_grid_like + normalize_grid(dim=0)
     (DeformableAttention2D.py:88-108,296-297): x is divided by (rows - 1), y by (cols - 1)."""
     qx = 2.0 * torch.arange(Ww, dtype=torch.float32, device=device) / max(Hh - 1, 1) - 1.0
