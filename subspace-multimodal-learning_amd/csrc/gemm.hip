@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
         const int gm = m0 + 4 * mq;
         const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
         if (k0 + k >= g.K) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (gm >= g.M) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);            // tile wider than the operand: nothing to read
         else if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
         else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
       }
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
         const int gn = n0 + 4 * nq;
         const float* p = B + (long long)min(k0 + k, g.K - 1) * g.sbk;
         if (k0 + k >= g.K) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (gn >= g.N) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
         else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
       }
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
         const int gm = m0 + 4 * mq;
         const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
         if (k0 + k >= g.K) ra[i] = zero4;
+        else if (gm >= g.M) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);            // tile wider than the operand: nothing to read
         else if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
         else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
       }
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
         const int gn = n0 + 4 * nq;
         const float* p = B + (long long)min(k0 + k, g.K - 1) * g.sbk;
         if (k0 + k >= g.K) rb[i] = zero4;
+        else if (gn >= g.N) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
         else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
       }

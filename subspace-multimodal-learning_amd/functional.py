@@ -451,7 +451,7 @@ class _Gram(torch.autograd.Function):
         x = _c(x)
         nb, R, K = x.shape
         g = torch.zeros(nb, R, R, device=x.device, dtype=torch.float32)
-        splitk = int(max(1, min((K + 2047) // 2048, 65535 // nb)))
+        splitk = int(max(1, min((K + 255) // 256, 1024 // max(nb, 1), 65535 // nb)))   # R x R outputs: the K axis is all there is to spread
         _gemm(x, x, g, M=R, N=R, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=R, nb0=nb, sa0=R * K, sb0=R * K, sc0=R * R,
               splitk=splitk)
         ctx.save_for_backward(x)
