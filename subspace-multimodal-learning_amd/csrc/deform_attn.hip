@@ -39,6 +39,9 @@
 #ifndef SMML_G_TERMS
 #define SMML_G_TERMS 3        // bf16 terms of g = h1 . d bias in the dW2 product of the position-bias backward (3: fp32-grade)
 #endif
+#ifndef SMML_FMA_MIX
+#define SMML_FMA_MIX 1          // residual of the fp16 split by v_fma_mix_f32 (one instruction per value instead of convert + subtract)
+#endif
 #ifndef SMML_FAST_MATH
 #define SMML_FAST_MATH 1    // 1: hardware log2/exp2/rcp approximations (1 ulp) instead of the libm-accurate forms
 #endif
@@ -75,7 +78,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
   for (int i = 0; i < 4; ++i) {
     const float2v v = {x[2 * i], x[2 * i + 1]};
     const half2v h = __builtin_convertvector(v, half2v);
+#if SMML_FMA_MIX
+    // x - float(hi) in one mixed-precision fma per value (v_fma_mix_f32 reads the fp16 half directly)
+    const unsigned hp = __builtin_bit_cast(unsigned, h);
+    float2v r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hp), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hp), "v"(v[1]));
+#else
     const float2v r = {x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]};
+#endif
     const half2v l = __builtin_convertvector(r, half2v);
     hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
     lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];

@@ -8,6 +8,6 @@ build() { # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -fno-honor-nans -mno-amdgpu-ieee -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
 build base
-build t5 -DSMML_SPLIT_TERMS=5
+build nomix -DSMML_FMA_MIX=0
 wait
 ls bin
