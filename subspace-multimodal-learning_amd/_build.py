@@ -17,7 +17,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # per-file additions.  deform_attn.hip: the ReLUs on matrix-core results (fmaxf(acc, 0)) otherwise cost a second
 # v_max per element that only quiets signalling NaNs (IEEE mode); no NaN is ever produced or consumed there.
-EXTRA_FLAGS = {"deform_attn.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
+# -fno-slp-vectorize: packed fp32 forms are no faster than two plain fp32 instructions on gfx950 except for FMA, and the
+# SLP vectoriser turns modifier forms (x + |x|) into packed ones that need extra instructions; the kernels write float2
+# arithmetic explicitly where it pays (tests/microbench/valu_mix_probe.hip)
+EXTRA_FLAGS = {"deform_attn.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]}
 
 
 def sources():

@@ -49,7 +49,17 @@
 namespace {
 
 #if SMML_FAST_MATH
-__device__ __forceinline__ float slog1p(float d) { return copysignf(__logf(fabsf(d) + 1.0f), d); }
+// |d| + 1 >= 1 is never subnormal: the raw v_log_f32 (log2) needs none of __logf's range handling
+#ifndef SMML_RAW_LOG
+#define SMML_RAW_LOG 1
+#endif
+__device__ __forceinline__ float slog1p(float d) {
+#if SMML_RAW_LOG
+  return copysignf(__builtin_amdgcn_logf(fabsf(d) + 1.0f) * 0.6931471805599453f, d);
+#else
+  return copysignf(__logf(fabsf(d) + 1.0f), d);
+#endif
+}
 __device__ __forceinline__ float sexp(float x) { return __expf(x); }
 __device__ __forceinline__ float srcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
@@ -57,6 +67,10 @@ __device__ __forceinline__ float slog1p(float d) { return signed_log1p(d); }
 __device__ __forceinline__ float sexp(float x) { return expf(x); }
 __device__ __forceinline__ float srcp(float x) { return 1.0f / x; }
 #endif
+// 2 relu(x) = x + |x|, exact.  On gfx950 v_add_f32 (with its free |.| modifier) is in the fast issue class (~1.1 ns per
+// instruction per SIMD with two resident waves) while v_max_f32 is in the slow one (~2.0 ns) -
+// tests/microbench/valu_mix_probe.hip; the factor 2 is folded into the constants downstream (powers of two: exact).
+__device__ __forceinline__ float relu2(float x) { return x + __builtin_fabsf(x); }
 
 constexpr int DH = 64;       // head dim (fixed: dim_head = 64 in both reference modules)
 constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
@@ -183,24 +197,30 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int oc = acc_row(s, hf);              // output channel held in accumulator register s
-    b2acc[s] = cp.b2[oc];
-    w3v[s] = cp.w3[oi * CH + oc];
+    b2acc[s] = 2.f * cp.b2[oc];                 // the chain runs on 2 h1 (relu2), so it delivers 2 (W2 h1 + b2) ...
+    w3v[s] = 0.25f * cp.w3[oi * CH + oc];       // ... and relu2 of that is 4 relu(.)
   }
-  // Layer 1 runs on the matrix pipe as two bf16 MFMAs (operands as in cpb_bwd_kernel: every factor in three bf16 terms,
-  // fp32-grade pre-activations, identical to what the backward recomputes); the result arrives in accumulator layout,
-  // so operand slot (K-block kb, element j) of the 32x32 layer carries hidden channel acc_row(8 kb + j, hf).
-  bf16x8 a1a, a1b;
+  // Layer 1 runs on the matrix pipe as ONE bf16 MFMA: x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch] with the weights
+  // and the positions each split into three bf16 terms (h + m + l = the fp32 value to 2^-24, fp32's exponent range) and
+  // b1 riding in as the C operand (exact).  Eight of the nine cross products (only l l, <= 2^-32, is left out) fill the
+  // 16 K slots; the B operand is the three packed conversion results as they stand plus one select:
+  //   B, both halves:  p0_h p1_h  p0_m p1_m  p0_l p1_l   and in slots 6, 7:  p0_h p1_h (half 0) / p0_m p1_m (half 1)
+  //   A, half 0:       x_h  y_h   x_h  y_h   x_h  y_h    x_l  y_l
+  //   A, half 1:       x_m  y_m   x_m  y_m   x_m  y_m    x_l  y_l
+  // The result arrives in accumulator layout, so operand slot (K-block kb, element j) of the 32x32 layer carries hidden
+  // channel acc_row(8 kb + j, hf).
+  bf16x8 a1;
+  floatx16 b1acc;
   {
-    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, bb = cp.b1[c];
+    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f;
     const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
     const __bf16 xl = (__bf16)(xr - (float)xm);
     const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
     const __bf16 yl = (__bf16)(yr - (float)ym);
-    const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
-    const __bf16 bl_ = (__bf16)(br - (float)bm);
-    const __bf16 z = (__bf16)0.f;
-    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
-    else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+    if (hf == 0) a1 = (bf16x8){xh, yh, xh, yh, xh, yh, xl, yl};
+    else a1 = (bf16x8){xm, ym, xm, ym, xm, ym, xl, yl};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) b1acc[s] = cp.b1[acc_row(s, hf)];
   }
   // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
   half8 w2h[2], w2m[2], w2l[2];
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
     split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
   }
-  const float b3 = cp.b3[oi];
+  const float b3h = (hf == 0) ? cp.b3[oi] : 0.f;
 
   floatx16 oacc0 = {0}, oacc1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
@@ -262,30 +282,33 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       {
         const float2v pv = {p0, p1};
         const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
-        const float2v r1 = {pv[0] - (float)hh[0], pv[1] - (float)hh[1]};
+        const float2v r1 = bf16_residual2(pv, hh);
         const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-        const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};
+        const float2v r2 = bf16_residual2(r1, mm);
         const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-        const uint4v bw = {__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm),
-                           __builtin_bit_cast(unsigned, ll), 0x00003F80u};
-        const bf16x8 b1op = __builtin_bit_cast(bf16x8, bw);
-        xacc = mfma16b(a1b, b1op, (floatx16){0});
-        xacc = mfma16b(a1a, b1op, xacc);
+        const unsigned hw = __builtin_bit_cast(unsigned, hh), mw = __builtin_bit_cast(unsigned, mm);
+        const uint4v bw = {hw, mw, __builtin_bit_cast(unsigned, ll), hf ? mw : hw};
+        xacc = mfma16b(a1, __builtin_bit_cast(bf16x8, bw), b1acc);
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float hv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = fmaxf(xacc[8 * kb + j], 0.f);
+        for (int j = 0; j < 8; ++j) hv[j] = relu2(xacc[8 * kb + j]);
         half8 bh, bl;
         split8(hv, bh, bl);
         d = mfma16_split(w2h[kb], w2m[kb], w2l[kb], bh, bl, d);
       }
-      float t3 = 0.f;
+      // layer 3: two packed-fp32 FMA chains (v_pk_fma_f32 does two channels per issue); b3 rides in half 0's sum
+      float2v ta = {b3h, 0.f}, tb = {0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t3 = fmaf(fmaxf(d[r], 0.f), w3v[r], t3);
-      t3 = xhalf_sum(t3) + b3;
-      if (hf == 0) biasT[wave][jj][c] = t3;
+      for (int r = 0; r < 16; r += 4) {
+        const float2v ra = {relu2(d[r]), relu2(d[r + 1])}, rb = {relu2(d[r + 2]), relu2(d[r + 3])};
+        ta = __builtin_elementwise_fma(ra, (float2v){w3v[r], w3v[r + 1]}, ta);
+        tb = __builtin_elementwise_fma(rb, (float2v){w3v[r + 2], w3v[r + 3]}, tb);
+      }
+      ta += tb;
+      biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);   // both halves store the same sum: no exec masking in the loop
     }
     wave_lds_fence();
 
@@ -689,7 +712,7 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 //   "query-major"   lane = query, registers = channels        "channel-major"  lane = channel, registers = queries
 //   h1  = relu(W1 p + b1)          (layer 1: two bf16 MFMAs)   D^T = h1^T W2^T      (chain Y; ReLU mask of layer 2)
 //   dh1 = d bias . (W2 w3)^T mask  (chain 2, exact)            h1^T = h1 . I        (chain T: the pipe transposes)
-//   layer-1 backward, d vs                                     db2, dW3: two scalars per lane
+//   layer-1 backward, d vs                                     db2 (and with e, dW3): one scalar pair per lane
 //                                                              dW2 = w3 . mask^T g,  g = h1 . d bias (bf16 x 3)
 //   mask^T = mask . I  brings the layer-2 mask back to the query-major side for chain 2.
 //
@@ -721,8 +744,15 @@ __device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh,
 //   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed.
 constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
 constexpr int CPB2_WAVE_LDS = CPB_XQ + 2 * CPB2_STG_KEYS * 65;      // floats
-constexpr int CPB2_TAB = 2 * 2 * 16;                                // {w1x, w1y} of ch(r) for both lane halves
+constexpr int CPB2_W1TAB = 2 * 2 * 16;                              // {w1x, w1y} of ch(r) for both lane halves
+constexpr int CPB2_TAB = CPB2_W1TAB + 2 * 64 * 4;                   // + the bf16 identity operand [kb][lane] (16 B each)
 
+#ifndef SMML_CLAMP_MASK
+#define SMML_CLAMP_MASK 1
+#endif
+#ifndef SMML_IDQ_LDS
+#define SMML_IDQ_LDS SMML_CLAMP_MASK   // the float masks need the 8 registers of the bf16 identity operand
+#endif
 template <int PD>
 __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
@@ -773,13 +803,22 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
     else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
   }
-  const float nb2c = -cp.b2[c];
+  const float nb2c = -2.f * cp.b2[c];  // the chains run on 2 h1: D^T arrives doubled, and so do h1^T, g and e
   const float w3c = cp.w3[oi * CH + c];
+#if SMML_CLAMP_MASK
+  float big;                                                  // 2^100 in an SGPR: v_fma_f32 takes modifiers only without a literal
+  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
+  const float b2big = -nb2c * 0x1p100f;
+#endif
 
   half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
   half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
   half8 idb[2];                        // identity: h1 (operand layout) . I = h1^T in accumulator layout
+#if SMML_IDQ_LDS
+  uint4v* idq = reinterpret_cast<uint4v*>(tab + CPB2_W1TAB);   // the same identity in bf16, in LDS (register budget): [kb][lane]
+#else
   bf16x8 idq[2];                       // the same identity in bf16: mask (operand layout, lane = channel) . I = mask^T
+#endif
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     float a[8], t[8];
@@ -789,8 +828,17 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       a[j] = cp.w2[c * CH + ch];
       t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
       idb[kb][j] = (ch == c) ? (_Float16)1.0f : (_Float16)0.0f;
+#if !SMML_IDQ_LDS
       idq[kb][j] = (ch == c) ? (__bf16)1.0f : (__bf16)0.0f;
+#endif
     }
+#if SMML_IDQ_LDS
+    uint4v iq;
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2)
+      iq[p2] = ((acc_row(8 * kb + 2 * p2, hf) == c) ? 0x00003F80u : 0u) | ((acc_row(8 * kb + 2 * p2 + 1, hf) == c) ? 0x3F800000u : 0u);
+    idq[kb * 64 + lane] = iq;                                 // every wave stores the same table
+#endif
     split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
     split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
   }
@@ -800,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
 #pragma unroll
   for (int p = 0; p < 8; ++p) { aw1x[p] = (float2v){0.f, 0.f}; aw1y[p] = aw1x[p]; ab1[p] = aw1x[p]; }
   float ab3 = 0.f;
-  float2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+  float2v s2 = {0.f, 0.f};             // sum mask . d bias of out = c (db2; dW3 follows from it and e at the end)
 
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
@@ -830,9 +878,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     {
       const float2v pv = {p0, p1};
       const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
-      const float2v r1 = {pv[0] - (float)hh[0], pv[1] - (float)hh[1]};
+      const float2v r1 = bf16_residual2(pv, hh);
       const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-      const float2v r2 = {r1[0] - (float)mm[0], r1[1] - (float)mm[1]};
+      const float2v r2 = bf16_residual2(r1, mm);
       const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
       const uint4v bw = {__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm), __builtin_bit_cast(unsigned, ll),
                          0x00003F80u};
@@ -843,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     float hv[16];
     bool on1[16];                       // layer-1 ReLU masks: live to the end of the trip as lane masks in SGPRs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hv[r] = fmaxf(xacc[r], 0.f); on1[r] = xacc[r] > 0.f; }
+    for (int r = 0; r < 16; ++r) { hv[r] = relu2(xacc[r]); on1[r] = xacc[r] > 0.f; }   // hv = 2 h1 (see relu2)
 
     // ---- chains Y and T on the same operand registers ----
     floatx16 dy = {0}, ht = {0};
@@ -855,9 +903,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       half8 bh, bl;
       split8(x8, bh, bl);
       dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
-      ht = mfma16(bl, idb[kb], ht);                                   // h1^T[query = acc_row(r, hf)][in = c]
-      ht = mfma16(bh, idb[kb], ht);
-    }
+      ht = mfma16(bl, idb[kb], ht);                                   // 2 h1^T[query = acc_row(r, hf)][in = c]
+      ht = mfma16(bh, idb[kb], ht);                                   // (layer 1 again with A and B exchanged would be two
+    }                                                                 //  MFMAs less, yet measured 3 % slower)
 
     // ---- channel-major stage, part 1: layer-2 mask of channel c for the lane's 16 queries (exact 0 / 1 bf16 operand),
     //      db2 / dW3 partial sums ----
@@ -874,11 +922,21 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = 8 * t + 2 * p;
+#if SMML_CLAMP_MASK
+        // mask = [D + b2 > 0] as an exact 0.0 / 1.0 in ONE fast-class instruction: clamp((D + b2) 2^100) - the fused sum
+        // has the exact sign and is either 0 or far above 2^-100 (tests/microbench/dot2_probe.hip).  Written as min / max
+        // so that the compiler folds the clamp modifier AND keeps track of the MFMA -> VALU hazard.  Compare + select
+        // are slow-class instructions (valu_mix_probe.hip): this form is about half their issue time.
+        const float2v mf = {fminf(fmaxf(fmaf(dy[r], big, b2big), 0.f), 1.f), fminf(fmaxf(fmaf(dy[r + 1], big, b2big), 0.f), 1.f)};
+        s2[0] = fmaf(mf[0], dbq[r], s2[0]);
+        s2[1] = fmaf(mf[1], dbq[r + 1], s2[1]);
+        amw[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(mf, bf16x2));
+#else
         const bool on0 = dy[r] > nb2c, on1 = dy[r + 1] > nb2c;
         const float2v dbm = {on0 ? dbq[r] : 0.f, on1 ? dbq[r + 1] : 0.f};
         s2 += dbm;
-        s1 = (float2v){dy[r], dy[r + 1]} * dbm + s1;
         amw[p] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);
+#endif
       }
       am[t] = __builtin_bit_cast(bf16x8, amw);
     }
@@ -886,8 +944,13 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     //      matrix pipe transposes it (mask . I, the same trick as h1^T), exact 0 / 1 values that convert to fp16 pairs.
     //      With an exact mask operand and the constant split exactly into three terms, three MFMAs per K-block give the
     //      fp32-exact column sums; the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
+#if SMML_IDQ_LDS
+    floatx16 mt = mfma16b(am[0], __builtin_bit_cast(bf16x8, idq[lane]), (floatx16){0});
+    mt = mfma16b(am[1], __builtin_bit_cast(bf16x8, idq[64 + lane]), mt);   // mask[out = ch(r)][query = c] as 0.0 / 1.0
+#else
     floatx16 mt = mfma16b(am[0], idq[0], (floatx16){0});
     mt = mfma16b(am[1], idq[1], mt);                         // mask[out = ch(r)][query = c] as 0.0 / 1.0
+#endif
     floatx16 dh = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -983,15 +1046,21 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
   __syncthreads();
   {
-    const float s1s = s1[0] + s1[1], s2s = s2[0] + s2[1];
+    const float s2s = s2[0] + s2[1];
     atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
-    atomicAdd(&red[1024 + 64 + 32 + 32 + c], fmaf(-nb2c, s2s, s1s));   // dW3[c] = sum relu(D + b2) . d bias
+    // dW3[out] = sum relu(D + b2) . d bias = sum_in W2[out][in] e[out][in] + b2[out] sum mask . d bias: nothing of it
+    // has to be accumulated per key (the first term is added row by row below)
+    atomicAdd(&red[1024 + 64 + 32 + 32 + c], -0.5f * nb2c * s2s);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, hf);
-    atomicAdd(&red[row * CH + c], e[r] * cp.w3[oi * CH + row]);        // dW2[out = row][in = c]
+    atomicAdd(&red[row * CH + c], 0.5f * e[r] * cp.w3[oi * CH + row]); // dW2[out = row][in = c]  (e holds 2 x the sum)
     float v;
+    v = 0.5f * e[r] * cp.w2[row * CH + c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
     v = ab1[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);

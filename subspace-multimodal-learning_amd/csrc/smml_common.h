@@ -63,12 +63,33 @@ __device__ __forceinline__ floatx16 mfma16b_x6(bf16x8 ah, bf16x8 am, bf16x8 al, 
   return mfma16b(ah, bh, d);
 }
 // four fp32 -> three planes of four bf16 (8 bytes each)
+#ifndef SMML_DOT2_SPLIT
+#define SMML_DOT2_SPLIT 0   // exact but not faster: fewer instructions, yet every DOT result costs 3 wait states (tests/microbench/README.md)
+#endif
+// v - float(h) for a packed bf16 pair h = rn(v): exact (the residual of a rounding fits fp32).  v_dot2_f32_bf16 against
+// the constant pairs {-1, 0} / {0, -1} reads the packed halves directly - one instruction per value instead of unpacking
+// (shift / and) and subtracting; exactness incl. subnormals checked by tests/microbench/dot2_probe.hip.  Through the
+// builtin, never inline asm: a DOT result needs 3 wait states before another VALU instruction reads it, which only the
+// compiler's hazard recognizer inserts.
+__device__ __forceinline__ float2v bf16_residual2(const float2v v, const bf16x2 h) {
+#if SMML_DOT2_SPLIT
+  // the constant pairs are kept opaque in VGPRs: folded to an inline constant, {-1, 0} is encoded as "-1.0", which
+  // the instruction does not read as a bf16 pair (dot2_probe.hip caught it)
+  unsigned c0, c1;
+  asm("v_mov_b32 %0, 0x0000bf80" : "=v"(c0));
+  asm("v_mov_b32 %0, 0xbf800000" : "=v"(c1));
+  return (float2v){__builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, c0), v[0], false),
+                   __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, c1), v[1], false)};
+#else
+  return (float2v){v[0] - (float)h[0], v[1] - (float)h[1]};
+#endif
+}
 __device__ __forceinline__ void split4_bf3(const float4 v, uint2v& h, uint2v& m, uint2v& l) {
   const float2v a = {v.x, v.y}, b = {v.z, v.w};
   const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
-  const float2v ra = {a[0] - (float)ha[0], a[1] - (float)ha[1]}, rb = {b[0] - (float)hb[0], b[1] - (float)hb[1]};
+  const float2v ra = bf16_residual2(a, ha), rb = bf16_residual2(b, hb);
   const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
-  const float2v sa = {ra[0] - (float)ma[0], ra[1] - (float)ma[1]}, sb = {rb[0] - (float)mb[0], rb[1] - (float)mb[1]};
+  const float2v sa = bf16_residual2(ra, ma), sb = bf16_residual2(rb, mb);
   const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
   h = (uint2v){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
   m = (uint2v){__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};

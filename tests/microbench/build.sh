@@ -5,9 +5,9 @@ cd "$(dirname "$0")"
 mkdir -p bin && rm -f bin/mb_*
 build() { # name, flags...
   local name=$1; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -fno-honor-nans -mno-amdgpu-ieee -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
 build base
-build nomix -DSMML_FMA_MIX=0
+build slp -fslp-vectorize
 wait
 ls bin

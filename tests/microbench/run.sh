@@ -1,6 +1,9 @@
 #!/bin/bash
 cd "$(dirname "$0")"
-for b in bin/mb_*; do timeout -k 5 120 $b ${MB_ARGS:-4 100} || echo "$b failed rc=$?"; done
+# MB_REPS rounds over all variants (interleaved: clocks drift by a percent or two between runs - compare minima)
+for rep in $(seq 1 ${MB_REPS:-1}); do
+  for b in bin/mb_*; do timeout -k 5 120 $b ${MB_ARGS:-4 100} || echo "$b failed rc=$?"; done
+done
 if [ -n "${MB_PROF:-}" ]; then   # per-kernel times of one variant: MB_PROF=base
   cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
   out=../../gpurun_out/mbprof; rm -rf $out
