@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 PKG = "subspace-multimodal-learning_amd"
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
+CPB_BWD_MFMAS = 24                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 2 + 6 + 4 + 2 + 6 + 4
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
@@ -188,18 +189,18 @@ def main():
             # splits, layer-1 backward) at two waves per SIMD.  Priced as algorithmic fp32 flops against the fp32 peak
             # (matrix = vector = 157.3 TF).
             kname = "cpb_bwd_kernel<2>"
-            # share of the 16-bit matrix pipe's time: 26 MFMAs of 32 cycles per (key, 32 queries) on 1024 SIMDs at 2.4 GHz
-            pipe = (pairs / 32.0) * 26 * 32 / (1024 * ms * 1e-3 * 2.4e9)
+            # share of the 16-bit matrix pipe's time: CPB_BWD_MFMAS of 32 cycles per (key, 32 queries) on 1024 SIMDs at 2.4 GHz
+            pipe = (pairs / 32.0) * CPB_BWD_MFMAS * 32 / (1024 * ms * 1e-3 * 2.4e9)
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                "traffic": measured_traffic(kname, B) if (S, in_dim) == (100, 512) else None,
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                               # what the hardware executes: 26 MFMAs of 32x32x16 (2 * 16384 flop) per (key, 32 queries)
-                               "executed_16bit": {"achieved": (pairs / 32.0) * 26 * 32768 / (ms * 1e-3) / 1e12, "peak": 2500.0,
-                                                  "unit": "TFLOP/s", "frac": (pairs / 32.0) * 26 * 32768 / (ms * 1e-3) / 2.5e15},
+                               # what the hardware executes: CPB_BWD_MFMAS MFMAs of 32x32x16 (2 * 16384 flop) per (key, 32 queries)
+                               "executed_16bit": {"achieved": (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 1e12, "peak": 2500.0,
+                                                  "unit": "TFLOP/s", "frac": (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 2.5e15},
                                "note": "achieved = algorithmic fp32 flops (4480 per pair, recompute not counted) against the fp32 "
                                        "matrix (= vector) peak; the kernel runs them as split products on the 16-bit matrix pipe "
-                                       "(26 fp16 / bf16 MFMAs + ~300 vector instructions per (key, 32 queries)), so frac can pass 1; "
+                                       f"({CPB_BWD_MFMAS} fp16 / bf16 MFMAs + ~290 vector instructions per (key, 32 queries)), so frac can pass 1; "
                                        f"executed_16bit prices the issued MFMAs against the dense 16-bit peak: the pipe is busy "
                                        f"{100 * pipe:.0f} % of the kernel's time at 2.4 GHz, the rest is vector issue (on gfx950 "
                                        "the two add up, DESIGN.md section 4)"}
