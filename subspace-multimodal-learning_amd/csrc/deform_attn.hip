@@ -36,6 +36,12 @@
                               // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
                               // 4 of 12 (forward) / 30 (backward) MFMAs per key
 #endif
+#ifndef SMML_CHAIN2_TERMS
+#define SMML_CHAIN2_TERMS 2   // fp16 terms of the constant (W2 w3)^T in d h1 = (W2 w3)^T mask.  The mask operand is exact, so the
+                              // only error is the constant's: 2 terms = 22 bits, a fixed relative perturbation <= 2^-23 of
+                              // each (W2 w3)[out][in] - below what rounding d bias w3 and the 32-term fp32 dot cost the
+                              // unfused evaluation.  3: the constant to 2^-33.
+#endif
 #ifndef SMML_G_TERMS
 #define SMML_G_TERMS 2        // bf16 terms of g = h1 . d bias in the dW2 product of the position-bias backward.  2: every
                               // summand carries 16 mantissa bits (<= 2^-17 relative, round-to-nearest, unbiased) against an
@@ -946,8 +952,8 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     }
     // ---- chain 2: dh1[in = ch(r)][query = c] = d bias[query] . (W2 w3)^T mask.  Chain 2 wants the mask query-major: the
     //      matrix pipe transposes it (mask . I, the same trick as h1^T), exact 0 / 1 values that convert to fp16 pairs.
-    //      With an exact mask operand and the constant split exactly into three terms, three MFMAs per K-block give the
-    //      fp32-exact column sums; the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
+    //      With an exact mask operand and the constant split into fp16 terms (SMML_CHAIN2_TERMS), two MFMAs per K-block give
+    //      the column sums to the constant's 22 bits (three: exactly); the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
 #if SMML_IDQ_LDS
     floatx16 mt = mfma16b(am[0], __builtin_bit_cast(bf16x8, idq[lane]), (floatx16){0});
     mt = mfma16b(am[1], __builtin_bit_cast(bf16x8, idq[64 + lane]), mt);   // mask[out = ch(r)][query = c] as 0.0 / 1.0
@@ -965,7 +971,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
         const half2v hh = __builtin_convertvector(v, half2v);
         mk[2 * p] = hh[0]; mk[2 * p + 1] = hh[1];
       }
+#if SMML_CHAIN2_TERMS == 3
       dh = mfma16(w2tl[kb], mk, dh);
+#endif
       dh = mfma16(w2tm[kb], mk, dh);
       dh = mfma16(w2th[kb], mk, dh);
     }
