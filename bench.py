@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 PKG = "subspace-multimodal-learning_amd"
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
-CPB_BWD_MFMAS = 22                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 2 + 6 + 4 + 2 + 4 + 4
+CPB_BWD_MFMAS = 14                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 2 + 2 + 2 + 4 + 4
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
@@ -200,7 +200,7 @@ def main():
                                                   "unit": "TFLOP/s", "frac": (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 2.5e15},
                                "note": "achieved = algorithmic fp32 flops (4480 per pair, recompute not counted) against the fp32 "
                                        "matrix (= vector) peak; the kernel runs them as split products on the 16-bit matrix pipe "
-                                       f"({CPB_BWD_MFMAS} fp16 / bf16 MFMAs + ~290 vector instructions per (key, 32 queries)), so frac can pass 1; "
+                                       f"({CPB_BWD_MFMAS} fp16 / bf16 MFMAs + ~230 vector instructions per (key, 32 queries)), so frac can pass 1; "
                                        f"executed_16bit prices the issued MFMAs against the dense 16-bit peak: the pipe is busy "
                                        f"{100 * pipe:.0f} % of the kernel's time at 2.4 GHz, the rest is vector issue (on gfx950 "
                                        "the two add up, DESIGN.md section 4)"}

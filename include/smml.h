@@ -121,16 +121,18 @@ int smml_bilinear_corners_f32(const float* vs, int* cx, int* cy, unsigned char* 
  * Replaces DeformableAttention2D.py:120-157,284-312 and DeformableAttention1D.py:60-102,205-232.
  *   q [B, N, H*64] (unscaled)  k, v [B, J, H*64]  vs [(B G), J, posdim]  gq [N, posdim]
  *   w1 [32, posdim] b1 [32] w2 [32, 32] b2 [32] w3 [H/G, 32] b3 [H/G]
- *   out [B, N, H*64]  lse [B, H, N]  logits_t [B, H, J, smml_deform_attn_nst(N)] (nullable: only
- *   needed for backward).  H/G <= 2.
+ *   out [B, N, H*64]  lse [B, H, N]  logits_t [B, H, J, smml_deform_attn_nst(N)] and
+ *   relu_masks [B, H, J, 2, smml_deform_attn_nst(N)] uint16 (both nullable together: only needed for
+ *   backward; relu_masks holds the ReLU decisions of the position bias's second layer, 32 bits per
+ *   (query, key, head), in the bit order the backward kernel consumes - opaque to the caller).  H/G <= 2.
  * ev_start / ev_stop (nullable, handles of smml_event_create) are recorded on `stream` around the fused
  * forward kernel, resp. around the position-bias backward kernel (the dominant kernel of the step). */
 int smml_deform_attn_nst(int N);
 int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
-                             int B, int N, int J, int H, int G, int posdim, float scale, float dropout_p,
-                             unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
+                             unsigned short* relu_masks, int B, int N, int J, int H, int G, int posdim, float scale,
+                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
 /* scratch the backward needs: position-bias gradient slabs and the query-sliced dK / dV partial sums; 16-byte aligned */
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
 /* dlogits_t: scratch of logits_t's size (receives d scores); dq / dk / dv / dw* / db* overwritten;
@@ -138,8 +140,8 @@ size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
 int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, const float* out, const float* dout,
-                             const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
-                             float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                             const float* lse, const float* logits_t, const unsigned short* relu_masks,
+                             float* dlogits_t, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                              void* ev_start, void* ev_stop, void* stream);

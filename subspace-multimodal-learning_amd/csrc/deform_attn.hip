@@ -168,11 +168,12 @@ struct CpbParams {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int PD>
+template <int PD, bool SAVE>
 __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
-    float* __restrict__ LSE, float* __restrict__ LT, int N, int J, int H, int G, int NST, float scale, DropCfg dc) {
+    float* __restrict__ LSE, float* __restrict__ LT, unsigned short* __restrict__ MK, int N, int J, int H, int G, int NST,
+    float scale, DropCfg dc) {
   __shared__ float Ks[DH][KT + 1];           // K tile, d-major (A operand of S^T)
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
@@ -249,6 +250,11 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   float* LTb = LT ? LT + ((size_t)(b * H + h) * J) * NST : nullptr;
+  // layer-2 ReLU masks for the backward (training only): 16 bits per lane and key, element r (hidden channel
+  // acc_row(r, hf)) at bit (13 + r) % 16 - the position from which the backward rotates it straight into an fp16 operand
+  unsigned short* MKb = MK ? MK + ((size_t)(b * H + h) * J * 2 + hf) * NST : nullptr;
+  float big;                                                  // 2^100 in an SGPR (v_mul_f32 ... clamp takes no literal)
+  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
 
   const int ntiles = (J + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -311,12 +317,20 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       }
       // layer 3: two packed-fp32 FMA chains (v_pk_fma_f32 does two channels per issue); b3 rides in half 0's sum
       float2v ta = {b3h, 0.f}, tb = {0.f, 0.f};
+      float mb0 = 0.f, mb1 = 0.f;           // the 16 mask bits, summed as exact powers of two (two chains)
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
         const float2v ra = {relu2(d[r]), relu2(d[r + 1])}, rb = {relu2(d[r + 2]), relu2(d[r + 3])};
         ta = __builtin_elementwise_fma(ra, (float2v){w3v[r], w3v[r + 1]}, ta);
         tb = __builtin_elementwise_fma(rb, (float2v){w3v[r + 2], w3v[r + 3]}, tb);
+        if (SAVE) {                         // [d > 0] = clamp(relu2(d) 2^100): exact 0.0 / 1.0, fast-class instructions only
+          mb0 = fmaf(fminf(fmaxf(ra[0] * big, 0.f), 1.f), (float)(1u << ((13 + r) & 15)), mb0);
+          mb1 = fmaf(fminf(fmaxf(ra[1] * big, 0.f), 1.f), (float)(1u << ((14 + r) & 15)), mb1);
+          mb0 = fmaf(fminf(fmaxf(rb[0] * big, 0.f), 1.f), (float)(1u << ((15 + r) & 15)), mb0);
+          mb1 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb1);
+        }
       }
+      if (SAVE && qvalid) MKb[(size_t)(j0 + jj) * 2 * NST + q0 + c] = (unsigned short)(unsigned)(mb0 + mb1);
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);   // both halves store the same sum: no exec masking in the loop
     }
@@ -736,17 +750,6 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 // ------------------------------------------------------------------------------------------------
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
 constexpr int CPB_XQ = 2 * 32;                            // double-buffered d bias of the wave's 32 queries
-// D += h . W with the split ACTIVATION as the A operand (transposed product of mfma16_split)
-__device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh, half8 wm, half8 wl, floatx16 d) {
-#if SMML_SPLIT_TERMS == 5
-  d = mfma16(bh, wl, d);
-  d = mfma16(bl, wm, d);
-#endif
-  d = mfma16(bh, wm, d);
-  d = mfma16(bl, wh, d);
-  return mfma16(bh, wh, d);
-}
-
 // Register budget (256 per wave, two waves per SIMD):
 //   * layer 1 itself runs on the matrix pipe: W1 p + b1 as a K = 8 bf16 product with every factor in three terms - a
 //     pair of 4-register constant operands instead of 48 per-channel constants;
@@ -754,19 +757,13 @@ __device__ __forceinline__ floatx16 mfma16_split_t(half8 bh, half8 bl, half8 wh,
 //   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed.
 constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
 constexpr int CPB2_WAVE_LDS = CPB_XQ + 2 * CPB2_STG_KEYS * 65;      // floats
-constexpr int CPB2_W1TAB = 2 * 2 * 16;                              // {w1x, w1y} of ch(r) for both lane halves
-constexpr int CPB2_TAB = CPB2_W1TAB + 2 * 64 * 4;                   // + the bf16 identity operand [kb][lane] (16 B each)
+constexpr int CPB2_TAB = 2 * 2 * 16;                                // {w1x, w1y} of ch(r) for both lane halves
 
-#ifndef SMML_CLAMP_MASK
-#define SMML_CLAMP_MASK 1
-#endif
-#ifndef SMML_IDQ_LDS
-#define SMML_IDQ_LDS SMML_CLAMP_MASK   // the float masks need the 8 registers of the bf16 identity operand
-#endif
 template <int PD>
 __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
-    const float* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp,
-    float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H, int G, int NST) {
+    const float* __restrict__ dLT, const unsigned short* __restrict__ MK, const float* __restrict__ VS,
+    const float* __restrict__ GQ, CpbParams cp, float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H,
+    int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // layout: tab[2][2][16] | dvs[J*2, padded to 4] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -813,43 +810,25 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
     else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
   }
-  const float nb2c = -2.f * cp.b2[c];  // the chains run on 2 h1: D^T arrives doubled, and so do h1^T, g and e
+  const float b2c = cp.b2[c];
   const float w3c = cp.w3[oi * CH + c];
-#if SMML_CLAMP_MASK
-  float big;                                                  // 2^100 in an SGPR: v_fma_f32 takes modifiers only without a literal
-  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
-  const float b2big = -nb2c * 0x1p100f;
-#endif
 
-  half8 w2h[2], w2m[2], w2l[2];        // W2[out = c][in = ch(8 kb + j)]: A operand of chain X, B operand of chain Y
-  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out]: A operand of chain 2
-  half8 idb[2];                        // identity: h1 (operand layout) . I = h1^T in accumulator layout
-#if SMML_IDQ_LDS
-  uint4v* idq = reinterpret_cast<uint4v*>(tab + CPB2_W1TAB);   // the same identity in bf16, in LDS (register budget): [kb][lane]
-#else
-  bf16x8 idq[2];                       // the same identity in bf16: mask (operand layout, lane = channel) . I = mask^T
-#endif
+  // The layer-2 ReLU mask comes from the forward (16 bits per lane and key, element r at bit (13 + r) % 16).  Rotated by
+  // 2 p and masked with 0x40002000 the word holds elements 2 p and 2 p + 1 as the fp16 pair {2^-7 or 0, 2.0 or 0} (single
+  // bits 13 and 30): an MFMA operand without any conversion.  The constant operands carry the inverse scales per K slot
+  // (128 for even slots, 0.5 for odd ones - powers of two, exact):
+  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out] * slot scale: A operand of chain 2
+  half8 idb[2];                        // scaled identity: mask (operand layout, lane = query) . I = mask^T as exact 0.0 / 1.0
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    float a[8], t[8];
+    float t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ch = acc_row(8 * kb + j, hf);
-      a[j] = cp.w2[c * CH + ch];
-      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch];
-      idb[kb][j] = (ch == c) ? (_Float16)1.0f : (_Float16)0.0f;
-#if !SMML_IDQ_LDS
-      idq[kb][j] = (ch == c) ? (__bf16)1.0f : (__bf16)0.0f;
-#endif
+      const float sc = (j & 1) ? 0.5f : 128.f;
+      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch] * sc;
+      idb[kb][j] = (ch == c) ? (_Float16)sc : (_Float16)0.0f;
     }
-#if SMML_IDQ_LDS
-    uint4v iq;
-#pragma unroll
-    for (int p2 = 0; p2 < 4; ++p2)
-      iq[p2] = ((acc_row(8 * kb + 2 * p2, hf) == c) ? 0x00003F80u : 0u) | ((acc_row(8 * kb + 2 * p2 + 1, hf) == c) ? 0x3F800000u : 0u);
-    idq[kb * 64 + lane] = iq;                                 // every wave stores the same table
-#endif
-    split8_3(a, w2h[kb], w2m[kb], w2l[kb]);
     split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
   }
 
@@ -868,14 +847,18 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
   float db_n = dLTb[qcol];
+  const unsigned short* MKb = MK + ((size_t)(b * H + h) * J * 2 + hf) * NST;
+  unsigned m16_n = MKb[qcol];
 
   for (int j = 0; j < J; ++j) {
     const float vx = vx_n, vy = vy_n, dbias = qvalid ? db_n : 0.f;
+    const unsigned m16 = m16_n;
     {
       const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
       vx_n = VSb[(size_t)jn * PD];
       if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
       db_n = dLTb[(size_t)jn * NST + qcol];
+      m16_n = MKb[(size_t)jn * 2 * NST + qcol];
     }
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;                                          // for the channel-major stage (both halves store the same value)
@@ -883,8 +866,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float p0 = slog1p(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
 
-    // ---- layer 1 on the matrix pipe ----
-    floatx16 xacc;
+    // ---- layer 1 on the matrix pipe, in both layouts: the same two MFMAs with A and B exchanged deliver x^T (queries in
+    //      the registers, channel c in the lane), which is what the channel-major stage wants of h1 ----
+    floatx16 xacc, ht;
     {
       const float2v pv = {p0, p1};
       const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
@@ -897,28 +881,34 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       const bf16x8 b1op = __builtin_bit_cast(bf16x8, bw);
       xacc = mfma16b(a1b, b1op, (floatx16){0});
       xacc = mfma16b(a1a, b1op, xacc);
+      ht = mfma16b(b1op, a1b, (floatx16){0});
+      ht = mfma16b(b1op, a1a, ht);
     }
-    float hv[16];
     bool on1[16];                       // layer-1 ReLU masks: live to the end of the trip as lane masks in SGPRs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hv[r] = relu2(xacc[r]); on1[r] = xacc[r] > 0.f; }   // hv = 2 h1 (see relu2)
+    for (int r = 0; r < 16; ++r) on1[r] = xacc[r] > 0.f;
 
-    // ---- chains Y and T on the same operand registers ----
-    floatx16 dy = {0}, ht = {0};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float x8[8];
-#pragma unroll
-      for (int jx = 0; jx < 8; ++jx) x8[jx] = hv[8 * kb + jx];
-      half8 bh, bl;
-      split8(x8, bh, bl);
-      dy = mfma16_split_t(bh, bl, w2h[kb], w2m[kb], w2l[kb], dy);     // D^T[query = acc_row(r, hf)][out = c]
-      ht = mfma16(bl, idb[kb], ht);                                   // 2 h1^T[query = acc_row(r, hf)][in = c]
-      ht = mfma16(bh, idb[kb], ht);                                   // (layer 1 again with A and B exchanged would be two
-    }                                                                 //  MFMAs less, yet measured 3 % slower)
+    // ---- layer-2 mask: the forward's bits -> query-major fp16 operand (lane = query, K slot = out channel) ----
+    half8 mk[2];
+    {
+      const unsigned mm2 = m16 | (m16 << 16);
+      uint4v w0, w1;
+      w0[0] = mm2 & 0x40002000u;
+      w0[1] = __builtin_amdgcn_alignbit(mm2, mm2, 2) & 0x40002000u;
+      w0[2] = __builtin_amdgcn_alignbit(mm2, mm2, 4) & 0x40002000u;
+      w0[3] = __builtin_amdgcn_alignbit(mm2, mm2, 6) & 0x40002000u;
+      w1[0] = __builtin_amdgcn_alignbit(mm2, mm2, 8) & 0x40002000u;
+      w1[1] = __builtin_amdgcn_alignbit(mm2, mm2, 10) & 0x40002000u;
+      w1[2] = __builtin_amdgcn_alignbit(mm2, mm2, 12) & 0x40002000u;
+      w1[3] = __builtin_amdgcn_alignbit(mm2, mm2, 14) & 0x40002000u;
+      mk[0] = __builtin_bit_cast(half8, w0);
+      mk[1] = __builtin_bit_cast(half8, w1);
+    }
+    // ---- the matrix pipe transposes it: mask . (scaled I) = mask^T[query = acc_row(r, hf)][out = c] as exact 0.0 / 1.0 ----
+    floatx16 mtt = mfma16(mk[0], idb[0], (floatx16){0});
+    mtt = mfma16(mk[1], idb[1], mtt);
 
-    // ---- channel-major stage, part 1: layer-2 mask of channel c for the lane's 16 queries (exact 0 / 1 bf16 operand),
-    //      db2 / dW3 partial sums ----
+    // ---- channel-major stage, part 1: db2 partial sums and the exact 0 / 1 bf16 mask operand of the dW2 product ----
     float dbq[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -932,50 +922,24 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = 8 * t + 2 * p;
-#if SMML_CLAMP_MASK
-        // mask = [D + b2 > 0] as an exact 0.0 / 1.0 in ONE fast-class instruction: clamp((D + b2) 2^100) - the fused sum
-        // has the exact sign and is either 0 or far above 2^-100 (tests/microbench/dot2_probe.hip).  Written as min / max
-        // so that the compiler folds the clamp modifier AND keeps track of the MFMA -> VALU hazard.  Compare + select
-        // are slow-class instructions (valu_mix_probe.hip): this form is about half their issue time.
-        const float2v mf = {fminf(fmaxf(fmaf(dy[r], big, b2big), 0.f), 1.f), fminf(fmaxf(fmaf(dy[r + 1], big, b2big), 0.f), 1.f)};
+        const float2v mf = {mtt[r], mtt[r + 1]};
         s2[0] = fmaf(mf[0], dbq[r], s2[0]);
         s2[1] = fmaf(mf[1], dbq[r + 1], s2[1]);
         amw[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(mf, bf16x2));
-#else
-        const bool on0 = dy[r] > nb2c, on1 = dy[r + 1] > nb2c;
-        const float2v dbm = {on0 ? dbq[r] : 0.f, on1 ? dbq[r + 1] : 0.f};
-        s2 += dbm;
-        amw[p] = (on0 ? 0x00003F80u : 0u) | (on1 ? 0x3F800000u : 0u);
-#endif
       }
       am[t] = __builtin_bit_cast(bf16x8, amw);
     }
-    // ---- chain 2: dh1[in = ch(r)][query = c] = d bias[query] . (W2 w3)^T mask.  Chain 2 wants the mask query-major: the
-    //      matrix pipe transposes it (mask . I, the same trick as h1^T), exact 0 / 1 values that convert to fp16 pairs.
-    //      With an exact mask operand and the constant split into fp16 terms (SMML_CHAIN2_TERMS), two MFMAs per K-block give
-    //      the column sums to the constant's 22 bits (three: exactly); the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
-#if SMML_IDQ_LDS
-    floatx16 mt = mfma16b(am[0], __builtin_bit_cast(bf16x8, idq[lane]), (floatx16){0});
-    mt = mfma16b(am[1], __builtin_bit_cast(bf16x8, idq[64 + lane]), mt);   // mask[out = ch(r)][query = c] as 0.0 / 1.0
-#else
-    floatx16 mt = mfma16b(am[0], idq[0], (floatx16){0});
-    mt = mfma16b(am[1], idq[1], mt);                         // mask[out = ch(r)][query = c] as 0.0 / 1.0
-#endif
+    // ---- chain 2: dh1[in = ch(r)][query = c] = (W2 w3)^T mask.  With an exact mask operand and the constant split into
+    //      fp16 terms (SMML_CHAIN2_TERMS), two MFMAs per K-block give the column sums to the constant's 22 bits (three:
+    //      exactly); the lane's d bias multiplies its column afterwards (no gradient scaling needed) ----
     floatx16 dh = {0};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      half8 mk;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float2v v = {mt[8 * kb + 2 * p], mt[8 * kb + 2 * p + 1]};
-        const half2v hh = __builtin_convertvector(v, half2v);
-        mk[2 * p] = hh[0]; mk[2 * p + 1] = hh[1];
-      }
 #if SMML_CHAIN2_TERMS == 3
-      dh = mfma16(w2tl[kb], mk, dh);
+      dh = mfma16(w2tl[kb], mk[kb], dh);
 #endif
-      dh = mfma16(w2tm[kb], mk, dh);
-      dh = mfma16(w2th[kb], mk, dh);
+      dh = mfma16(w2tm[kb], mk[kb], dh);
+      dh = mfma16(w2th[kb], mk[kb], dh);
     }
     ab3 += (hf == 0) ? dbias : 0.f;
 
@@ -984,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     for (int t = 0; t < 2; ++t) {
       float g8[8];
 #pragma unroll
-      for (int jx = 0; jx < 8; ++jx) g8[jx] = ht[8 * t + jx] * dbq[8 * t + jx];
+      for (int jx = 0; jx < 8; ++jx) g8[jx] = relu2(ht[8 * t + jx]) * dbq[8 * t + jx];   // 2 h1^T . d bias
 #if SMML_G_TERMS == 3
       bf16x8 g1, g2, g3;
       split8_bf3(g8, g1, g2, g3);
@@ -1062,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
     // dW3[out] = sum relu(D + b2) . d bias = sum_in W2[out][in] e[out][in] + b2[out] sum mask . d bias: nothing of it
     // has to be accumulated per key (the first term is added row by row below)
-    atomicAdd(&red[1024 + 64 + 32 + 32 + c], -0.5f * nb2c * s2s);
+    atomicAdd(&red[1024 + 64 + 32 + 32 + c], b2c * s2s);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1234,8 +1198,8 @@ static int check_common(const char* fn, int B, int N, int J, int H, int G, int p
 int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
-                             int B, int N, int J, int H, int G, int posdim, float scale, float dropout_p,
-                             unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+                             unsigned short* relu_masks, int B, int N, int J, int H, int G, int posdim, float scale,
+                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
   int rc = check_common("smml_deform_attn_fwd_f32", B, N, J, H, G, posdim);
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_fwd_f32: dropout_p must be in [0, 1)");
   const DropCfg dc = make_drop(dropout_p, dropout_seed);
@@ -1247,12 +1211,20 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
   const int nst = smml_deform_attn_nst(N);
   hipStream_t st = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  if (posdim == 2)
-    hipLaunchKernelGGL(deform_attn_fwd_kernel<2>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
-                       N, J, H, G, nst, scale, dc);
+  SMML_REQUIRE((logits_t == nullptr) == (relu_masks == nullptr),
+               "smml_deform_attn_fwd_f32: logits_t and relu_masks are saved together (training) or not at all");
+  if (posdim == 2 && relu_masks)
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<2, true>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
+  else if (posdim == 2)
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<2, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
+  else if (relu_masks)
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<1, true>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
   else
-    hipLaunchKernelGGL(deform_attn_fwd_kernel<1>, grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
-                       N, J, H, G, nst, scale, dc);
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<1, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   SMML_LAUNCH_CHECK("smml_deform_attn_fwd_f32");
   return SMML_OK;
@@ -1261,7 +1233,8 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
 int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, const float* out, const float* dout,
-                             const float* lse, const float* logits_t, float* dlogits_t, float* dq, float* dk,
+                             const float* lse, const float* logits_t, const unsigned short* relu_masks,
+                             float* dlogits_t, float* dq, float* dk,
                              float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
@@ -1271,7 +1244,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   const DropCfg dc = make_drop(dropout_p, dropout_seed);
   if (rc) return rc;
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits_t &&
-                   dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
+                   relu_masks && dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
                "smml_deform_attn_bwd_f32: null pointer");
   SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, J, H),
                "smml_deform_attn_bwd_f32: workspace too small (%zu < %zu)", workspace_bytes,
@@ -1311,11 +1284,11 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     SMML_REQUIRE(lds <= 80 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
-      hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
-                         J, H, G, nst);
+      hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, vs, gq, cp, slab,
+                         dvs, N, J, H, G, nst);
     else
-      hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, vs, gq, cp, slab, dvs, N,
-                         J, H, G, nst);
+      hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, vs, gq, cp, slab,
+                         dvs, N, J, H, G, nst);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;

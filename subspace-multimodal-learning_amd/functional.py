@@ -349,22 +349,24 @@ class _DeformAttn(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad)
-        logits = None
+        logits = masks = None
         if need_grad:
-            logits = torch.empty(B, heads, J, L.smml_deform_attn_nst(N), device=q.device, dtype=torch.float32)
+            nst = L.smml_deform_attn_nst(N)
+            logits = torch.empty(B, heads, J, nst, device=q.device, dtype=torch.float32)
+            masks = torch.empty(B, heads, J, 2, nst, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
         capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                               capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
-                                              capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), B, N, J,
+                                              capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
                                               heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
                                               *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
                    "deform_attn_fwd")
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed))
-        ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits)
+        ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits = ctx.saved_tensors
+        q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks = ctx.saved_tensors
         heads, groups, scale, dropout_p, dropout_seed = ctx.cfg
         B, N, _ = q.shape
         J = k.shape[1]
@@ -380,7 +382,7 @@ class _DeformAttn(torch.autograd.Function):
         capi.check(L.smml_deform_attn_bwd_f32(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
             capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
-            capi.fptr(logits), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+            capi.fptr(logits), capi.ptr(masks), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
             capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
             capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
             *TIMER.events("cpb_bwd", B * heads * N * J),

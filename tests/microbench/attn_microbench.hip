@@ -53,6 +53,7 @@ int main(int argc, char** argv) {
   float* dout = dev_rand((size_t)B * N * HD, -1.f, 1.f, 12);
   float* out = dev_zero((size_t)B * N * HD); float* lse = dev_zero((size_t)B * H * N);
   float* lt = dev_zero((size_t)B * H * J * nst); float* dlt = dev_zero((size_t)B * H * J * nst);
+  unsigned short* mk = (unsigned short*)dev_zero((size_t)B * H * J * nst);   // [B, H, J, 2, nst] uint16
   float* dq = dev_zero((size_t)B * N * HD); float* dk = dev_zero((size_t)B * J * HD); float* dv = dev_zero((size_t)B * J * HD);
   float* dvs = dev_zero((size_t)B * G * J * PD);
   float* dw1 = dev_zero(64); float* db1 = dev_zero(32); float* dw2 = dev_zero(1024); float* db2 = dev_zero(32);
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
   const int reps = 3;
   for (int it = 0; it < reps + 1; ++it) {
     hipEventRecord(e0, 0);
-    int rc = smml_deform_attn_fwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, lt, B, N, J, H, G, PD, scale,
+    int rc = smml_deform_attn_fwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, lt, mk, B, N, J, H, G, PD, scale,
                                       drop_p, 77ull, nullptr, nullptr, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("fwd error: %s\n", smml_last_error()); return 1; }
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (it > 0) fwd_ms += ms;
     hipEventRecord(e0, 0);
-    rc = smml_deform_attn_bwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, dout, lse, lt, dlt, dq, dk, dv, dvs, dw1,
+    rc = smml_deform_attn_bwd_f32(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, dout, lse, lt, mk, dlt, dq, dk, dv, dvs, dw1,
                                   db1, dw2, db2, dw3, db3, ws, wsb, B, N, J, H, G, PD, scale, drop_p, 77ull, c0, c1, nullptr);
     hipEventRecord(e1, 0);
     if (rc) { printf("bwd error: %s\n", smml_last_error()); return 1; }
