@@ -729,22 +729,24 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward of the continuous position bias: given dS^T (= d bias) recompute the MLP per (key, 32 queries) and
-// accumulate dW1, db1, dW2, db2, dW3, db3 and d vs.  Every contraction runs on the 16-bit matrix pipe; the two
-// register layouts an MFMA can deliver are both used so that no operand is transposed through LDS:
+// backward of the continuous position bias: given dS^T (= d bias) and the layer-2 ReLU decisions the forward saved,
+// accumulate dW1, db1, dW2, db2, dW3, db3 and d vs per (key, 32 queries).  Every contraction runs on the 16-bit matrix
+// pipe; the two register layouts an MFMA can deliver are both used so that no operand is transposed through LDS:
 //
 //   "query-major"   lane = query, registers = channels        "channel-major"  lane = channel, registers = queries
-//   h1  = relu(W1 p + b1)          (layer 1: two bf16 MFMAs)   D^T = h1^T W2^T      (chain Y; ReLU mask of layer 2)
-//   dh1 = d bias . (W2 w3)^T mask  (chain 2, exact)            h1^T = h1 . I        (chain T: the pipe transposes)
-//   layer-1 backward, d vs                                     db2 (and with e, dW3): one scalar pair per lane
-//                                                              dW2 = w3 . mask^T g,  g = h1 . d bias (bf16 x 3)
-//   mask^T = mask . I  brings the layer-2 mask back to the query-major side for chain 2.
+//   x1 = W1 p + b1 (one bf16 MFMA; layer-1 masks)              x1^T: the same product with A and B exchanged -> h1^T
+//   mask2: the forward's bits, rotated into an fp16 operand     mask2^T = mask2 . (scaled I): exact 0.0 / 1.0
+//   dh1 = (W2 w3)^T mask2  (chain 2, exact mask operand)        db2: one scalar pair per lane (and with e, dW3)
+//   layer-1 backward, d vs                                     dW2 = w3 . mask2^T g,  g = h1 . d bias (bf16 x 2)
 //
-// What measurement says about gfx950 (tests/microbench/{valu,overlap,mfma}_probe.hip): a single wave issues one vector
-// instruction per ~5.2 cycles (8 when it depends on the previous one, 12 for packed forms); two waves per SIMD double that
-// rate; and an MFMA - the 16-bit forms included - occupies the SIMD for its whole duration (~32 cycles per
-// 32x32x16), it does not run beside other waves' vector work.  So the kernel is written for two resident waves (256
-// registers each) and for the fewest MFMAs + vector instructions per key: 26 + ~400.
+// Layer 2 itself is NOT recomputed (no W2 h1 product, no fp16 split of h1): its only use in the backward is the ReLU
+// mask, which costs the forward 16 bits per lane and key (1.6 GB per 8 bags of 10 000 x 625 x 8 heads).
+//
+// What measurement says about gfx950 (tests/microbench/{valu,overlap,mfma,valu_mix}_probe.hip): two waves per SIMD are
+// needed to keep the vector unit issuing; an MFMA - the 16-bit forms included - occupies the SIMD for its duration, it
+// does not run beside other waves' vector work; vector instructions come in a fast and a slow issue class.  So the
+// kernel is written for two resident waves (256 registers each) and for the fewest MFMAs + slow-class instructions per
+// key: 12 MFMAs (1 + 1 + 2 + 4 + 4) + about 230 vector instructions.
 // Per-lane partial sums are reduced per workgroup into a slab [numWG][CPB_SLAB] that two small kernels add up in a
 // fixed order (deterministic).   slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
 // ------------------------------------------------------------------------------------------------
@@ -789,15 +791,18 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
 
-  // layer 1 as two bf16 MFMAs: x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch] with every factor split into three bf16
-  // terms (h + m + l = the fp32 value to 2^-24, fp32's exponent range).  Both lane halves feed the same 8 K slots
-  //   B:  p0_h  p1_h  p0_m  p1_m  p0_l  p1_l  1  0        (the three packed conversion results as they stand)
-  // against different constants, so that all products down to 2^-32 of the leading one are summed:
-  //   A (MFMA 1, half 0):  x_h  y_h  x_h  y_h  x_h  y_h  b_h  0      A (MFMA 1, half 1):  x_m  y_m  x_m  y_m  x_m  y_m  b_m  0
-  //   A (MFMA 2, half 0):  x_l  y_l  x_l  y_l   0    0   b_l  0      A (MFMA 2, half 1):  0
-  // i.e. eight of the nine cross products (only l l, <= 2^-32, is left out)
-  // fp32-grade pre-activations matter: the ReLU masks of the layer-1 backward flip wherever x is within its error of 0.
-  bf16x8 a1a, a1b;
+  // Layer 1, x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch], runs on the matrix pipe in both layouts, one bf16 MFMA
+  // each, with weights and positions split into three bf16 terms (h + m + l = the fp32 value to 2^-24):
+  //  * query-major (lane = query), exactly the forward's product - eight of the nine cross terms in the 16 K slots
+  //    (slots 6, 7 of the position operand: p_h in lane half 0, p_m in half 1), b1 exact in the C operand - so the
+  //    layer-1 ReLU masks of the backward are the forward's, bit for bit;
+  //  * channel-major (x^T: queries in the registers, channel c in the lane; feeds only g = h1 . d bias, which is kept
+  //    to 16 bits) with the operands exchanged: six cross terms + b1 in three terms in the 16 K slots (what is left
+  //    out, m l + l m + l l, is <= 2^-23 of a term):
+  //      positions, half 0:  p0_h p1_h p0_m p1_m p0_l p1_l 1 1     half 1:  p0_h p1_h p0_m p1_m p0_h p1_h 1 0
+  //      constants, half 0:  x_h  y_h  x_h  y_h  x_h  y_h  b_h b_m  half 1:  x_m  y_m  x_m  y_m  x_l  y_l  b_l 0
+  bf16x8 a1q, a1t;
+  floatx16 b1acc;
   {
     const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, bb = cp.b1[c];
     const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
@@ -807,8 +812,10 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
     const __bf16 bl_ = (__bf16)(br - (float)bm);
     const __bf16 z = (__bf16)0.f;
-    if (hf == 0) { a1a = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, z}; a1b = (bf16x8){xl, yl, xl, yl, z, z, bl_, z}; }
-    else { a1a = (bf16x8){xm, ym, xm, ym, xm, ym, bm, z}; a1b = (bf16x8){z, z, z, z, z, z, z, z}; }
+    if (hf == 0) { a1q = (bf16x8){xh, yh, xh, yh, xh, yh, xl, yl}; a1t = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, bm}; }
+    else { a1q = (bf16x8){xm, ym, xm, ym, xm, ym, xl, yl}; a1t = (bf16x8){xm, ym, xm, ym, xl, yl, bl_, z}; }
+#pragma unroll
+    for (int s16 = 0; s16 < 16; ++s16) b1acc[s16] = cp.b1[acc_row(s16, hf)];
   }
   const float b2c = cp.b2[c];
   const float w3c = cp.w3[oi * CH + c];
@@ -866,8 +873,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float p0 = slog1p(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
 
-    // ---- layer 1 on the matrix pipe, in both layouts: the same two MFMAs with A and B exchanged deliver x^T (queries in
-    //      the registers, channel c in the lane), which is what the channel-major stage wants of h1 ----
+    // ---- layer 1 on the matrix pipe, in both layouts ----
     floatx16 xacc, ht;
     {
       const float2v pv = {p0, p1};
@@ -876,13 +882,11 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
       const float2v r2 = bf16_residual2(r1, mm);
       const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-      const uint4v bw = {__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm), __builtin_bit_cast(unsigned, ll),
-                         0x00003F80u};
-      const bf16x8 b1op = __builtin_bit_cast(bf16x8, bw);
-      xacc = mfma16b(a1b, b1op, (floatx16){0});
-      xacc = mfma16b(a1a, b1op, xacc);
-      ht = mfma16b(b1op, a1b, (floatx16){0});
-      ht = mfma16b(b1op, a1a, ht);
+      const unsigned hw = __builtin_bit_cast(unsigned, hh), mw = __builtin_bit_cast(unsigned, mm), lw = __builtin_bit_cast(unsigned, ll);
+      const uint4v qw = {hw, mw, lw, hf ? mw : hw};
+      xacc = mfma16b(a1q, __builtin_bit_cast(bf16x8, qw), b1acc);
+      const uint4v tw = {hw, mw, hf ? hw : lw, hf ? 0x00003F80u : 0x3F803F80u};
+      ht = mfma16b(__builtin_bit_cast(bf16x8, tw), a1t, (floatx16){0});
     }
     bool on1[16];                       // layer-1 ReLU masks: live to the end of the trip as lane masks in SGPRs
 #pragma unroll
