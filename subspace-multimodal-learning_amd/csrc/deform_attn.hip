@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       }
       // layer 3: two packed-fp32 FMA chains (v_pk_fma_f32 does two channels per issue); b3 rides in half 0's sum
       float2v ta = {b3h, 0.f}, tb = {0.f, 0.f};
-      float mb0 = 0.f, mb1 = 0.f;           // the 16 mask bits, summed as exact powers of two (two chains)
+      float mb0 = 0.f, mb1 = 0.f, mb2 = 0.f, mb3 = 0.f;   // the 16 mask bits, summed as exact powers of two (four chains)
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
         const float2v ra = {relu2(d[r]), relu2(d[r + 1])}, rb = {relu2(d[r + 2]), relu2(d[r + 3])};
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
         if (SAVE) {                         // [d > 0] = clamp(relu2(d) 2^100): exact 0.0 / 1.0, fast-class instructions only
           mb0 = fmaf(fminf(fmaxf(ra[0] * big, 0.f), 1.f), (float)(1u << ((13 + r) & 15)), mb0);
           mb1 = fmaf(fminf(fmaxf(ra[1] * big, 0.f), 1.f), (float)(1u << ((14 + r) & 15)), mb1);
-          mb0 = fmaf(fminf(fmaxf(rb[0] * big, 0.f), 1.f), (float)(1u << ((15 + r) & 15)), mb0);
-          mb1 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb1);
+          mb2 = fmaf(fminf(fmaxf(rb[0] * big, 0.f), 1.f), (float)(1u << ((15 + r) & 15)), mb2);
+          mb3 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb3);
         }
       }
-      if (SAVE && qvalid) MKb[(size_t)(j0 + jj) * 2 * NST + q0 + c] = (unsigned short)(unsigned)(mb0 + mb1);
+      if (SAVE) MKb[(size_t)(j0 + jj) * 2 * NST + q0 + c] = (unsigned short)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded rows: no bounds check
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);   // both halves store the same sum: no exec masking in the loop
     }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       s[r] = sv;
       tmax = fmaxf(tmax, sv);
     }
-    if (LTb && qvalid) {
+    if (SAVE) {                               // rows are padded to whole workgroup tiles: lanes past N write padding
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = acc_row(r, hf);
@@ -1172,7 +1172,9 @@ __global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long to
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int smml_deform_attn_nst(int N) { return (N + 31) & ~31; }
+// row stride of the key-major score / mask tensors: whole 128-query workgroup tiles, so that the forward stores its rows
+// without per-lane bounds checks (columns >= N are padding nobody reads)
+int smml_deform_attn_nst(int N) { return (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
 
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
                                       void* stream) {

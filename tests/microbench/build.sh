@@ -8,6 +8,5 @@ build() { # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
 build base
-build g3c3 -DSMML_G_TERMS=3 -DSMML_CHAIN2_TERMS=3
 wait
 ls bin
