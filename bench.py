@@ -208,12 +208,12 @@ def main():
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
             ach = flop / (ms * 1e-3) / 1e12
-            out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2>", "bound": "mfma", "achieved": ach,
+            out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2, true>", "bound": "mfma", "achieved": ach,
                                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                    "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                    "note": "priced against the fp32 peak although the position-bias layers run as split products on the "
                                            "16-bit matrix pipe (one 32x32x16 MFMA does the work of eight fp32 ones), hence frac > 1 is "
-                                           "possible; 7 MFMAs + ~110 vector instructions per (key, 32 queries) + the fp32 QK^T / PV MFMAs"}
+                                           "possible; 7 MFMAs + ~145 vector instructions per (key, 32 queries) incl. packing the ReLU bits for the backward, + the fp32 QK^T / PV MFMAs"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, in_dim)
         print(json.dumps(out))
