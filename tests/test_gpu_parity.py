@@ -519,6 +519,48 @@ def test_fused_core_random_shapes(cuda):
                 assert l2(g, g64) <= tol, f"{tag} d{n}: l2 err {l2(g, g64):.3e} > {tol:.3e} (margin {margin:.1e})"
 
 
+def test_saved_relu_masks_match_reference(cuda):
+    """What the fused forward keeps of the position bias's hidden layer for its backward: one bit per unit
+    (include/smml.h: relu_masks [B, H, J, 2, nst] uint16, hidden channel acc_row(r, half) of lane (query, half) at bit
+    (13 + r) % 16).  Decoded, the bits must equal [W2 relu(W1 p + b1) + b2 > 0] of a torch fp64 evaluation wherever that
+    pre-activation is not within fp32 rounding of zero; padding columns are ignored."""
+    capi = smml._capi
+    gen = torch.Generator().manual_seed(5)
+    B, N, J, H, G, PD = 2, 150, 37, 8, 4, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * G, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+             w3=rn(H // G, 32) * 0.3, b3=rn(H // G) * 0.1)
+    d = {n: x.to(cuda).contiguous() for n, x in t.items()}
+    L = capi.lib()
+    nst = L.smml_deform_attn_nst(N)
+    assert nst % 128 == 0 and nst >= N
+    out = torch.empty(B, N, 512, device=cuda)
+    lse = torch.empty(B, H, N, device=cuda)
+    logits = torch.empty(B, H, J, nst, device=cuda)
+    masks = torch.zeros(B, H, J, 2, nst, device=cuda, dtype=torch.int16)
+    capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
+                                          capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
+                                          0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")
+    torch.cuda.synchronize()
+    r = {n: x.to(cuda, torch.float64) for n, x in t.items()}
+    pos = r["gq"][None, :, None, :] - r["vs"].view(B * G, 1, J, PD)
+    x2 = torch.relu((torch.sign(pos) * torch.log(pos.abs() + 1)) @ r["w1"].T + r["b1"]) @ r["w2"].T + r["b2"]   # [(B G), N, J, 32]
+    x2 = x2.view(B, G, N, J, 32)
+    bits = masks.to(torch.int32) & 0xFFFF                                                   # [B, H, J, 2, nst]
+    o = H // G
+    checked = wrong = 0
+    for half in range(2):
+        for reg in range(16):
+            ch = (reg & 3) + 8 * (reg >> 2) + 4 * half                                      # acc_row(reg, half)
+            got = ((bits[:, :, :, half, :N] >> ((13 + reg) % 16)) & 1).bool()               # [B, H, J, N]
+            ref = x2[..., ch].permute(0, 1, 3, 2).repeat_interleave(o, dim=1)               # [B, H, J, N] (heads of a group share layers 1-2)
+            sure = ref.abs() > 1e-5
+            checked += int(sure.sum())
+            wrong += int(((got != (ref > 0)) & sure).sum())
+    assert checked > 0.99 * B * H * J * N * 32 and wrong == 0, f"{wrong} of {checked} saved ReLU decisions differ"
+
+
 def test_gemm_random_shapes(cuda):
     """smml_gemm_f32 on random shapes, operand layouts (k- or row-contiguous, padded leading dimensions that keep or break
     the 16-byte alignment of the tiled kernels), batch dimensions, split-K and epilogues, against torch in fp64."""
