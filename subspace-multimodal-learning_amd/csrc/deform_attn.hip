@@ -36,6 +36,13 @@
                               // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
                               // 4 of 12 (forward) / 30 (backward) MFMAs per key
 #endif
+#ifndef SMML_DELTA_FIX
+#define SMML_DELTA_FIX 0      // 1: re-centre the rows of d bias in the position-bias backward (d bias_k - P_k sum_k d bias_k).
+                              // A fused softmax backward leaves sum_k dS_k != 0 at the 1e-7 level (delta = rowsum(dO . O));
+                              // sums that weight d bias with near-constant factors amplify it.  Measured (tests/diag_gterms.py):
+                              // dW3 4x and, with every ReLU unit active, dW2 / db 3-4x closer to fp64; everything else
+                              // unchanged; costs 0.3-0.45 ms of the 17.5 ms step (one more score read + an exp per pair).
+#endif
 #ifndef SMML_CHAIN2_TERMS
 #define SMML_CHAIN2_TERMS 2   // fp16 terms of the constant (W2 w3)^T in d h1 = (W2 w3)^T mask.  The mask operand is exact, so the
                               // only error is the constant's: 2 terms = 22 bits, a fixed relative perturbation <= 2^-23 of
@@ -424,7 +431,7 @@ __device__ __forceinline__ float prob_bias(float lse) { return -lse; }
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
-    float* __restrict__ dLT, float* __restrict__ dQ, int N, int J, int H, int NST,
+    float* __restrict__ dLT, float* __restrict__ dQ, float* __restrict__ RHO, int N, int J, int H, int NST,
     float scale, DropCfg dc) {
   __shared__ __attribute__((aligned(16))) __bf16 Vp[2][3][KT * VBLD];
   __shared__ __attribute__((aligned(16))) __bf16 Kp[2][3][KT * KBLD];
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
 
   floatx16 dq0 = {0}, dq1 = {0};
+  float rho = 0.f;       // sum over keys of this query's d scores: 0 in exact arithmetic, ~1e-7 |dO||O| with delta = rowsum(dO . O)
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
@@ -532,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
       }
       ds[r] = v;
+      rho += v;
     }
     // dQ^T[d, query] += K^T . dS^T: accumulator register 8 kb + j of dS^T is element j of K-block kb (keys 16 kb + 4 hf + 0..3
     // and 16 kb + 8 + 4 hf + 0..3), the K^T fragment is gathered for the same keys by two transposed reads
@@ -553,6 +562,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       }
     }
   }
+  rho = xhalf_sum(rho);
+  if (qvalid && hf == 0) RHO[(size_t)(b * H + h) * N + qi] = rho;
   if (qvalid) {
     float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
 #pragma unroll
@@ -763,7 +774,8 @@ constexpr int CPB2_TAB = 2 * 2 * 16;                                // {w1x, w1y
 
 template <int PD>
 __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
-    const float* __restrict__ dLT, const unsigned short* __restrict__ MK, const float* __restrict__ VS,
+    const float* __restrict__ dLT, const unsigned short* __restrict__ MK, const float* __restrict__ LT,
+    const float* __restrict__ LSE, const float* __restrict__ RHO, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H,
     int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -854,11 +866,24 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
   float db_n = dLTb[qcol];
+#if SMML_DELTA_FIX
+  // The d scores of a fused softmax backward use delta = rowsum(dO . O), which leaves sum_k dS_k = rho != 0 at the 1e-7
+  // level per query (in exact arithmetic delta = sum_k P_k dP_k and the row sums vanish).  The sums below multiply d bias
+  // by near-constant factors, which amplifies exactly that component, so the row is re-centred here: d bias_k - P_k rho.
+  const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
+  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
+  const float nrho = -RHO[(size_t)(b * H + h) * N + qi];
+  float lt_n = LTb[qcol];
+#endif
   const unsigned short* MKb = MK + ((size_t)(b * H + h) * J * 2 + hf) * NST;
   unsigned m16_n = MKb[qcol];
 
   for (int j = 0; j < J; ++j) {
+#if SMML_DELTA_FIX
+    const float vx = vx_n, vy = vy_n, dbias = qvalid ? fmaf(prob_of(lt_n, nl), nrho, db_n) : 0.f;
+#else
     const float vx = vx_n, vy = vy_n, dbias = qvalid ? db_n : 0.f;
+#endif
     const unsigned m16 = m16_n;
     {
       const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
@@ -866,6 +891,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
       db_n = dLTb[(size_t)jn * NST + qcol];
       m16_n = MKb[(size_t)jn * 2 * NST + qcol];
+#if SMML_DELTA_FIX
+      lt_n = LTb[(size_t)jn * NST + qcol];
+#endif
     }
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;                                          // for the channel-major stage (both halves store the same value)
@@ -1137,7 +1165,7 @@ static int dkv_parts(int B, int N, int J, int H) {
 // workspace layout (floats): [CPB slabs nwg * CPB_SLAB][stage-1 partials CHUNKS * CPB_SLAB * 2]
 //                            [dK slabs parts * B*J*H*64][dV slabs parts * B*J*H*64]
 struct BwdWorkspace {
-  size_t slab, partial, dkp, dvp, total;   // float offsets / total floats
+  size_t slab, partial, dkp, dvp, rho, total;   // float offsets / total floats
 };
 static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   BwdWorkspace w;
@@ -1147,7 +1175,8 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   w.partial = nwg * CPB_SLAB;
   w.dkp = (w.partial + (size_t)CPB_RED_CHUNKS * CPB_SLAB * 2 + 3) & ~(size_t)3;
   w.dvp = w.dkp + kv;
-  w.total = w.dvp + kv;
+  w.rho = w.dvp + kv;                      // [B, H, N] row sums of d scores (SMML_DELTA_FIX)
+  w.total = w.rho + (((size_t)B * H * N + 3) & ~(size_t)3);
   return w;
 }
 
@@ -1265,7 +1294,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
   float* wsf = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
-                     dlogits_t, dq, N, J, H, nst, scale, dc);
+                     dlogits_t, dq, wsf + wsl.rho, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
   // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
   {
@@ -1290,11 +1319,11 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     SMML_REQUIRE(lds <= 80 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
-      hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, vs, gq, cp, slab,
-                         dvs, N, J, H, G, nst);
+      hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
+                         wsf + wsl.rho, vs, gq, cp, slab, dvs, N, J, H, G, nst);
     else
-      hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, vs, gq, cp, slab,
-                         dvs, N, J, H, G, nst);
+      hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
+                         wsf + wsl.rho, vs, gq, cp, slab, dvs, N, J, H, G, nst);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;

@@ -8,5 +8,6 @@ build() { # name, flags...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize -DVARIANT="\"$name\"" "$@" attn_microbench.hip -o bin/mb_$name &
 }
 build base
+build deltafix -DSMML_DELTA_FIX=1
 wait
 ls bin
