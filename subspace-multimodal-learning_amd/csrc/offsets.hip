@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
     const int ty = j / tw, tx = j - ty * tw;
     // recompute the forward
     float y[CPL], ge[CPL];
+    float qv[CPL][KH * KW];                  // the window's taps: read once, used by the recompute and by the weight gradient
     float o0 = 0.f, o1 = 0.f;
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
           const int ix = tx * rw - pw + kx;
-          if (iy >= 0 && iy < Hh && ix >= 0 && ix < Ww)
-            acc = fmaf(w0[(ch * KH + ky) * KW + kx], q[(((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch], acc);
+          const bool in = iy >= 0 && iy < Hh && ix >= 0 && ix < Ww;
+          qv[u][ky * KW + kx] = in ? q[(((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch] : 0.f;
+          acc = fmaf(w0[(ch * KH + ky) * KW + kx], qv[u][ky * KW + kx], acc);
         }
       }
       y[u] = acc;
@@ -182,17 +184,7 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
       dyb[(size_t)wid * dg + ch] = dy;
       ab0[u] += dy;
 #pragma unroll
-      for (int ky = 0; ky < KH; ++ky) {
-        const int iy = ty * rh - ph + ky;
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-          const int ix = tx * rw - pw + kx;
-          if (iy >= 0 && iy < Hh && ix >= 0 && ix < Ww) {
-            const size_t qi = (((size_t)b * Hh + iy) * Ww + ix) * inner + g * dg + ch;
-            aw0[u][ky * KW + kx] = fmaf(dy, q[qi], aw0[u][ky * KW + kx]);
-          }
-        }
-      }
+      for (int t = 0; t < KH * KW; ++t) aw0[u][t] = fmaf(dy, qv[u][t], aw0[u][t]);   // taps outside the map are 0
     }
   }
   // weight-gradient partials: sum the workgroup's waves in LDS, then one contiguous slab row per workgroup
@@ -219,26 +211,33 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
 __global__ __launch_bounds__(256) void offsets_bwd_gather_kernel(const float* __restrict__ dyb, const float* __restrict__ w0,
                                                                  float* __restrict__ dq, int Hh, int Ww, int G, int dg, int KH,
                                                                  int KW, int rh, int rw, int ph, int pw, int th, int tw) {
+  extern __shared__ __attribute__((aligned(16))) float wT[];   // w0 transposed to [tap][channel]: one float4 per window
+  const int KKs = KH * KW;
+  for (int i = threadIdx.x; i < dg * KKs; i += blockDim.x) {
+    const int chs = i / KKs, tap = i - chs * KKs;
+    wT[tap * dg + chs] = w0[i];
+  }
+  __syncthreads();
   const int inner = G * dg, iq = inner >> 2;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= Ww * iq) return;
-  const int x = t / iq, c4 = (t - x * iq) * 4, g = c4 / dg, ch = c4 - g * dg;
   const int y = blockIdx.y % Hh, b = blockIdx.y / Hh;
   const int ty1 = min(th - 1, (y + ph) / rh), ty0 = max(0, (y + ph - (KH - 1) + rh - 1) / rh);
-  const int tx1 = min(tw - 1, (x + pw) / rw), tx0 = max(0, (x + pw - (KW - 1) + rw - 1) / rw);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int KK = KH * KW;
-  for (int ty = ty0; ty <= ty1; ++ty) {
-    const int ky = y + ph - ty * rh;
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int kx = x + pw - tx * rw;
-      const float4 d = *reinterpret_cast<const float4*>(dyb + ((size_t)(b * G + g) * th * tw + ty * tw + tx) * dg + ch);
-      const float* w = w0 + ch * KK + ky * KW + kx;
-      acc.x = fmaf(d.x, w[0], acc.x); acc.y = fmaf(d.y, w[KK], acc.y);
-      acc.z = fmaf(d.z, w[2 * KK], acc.z); acc.w = fmaf(d.w, w[3 * KK], acc.w);
+  // a block walks a slice of one (b, y) row of the map: the transposed weights are staged once per slice
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Ww * iq; t += gridDim.x * blockDim.x) {
+    const int x = t / iq, c4 = (t - x * iq) * 4, g = c4 / dg, ch = c4 - g * dg;
+    const int tx1 = min(tw - 1, (x + pw) / rw), tx0 = max(0, (x + pw - (KW - 1) + rw - 1) / rw);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ty = ty0; ty <= ty1; ++ty) {
+      const int ky = y + ph - ty * rh;
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int kx = x + pw - tx * rw;
+        const float4 d = *reinterpret_cast<const float4*>(dyb + ((size_t)(b * G + g) * th * tw + ty * tw + tx) * dg + ch);
+        const float4 w = *reinterpret_cast<const float4*>(wT + (ky * KW + kx) * dg + ch);
+        acc.x = fmaf(d.x, w.x, acc.x); acc.y = fmaf(d.y, w.y, acc.y);
+        acc.z = fmaf(d.z, w.z, acc.z); acc.w = fmaf(d.w, w.w, acc.w);
+      }
     }
+    *reinterpret_cast<float4*>(dq + (((size_t)b * Hh + y) * Ww + x) * inner + c4) = acc;
   }
-  *reinterpret_cast<float4*>(dq + (((size_t)b * Hh + y) * Ww + x) * inner + c4) = acc;
 }
 
 // column sums of a slab [nrows][nred] in two fixed-order stages: part[p][i] = sum of rows p*chunk .. ; then the final sum
@@ -436,7 +435,11 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
                        B, Hh, Ww, G, rh, r, ph, pw, th, tw, posdim, offset_scale);
   SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/points");
   SMML_REQUIRE((dg % 4) == 0, "smml_offsets_bwd_f32: channels per group must be a multiple of 4");
-  hipLaunchKernelGGL(offsets_bwd_gather_kernel, dim3((Ww * (G * dg / 4) + 255) / 256, B * Hh), block, 0, st, dyb, w0, dq, Hh,
+  // grid.x: slices of a (b, y) row; few enough that the weight staging is amortised, enough rows x slices to fill the chip
+  const int row_threads = Ww * (G * dg / 4);
+  const int slices = max(1, min((row_threads + 255) / 256, (4096 + B * Hh - 1) / (B * Hh)));
+  hipLaunchKernelGGL(offsets_bwd_gather_kernel, dim3(slices, B * Hh), block,
+                     (size_t)dg * kh * ks * sizeof(float), st, dyb, w0, dq, Hh,
                      Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
   SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/gather");
   float* part = slab + (size_t)nblk * nred;

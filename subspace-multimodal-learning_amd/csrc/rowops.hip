@@ -118,6 +118,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// sum over the 32 lanes of a half-wave (both halves independently)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// C = 128 (the path's token width): a half-wave per row, one float4 per lane, two row pairs per trip - four rows of
+// loads in flight per wave instead of one (the generic kernel is latency-bound at 128 columns)
+__global__ __launch_bounds__(256) void layernorm_bwd128_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               long long R, long long rows_per_dy, float dy_scale,
+                                                               int accumulate_dx) {
+  constexpr int C = 128;
+  __shared__ float red[2][8][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * hl);
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  const long long stride = (long long)gridDim.x * 16;          // rows per trip of the whole grid: 4 waves x 2 halves x 2
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 4 + half; r0 < R; r0 += stride) {
+    float4 xv[2], dv[2];
+    float mu[2], rs[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long row = r0 + 2 * u;
+      ok[u] = row < R;
+      const long long rr = ok[u] ? row : R - 1;
+      xv[u] = *reinterpret_cast<const float4*>(x + rr * C + 4 * hl);
+      dv[u] = *reinterpret_cast<const float4*>(dy + (rr / rows_per_dy) * C + 4 * hl);
+      mu[u] = mean[rr]; rs[u] = rstd[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float sc = ok[u] ? dy_scale : 0.f;
+      const float4 d = make_float4(dv[u].x * sc, dv[u].y * sc, dv[u].z * sc, dv[u].w * sc);
+      const float4 xh = make_float4((xv[u].x - mu[u]) * rs[u], (xv[u].y - mu[u]) * rs[u], (xv[u].z - mu[u]) * rs[u],
+                                    (xv[u].w - mu[u]) * rs[u]);
+      const float4 gd = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      float s1 = (gd.x + gd.y) + (gd.z + gd.w);
+      float s2 = (gd.x * xh.x + gd.y * xh.y) + (gd.z * xh.z + gd.w * xh.w);
+      ag.x += d.x * xh.x; ag.y += d.y * xh.y; ag.z += d.z * xh.z; ag.w += d.w * xh.w;
+      ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+      s1 = half_sum(s1) * (1.f / C);
+      s2 = half_sum(s2) * (1.f / C);
+      if (ok[u]) {
+        float4* dxr = reinterpret_cast<float4*>(dx + (r0 + 2 * u) * C + 4 * hl);
+        float4 v = make_float4(rs[u] * (gd.x - s1 - xh.x * s2), rs[u] * (gd.y - s1 - xh.y * s2),
+                               rs[u] * (gd.z - s1 - xh.z * s2), rs[u] * (gd.w - s1 - xh.w * s2));
+        if (accumulate_dx) { const float4 o = *dxr; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dxr = v;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(&red[0][wave * 2 + half][4 * hl]) = ag;
+  *reinterpret_cast<float4*>(&red[1][wave * 2 + half][4 * hl]) = ab;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float g = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g += red[0][i][threadIdx.x]; bsum += red[1][i][threadIdx.x]; }
+    atomicAdd(&dgamma[threadIdx.x], g);
+    atomicAdd(&dbeta[threadIdx.x], bsum);
+  }
+}
+
 // out[b, c] += scale * sum_{r in chunk} x[b, r, c]   (x [nb, R, C] contiguous; out zeroed by the caller)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long R,
                                                      int C, float scale, int rows_per_block) {
@@ -220,6 +288,13 @@ int smml_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, 
   SMML_REQUIRE(R > 0 && C > 0 && C <= 64 * MAXV, "smml_layernorm_bwd_f32: need 0 < C <= %d (got %d)", 64 * MAXV, C);
   SMML_REQUIRE(rows_per_dy >= 1, "smml_layernorm_bwd_f32: rows_per_dy must be >= 1");
   const long long nblk = (R + 3) / 4;
+  const bool aligned = ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(dx) |
+                         reinterpret_cast<size_t>(gamma)) & 15) == 0;
+  if (C == 128 && aligned) {
+    const long long nb16 = (R + 15) / 16;
+    hipLaunchKernelGGL(layernorm_bwd128_kernel, dim3((unsigned)(nb16 < 768 ? nb16 : 768)), dim3(256), 0, (hipStream_t)stream,
+                       x, dy, gamma, mean, rstd, dx, dgamma, dbeta, R, rows_per_dy, dy_scale, accumulate_dx);
+  } else
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)(nblk < 1024 ? nblk : 1024)), dim3(256), 0, (hipStream_t)stream,
                      x, dy, gamma, mean, rstd, dx, dgamma, dbeta, R, C, rows_per_dy, dy_scale, accumulate_dx);
   SMML_LAUNCH_CHECK("smml_layernorm_bwd_f32");

@@ -159,6 +159,26 @@ def test_linear_layernorm_autograd(cuda):
         _assert_close(n, a, r, 2e-5)
 
 
+@pytest.mark.parametrize("rows", [1, 3, 16, 37, 1000])
+def test_layernorm_128_columns(cuda, rows):
+    """The 128-column LayerNorm backward has its own kernel (half-wave per row, four rows in flight): plain and
+    token-mean forms (broadcast dy rows) at row counts that are not multiples of its 16-row blocks, vs torch on CPU."""
+    torch.manual_seed(rows)
+    x = torch.randn(2, rows, 128); g = torch.randn(128); be = torch.randn(128)
+    wy = torch.randn(2, rows, 128); wm = torch.randn(2, 128)
+    def run(dev, ln, ln_mean):
+        xs, gs, bes = (t.clone().to(dev).requires_grad_() for t in (x, g, be))
+        y = ln(xs, gs, bes)
+        z = ln_mean(xs * 0.5 + 0.1, gs, bes)
+        ((y * wy.to(dev)).sum() + (z * wm.to(dev)).sum()).backward()
+        return [y, z, xs.grad, gs.grad, bes.grad]
+    ref = run("cpu", lambda a, gg, bb: torch.nn.functional.layer_norm(a, (128,), gg, bb),
+              lambda a, gg, bb: torch.nn.functional.layer_norm(a, (128,), gg, bb).mean(dim=1))
+    got = run(cuda, Fh.layer_norm, Fh.layer_norm_token_mean)
+    for n, a, r in zip(("y", "z", "dx", "dgamma", "dbeta"), got, ref):
+        _assert_close(n, a, r, 2e-5)
+
+
 @pytest.mark.parametrize("B,Hh,Ww", [(2, 12, 12), (1, 20, 20), (2, 14, 23), (1, 38, 38), (1, 6, 6), (2, 5, 9), (1, 31, 7)])
 def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     """Small grids incl. non-square, N not a multiple of 128, J not a multiple of 32 (ragged tiles)."""
