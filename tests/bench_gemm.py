@@ -10,6 +10,14 @@ cuda = torch.device("cuda:0")
 L = smml.lib()
 # (name, batch, M, N, K, a_kc, b_kc)
 SHAPES = [
+    # the headline step at 8 bags (80 000 tokens)
+    ("8 bags fc1 / to_out fwd  x W^T", 1, 80000, 128, 512, True, True),
+    ("8 bags to_q fwd          x W^T", 1, 80000, 512, 128, True, True),
+    ("8 bags to_out dX         dy W", 1, 80000, 512, 128, True, False),
+    ("8 bags to_q dX           dy W", 1, 80000, 128, 512, True, False),
+    ("8 bags fc1 dW            dy^T x", 1, 128, 512, 80000, False, False),
+    ("8 bags to_q dW           dy^T x", 1, 512, 128, 80000, False, False),
+    ("8 bags fusion            x W^T", 1, 80000, 128, 128, True, True),
     ("fc1 fwd            x W^T", 1, 40000, 128, 512, True, True),
     ("fc1 dW             dy^T x", 1, 128, 512, 40000, False, False),
     ("nystrom qkv        x W^T", 1, 32768, 1536, 512, True, True),
