@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)      # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("SMML_GEMM_MODE"):       # measurement switch: 1 = fp32-MFMA GEMM only, 2 = split-bf16 wherever it applies
+            handle.smml_gemm_set_mode(int(os.environ["SMML_GEMM_MODE"]))
         _lib = handle
     return _lib
 

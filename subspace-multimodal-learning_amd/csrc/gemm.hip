@@ -155,43 +155,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   const int tps = (ktiles + g.splitk - 1) / g.splitk;
   const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
 
-  // staging maps (2 float4 of A, NI float4 of B per thread)
+  // staging maps (2 float4 of A, NI float4 of B per thread).  Everything that does not depend on the K-tile - row / column
+  // clamps, 64-bit row offsets, which of the three forms a row-contiguous float4 takes - is worked out once here: the
+  // fp32 MFMA shares its ALUs with vector work, so address arithmetic inside the K loop costs matrix throughput.
   float4 ra[2], rb[NI];
+  const float* pa[2];            // k-contiguous: row base (+ 4 kq); row-contiguous: column base (+ 4 mq), advanced by k * stride
+  const float* pb[NI];
+  int ka[2], kb_[NI];            // the k index (within a tile) this thread stages
+  int fa[2], fb[NI];             // row-contiguous operands: 0 = nothing to read, 1 = one float4, 2 = ragged edge (scalar reads)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (A_KC) {
+      const int row = (tid >> 2) + 64 * i, kq = tid & 3;
+      pa[i] = A + (long long)min(m0 + row, g.M - 1) * g.sam + 4 * kq;
+      ka[i] = 4 * kq; fa[i] = 1;
+    } else {
+      const int k = (tid >> 5) + 8 * i, mq = tid & 31, gm = m0 + 4 * mq;
+      pa[i] = A + min(gm, g.M - 1);
+      ka[i] = k; fa[i] = (gm >= g.M) ? 0 : (gm + 3 < g.M ? 1 : 2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (B_KC) {
+      const int row = (tid >> 2) + 64 * i, kq = tid & 3;
+      pb[i] = B + (long long)min(n0 + row, g.N - 1) * g.sbn + 4 * kq;
+      kb_[i] = 4 * kq; fb[i] = 1;
+    } else {
+      constexpr int NQ = BN_ / 4;                            // float4 per k-row
+      const int idx = tid + 256 * i, k = idx / NQ, nq = idx - k * NQ, gn = n0 + 4 * nq;
+      pb[i] = B + min(gn, g.N - 1);
+      kb_[i] = k; fb[i] = (gn >= g.N) ? 0 : (gn + 3 < g.N ? 1 : 2);
+    }
+  }
   auto load_tile = [&](int kt) {
     const int k0 = kt * FBK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (A_KC) {
-        const int row = (tid >> 2) + 64 * i, kq = tid & 3;
-        const long long gm = min(m0 + row, g.M - 1);
-        ra[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i] = (k0 + ka[i] < g.K) ? *reinterpret_cast<const float4*>(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        const int k = (tid >> 5) + 8 * i, mq = tid & 31;
-        const int gm = m0 + 4 * mq;
-        const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
-        if (k0 + k >= g.K) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        else if (gm >= g.M) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);            // tile wider than the operand: nothing to read
-        else if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
-        else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
+        const int k = k0 + ka[i];
+        const float* p = pa[i] + (long long)min(k, g.K - 1) * g.sak;
+        if (k >= g.K || fa[i] == 0) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);               // K tail / tile wider than the operand: nothing to read
+        else if (fa[i] == 1) ra[i] = *reinterpret_cast<const float4*>(p);
+        else { const int gm = m0 + 4 * (tid & 31), last = g.M - 1 - gm;           // ragged edge: gm <= M - 1 < gm + 3
+               ra[i] = make_float4(p[0], p[min(1, last)], p[min(2, last)], p[min(3, last)]); }
       }
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       if (B_KC) {
-        const int row = (tid >> 2) + 64 * i, kq = tid & 3;
-        const long long gn = min(n0 + row, g.N - 1);
-        rb[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = (k0 + kb_[i] < g.K) ? *reinterpret_cast<const float4*>(pb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        constexpr int NQ = BN_ / 4;                            // float4 per k-row
-        const int idx = tid + 256 * i, k = idx / NQ, nq = idx - k * NQ;
-        const int gn = n0 + 4 * nq;
-        const float* p = B + (long long)min(k0 + k, g.K - 1) * g.sbk;
-        if (k0 + k >= g.K) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        else if (gn >= g.N) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        else if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
-        else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
+        const int k = k0 + kb_[i];
+        const float* p = pb[i] + (long long)min(k, g.K - 1) * g.sbk;
+        if (k >= g.K || fb[i] == 0) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (fb[i] == 1) rb[i] = *reinterpret_cast<const float4*>(p);
+        else { constexpr int NQ = BN_ / 4; const int idx = tid + 256 * i, gn = n0 + 4 * (idx - (idx / NQ) * NQ), last = g.N - 1 - gn;
+               rb[i] = make_float4(p[0], p[min(1, last)], p[min(2, last)], p[min(3, last)]); }
       }
     }
   };
@@ -316,7 +338,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
   const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
 
   float4 ra[NA], rb[NB];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_tile = [&](int kt) {
     const int k0 = kt * FBK;
 #pragma unroll
@@ -325,12 +346,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       if (A_KC) {
         const int row = idx >> 3, kq = idx & 7;
         const long long gm = min(m0 + row, g.M - 1);
-        ra[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq) : zero4;
+        ra[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         const int k = idx >> 5, mq = idx & 31;
         const int gm = m0 + 4 * mq;
         const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
-        if (k0 + k >= g.K) ra[i] = zero4;
+        if (k0 + k >= g.K) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (gm >= g.M) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);            // tile wider than the operand: nothing to read
         else if (gm + 3 < g.M) ra[i] = *reinterpret_cast<const float4*>(p + gm);
         else ra[i] = make_float4(p[min(gm, g.M - 1)], p[min(gm + 1, g.M - 1)], p[min(gm + 2, g.M - 1)], p[min(gm + 3, g.M - 1)]);
@@ -342,13 +363,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       if (B_KC) {
         const int row = idx >> 3, kq = idx & 7;
         const long long gn = min(n0 + row, g.N - 1);
-        rb[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq) : zero4;
+        rb[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(B + gn * g.sbn + k0 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         constexpr int NQ = BN_ / 4;
         const int k = idx / NQ, nq = idx - k * NQ;
         const int gn = n0 + 4 * nq;
         const float* p = B + (long long)min(k0 + k, g.K - 1) * g.sbk;
-        if (k0 + k >= g.K) rb[i] = zero4;
+        if (k0 + k >= g.K) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (gn >= g.N) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (gn + 3 < g.N) rb[i] = *reinterpret_cast<const float4*>(p + gn);
         else rb[i] = make_float4(p[min(gn, g.N - 1)], p[min(gn + 1, g.N - 1)], p[min(gn + 2, g.N - 1)], p[min(gn + 3, g.N - 1)]);
@@ -511,9 +532,11 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
     g.swap_xy = fswap;
     dim3 grid((unsigned)(fswap ? fy : gx), (unsigned)(fswap ? gx : fy), (unsigned)gz);
     hipStream_t st = (hipStream_t)stream;
-    // Measured (tests/bench_gemm.py): the split-bf16 kernel wins only on large square-ish products (138 vs 128 TF at 4096^3;
-    // on the path's skinny / short-K shapes the operand splits and the extra LDS traffic cost more than the MFMA time saved),
-    // so the automatic choice keeps it for those.
+    // Measured: in isolation (tests/bench_gemm.py) the split-bf16 kernel beats the fp32 MFMA kernel wherever K >= 128 and the
+    // tile is not a 64-column sliver (107 vs 92 TF on the 80 000 x 128 x 512 projections of the headline step, 150 vs 118
+    // TF on the Nystrom qkv product, 173 vs 124 TF at 4096^3) - but inside the training step, A/B on one box
+    // (SMML_GEMM_MODE=1 vs automatic with that wider rule), the step is not faster (17.2 / 17.5 vs 17.6 / 17.5 ms) and
+    // the errors against the oracle grow 2x.  So the automatic choice keeps it for large square-ish products only.
     const bool bf3 = (g_mode == 2) || (g_mode == 0 && K >= 2048 && M >= 1024 && N >= 1024);
 #define SMML_FAST(BNV, AK, BK2)                                                                   \
   do {                                                                                            \
