@@ -6,6 +6,7 @@ tensors are fp32 and token-major (channel-last).  There is no CPU / eager fallba
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -55,6 +56,41 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+class _ZeroPool:
+    """Small zero-initialised fp32 tensors (weight / bias gradients that kernels accumulate into with atomics) carved out
+    of one pre-zeroed slab per device: one fill kernel per slab instead of one per tensor (a training step asked for ~40
+    of them, each a launch-bound 2-5 us).  Slices are never reused - a slab is dropped when it runs out and lives on
+    only as long as its slices do - so a tensor handed out here is as private as torch.zeros(...) would be."""
+    SLAB = 1 << 20            # floats (4 MiB)
+    LIMIT = 1 << 16           # larger requests go to torch.zeros directly
+
+    def __init__(self):
+        self.slabs = {}
+        self.enabled = os.environ.get("SMML_ZERO_POOL", "1") != "0"   # measurement switch
+
+    def zeros(self, shape, device) -> torch.Tensor:
+        shape = tuple(int(d) for d in shape)
+        n = 1
+        for d in shape:
+            n *= d
+        if n == 0 or n > self.LIMIT or torch.device(device).type != "cuda" or not self.enabled:
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        buf, used = self.slabs.get(key, (None, self.SLAB))
+        n4 = (n + 3) & ~3                                    # keep every slice 16-byte aligned
+        if used + n4 > self.SLAB:
+            buf, used = torch.zeros(self.SLAB, device=device, dtype=torch.float32), 0
+        self.slabs[key] = (buf, used + n4)
+        return buf[used:used + n].view(shape)
+
+
+_ZEROS = _ZeroPool()
+
+
+def _zeros_like(t: torch.Tensor) -> torch.Tensor:
+    return _ZEROS.zeros(t.shape, t.device)
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
@@ -80,7 +116,7 @@ def colsum(x2d_or_3d: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     """x [nb, R, C] -> [nb, C] column sums * scale."""
     x = x2d_or_3d
     nb, R, Cc = x.shape
-    out = torch.zeros(nb, Cc, device=x.device, dtype=torch.float32)
+    out = _ZEROS.zeros((nb, Cc), x.device)
     capi.check(capi.lib().smml_colsum_f32(capi.fptr(x), capi.fptr(out), nb, R, Cc, float(scale), capi.stream()), "colsum")
     return out
 
@@ -129,7 +165,7 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             _gemm(dpre, weight, dx, M=M, N=K, K=N, sam=N, sak=1, sbk=K, sbn=1, ldc=K)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(weight)
+            dw = _zeros_like(weight)
             _gemm(dpre, x, dw, M=N, N=K, K=M, sam=1, sak=N, sbk=K, sbn=1, ldc=K, splitk=_splitk_for(N, K, M))
         if ctx.bias_mode and ctx.needs_input_grad[2]:
             if ctx.bias_mode == 1:
@@ -177,7 +213,7 @@ class _GroupedPointwise(torch.autograd.Function):
             _gemm(dy, w, dx, M=M, N=cin_g, K=cout_g, sam=Cout, sak=1, sbk=cin_g, sbn=1, ldc=Cin, nb1=G,
                   sa1=cout_g, sb1=cout_g * cin_g, sc1=cin_g)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            dw = _zeros_like(w)
             _gemm(dy, x, dw, M=cout_g, N=cin_g, K=M, sam=1, sak=Cout, sbk=Cin, sbn=1, ldc=cin_g, nb1=G,
                   sa1=cout_g, sb1=cin_g, sc1=cout_g * cin_g, splitk=_splitk_for(cout_g, cin_g, M, G))
             dw = dw.reshape(ctx.wshape)
@@ -217,8 +253,8 @@ class _LayerNorm(torch.autograd.Function):
         Cc = x.shape[-1]
         R = x.numel() // Cc
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dg = _zeros_like(gamma)
+        db = _zeros_like(gamma)
         rows_per_dy, scale = (x.shape[1], 1.0 / x.shape[1]) if ctx.token_mean else (1, 1.0)
         capi.check(capi.lib().smml_layernorm_bwd_f32(capi.fptr(x), capi.fptr(dy), capi.fptr(gamma), capi.fptr(mean),
                                                      capi.fptr(rstd), capi.fptr(dx), capi.fptr(dg), capi.fptr(db), R, Cc,
@@ -307,7 +343,7 @@ class _Sample(torch.autograd.Function):
         B, Hh, Ww, Cc = x.shape
         J = vs.shape[1]
         dx = torch.zeros_like(x)
-        dvs = torch.zeros_like(vs)
+        dvs = _zeros_like(vs)
         capi.check(capi.lib().smml_bilinear_sample_bwd_f32(capi.fptr(x), capi.fptr(vs), capi.fptr(_c(dkv)), capi.fptr(dx),
                                                            capi.fptr(dvs), B, Hh, Ww, groups, Cc // groups, J, posdim,
                                                            capi.stream()), "sample_bwd")
@@ -647,7 +683,7 @@ class _ResConv(torch.autograd.Function):
         v, w2 = ctx.saved_tensors
         B, H, n, D = v.shape
         dv = torch.empty_like(v)
-        dw = torch.zeros_like(w2)
+        dw = _zeros_like(w2)
         capi.check(capi.lib().smml_resconv_bwd_f32(capi.fptr(_c(dout)), capi.fptr(v), capi.fptr(w2), capi.fptr(dv),
                                                    capi.fptr(dw), B, H, n, D, w2.shape[1], capi.stream()), "resconv_bwd")
         return dv, dw.reshape(ctx.wshape)
@@ -679,8 +715,8 @@ class _DwConv7(torch.autograd.Function):
         L = capi.lib()
         capi.check(L.smml_dwconv7_fwd_f32(capi.fptr(dy), capi.fptr(wm), None, capi.fptr(dx), B, H, W, Cc, 1, capi.stream()),
                    "dwconv7_bwd_data")
-        dwm = torch.zeros_like(wm)
-        db = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+        dwm = _zeros_like(wm)
+        db = _ZEROS.zeros((Cc,), x.device)
         capi.check(L.smml_dwconv7_bwd_weight_f32(capi.fptr(x), capi.fptr(dy), capi.fptr(dwm), capi.fptr(db), B, H, W, Cc,
                                                  capi.stream()), "dwconv7_bwd_weight")
         return dx, dwm, db
