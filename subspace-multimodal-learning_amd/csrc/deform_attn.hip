@@ -764,8 +764,8 @@ __global__ void dkv_reduce_kernel(const float4* __restrict__ dKp, const float4* 
 constexpr int CPB_SLAB = 1024 + 64 + 32 + 32 + 32 + 8;   // 1192 floats
 constexpr int CPB_XQ = 2 * 32;                            // double-buffered d bias of the wave's 32 queries
 // Register budget (256 per wave, two waves per SIMD):
-//   * layer 1 itself runs on the matrix pipe: W1 p + b1 as a K = 8 bf16 product with every factor in three terms - a
-//     pair of 4-register constant operands instead of 48 per-channel constants;
+//   * layer 1 itself runs on the matrix pipe (K = 16 bf16 products with every factor in three terms): two 4-register
+//     constant operands + b1 in accumulator layout instead of 48 per-channel constants;
 //   * no software pipeline inside the wave (the sibling wave is the pipeline): nothing of the previous key is alive;
 //   * the layer-1 weights of the d vs product are read from a 256-byte LDS table when they are needed.
 constexpr int CPB2_STG_KEYS = 16;                                   // d vs staging rows per wave
