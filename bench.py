@@ -28,22 +28,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "subspace-multimodal-learning_amd"
 
-F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix), dense
+F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix) = FP32 vector, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA - the pipe every contraction of the dominant kernels issues on
 CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 1 + 1 + 2 + 4 + 4
-F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA
+CPB_FWD_MFMAS = 11                  # deform_attn_fwd_kernel: 1 (layer 1) + 10 (layer 2, five-term split) 16-bit MFMAs per (key, 32 queries)
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
+TRAFFIC_FILE = "r02_hbm_traffic.json"
 
 
 def measured_traffic(kernel, bags):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_hbm_traffic.json), scaled to this
-    run's bags per launch; None if no measurement is on file (bench.py itself cannot collect PMC counters)."""
+    """HBM bytes per launch of `kernel`.  bench.py cannot collect PMC counters itself: the figure is REPLAYED from the committed
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/r02_hbm_traffic.json, gfx950 correction
+    applied as MI355X_MICROARCH.md prescribes), scaled to this run's bags per launch; None if no pass is on file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             t = json.load(f)
         return t["kernels"][kernel]["hbm_bytes_per_launch"] * bags / t["bags_per_launch"]
     except Exception:
         return None
+
+
+def nystrom_flop(n, D=512, h=8, d=64, m=256, iters=6, k=33):
+    """forward flops F(n') of one Nystrom layer and the share of the 'QK / AV kernel' (sim1 + sim3 + attn3 v +
+    (attn1 z)(attn3 v) + attn1 z) the north_star's 40 % target is quoted on; fwd + bwd = 3 x."""
+    npad = -(-n // m) * m
+    total = (2 * npad * D * 3 * h * d + 2 * (2 * h * npad * m * d) + 2 * h * m * m * d + iters * 5 * 2 * h * m ** 3
+             + 2 * h * m * npad * d + 2 * h * npad * m * m + 2 * h * npad * m * d + 2 * k * h * npad * d + 2 * npad * D * D)
+    qkav = 2 * (2 * h * npad * m * d) + 2 * h * m * npad * d + 2 * h * npad * m * m + 2 * h * npad * m * d
+    return total, qkav
 
 
 def mil_args(in_dim):
@@ -58,37 +71,66 @@ def algorithmic_flop_per_bag(N, J, in_dim, C=128, H=8):
     return 2 * N * in_dim * C + 2 * N * 2 * C * C + attn
 
 
-def cpu_baseline(pkg, in_dim, seconds_budget=25.0):
-    """The oracle (plain PyTorch fp32 port of the reference's op sequence) timed on this box's host cores on a
-    bounded sample: one bag on the reference's own 50 x 50 grid, fwd+bwd; scaled to the N = 10 000 workload by
-    the algorithmic-flop ratio."""
+def cpu_baseline(pkg, in_dim, S, seconds_budget=90.0):
+    """The oracle (plain PyTorch fp32 port of the reference's op sequence, position bias evaluated in query chunks) timed on
+    this box's host cores on the workload itself: ONE bag of S*S instances (10 000 by default), forward + backward of the same
+    training-step loss, all cores; one warm-up on the reference's 50 x 50 grid (pages the code in), then >= 3 timed iterations
+    (fewer only if the budget runs out)."""
     from oracle.mil import deform_cross_trans_mil
-    cores = min(os.cpu_count() or 1, 32)      # small-op PyTorch CPU kernels stop scaling (and thrash) far beyond this
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    S = 50
     mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
     params = pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench")
-    path = pkg.synth.bag(1, S * S, in_dim, 42, "bench:cpu")
     omic = torch.relu(pkg.synth.normal((1, 128), 42, "bench:omic"))
 
-    def step():
+    def step(side):
+        path = pkg.synth.bag(1, side * side, in_dim, 42, f"bench:cpu:{side}")
         p = {k: v.clone().requires_grad_() for k, v in params.items()}
-        enc, logits, _, vg = deform_cross_trans_mil(path, omic, p, grid_hw=(S, S))
+        enc, logits, _, vg = deform_cross_trans_mil(path, omic, p, grid_hw=(side, side), q_chunk=1024)
         (torch.nn.functional.cross_entropy(logits, torch.tensor([1])) + 1e-3 * vg.pow(2).sum() + enc.sum() * 0).backward()
 
-    step()                                            # warm-up
-    t0 = time.perf_counter(); n = 0
-    while True:
-        step(); n += 1
-        el = time.perf_counter() - t0
-        if (n >= 3 and el > 10.0) or el > seconds_budget:
-            break
-    dt = (time.perf_counter() - t0) / n
-    ratio = algorithmic_flop_per_bag(10000, 625, in_dim) / algorithmic_flop_per_bag(S * S, 144, in_dim)
-    return {"value": (1.0 / dt) / ratio, "unit": "bags/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (plain PyTorch fp32) fwd+bwd of 1 bag on the reference's 50x50 grid (N=2500, J=144), "
-                      f"{n} iters, {dt:.2f} s/bag measured = {1.0 / dt:.3f} bags/s at N=2500; scaled to N=10000 by the "
-                      f"algorithmic-flop ratio {ratio:.1f}x"}
+    step(50)                                          # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
+        t0 = time.perf_counter(); step(S); times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    return {"value": 1.0 / dt, "unit": "bags/s", "cores": cores, "kind": "port", "cpu": model,
+            "sample": f"oracle (plain PyTorch fp32) fwd+bwd of 1 bag of {S * S} x {in_dim} ({S}x{S} grid), {len(times)} timed iterations "
+                      f"after 1 warm-up, {dt:.2f} s/bag, torch.set_num_threads({cores})"}
+
+
+def nystrom_leg(pkg, dev, B, n, steps=10, warmup=3):
+    """NystromAttention(dim 512, 8 heads x 64, 256 landmarks) forward + backward on B bags of n x 512 (BASELINE config 2 shape
+    and the N = 10 000 bag): ms per step from HIP events on the launch stream, algorithmic flops per SURVEY.md 8(d)."""
+    torch.manual_seed(7)
+    mod = pkg.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(dev).eval()
+    x = (torch.randn(B, n, 512, device=dev) * 0.5).requires_grad_()
+
+    def step():
+        mod.zero_grad(set_to_none=True); x.grad = None
+        mod(x).pow(2).mean().backward()
+
+    for _ in range(warmup):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(steps):
+        step()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    total, qkav = nystrom_flop(n)
+    tf = 3 * total * B / (ms * 1e-3) / 1e12
+    pipe = getattr(pkg.functional, "NYSTROM_PIPE", "f32")            # which matrix pipe the contractions issue on
+    peak = F16_MFMA_PEAK_TFLOPS if pipe != "f32" else F32_MFMA_PEAK_TFLOPS
+    return {"workload": f"NystromAttention fwd+bwd, {B} x {n} x 512, 256 landmarks", "ms_per_step": ms, "bags_per_s": B / (ms * 1e-3),
+            "algorithmic_TFLOPs": tf, "pipe": pipe, "peak_TFLOPs": peak, "frac": tf / peak,
+            "qkav_share_of_flops": qkav / total}
 
 
 def main():
@@ -100,6 +142,7 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,40 +225,38 @@ def main():
         }
         if "cpb_bwd" in kt:
             n, ms, pairs = kt["cpb_bwd"]
-            flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops, recompute not counted
+            flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops (4480 per pair), recompute not counted
             ach = flop / (ms * 1e-3) / 1e12
-            # dominant kernel.  Every 32x32 contraction runs on the 16-bit matrix pipe as a split product (fp16 / bf16
-            # terms, fp32-grade result); what bounds the kernel is the fp32 vector work around them (ReLU masks, operand
-            # splits, layer-1 backward) at two waves per SIMD.  Priced as algorithmic fp32 flops against the fp32 peak
-            # (matrix = vector = 157.3 TF).
+            issued = (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 1e12   # what the kernel executes: 12 MFMAs of 2 * 16384 flop
             kname = "cpb_bwd_kernel<2>"
-            # share of the 16-bit matrix pipe's time: CPB_BWD_MFMAS of 32 cycles per (key, 32 queries) on 1024 SIMDs at 2.4 GHz
-            pipe = (pairs / 32.0) * CPB_BWD_MFMAS * 32 / (1024 * ms * 1e-3 * 2.4e9)
-            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+            # dominant kernel.  Every contraction issues on the 16-bit matrix pipe (split fp16 / bf16 products, fp32-grade
+            # results), so the algorithmic flops are priced against THAT pipe's dense peak; what actually bounds the kernel is
+            # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~230 vector instructions per 12 MFMAs.
+            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
                                "traffic": measured_traffic(kname, B) if (S, in_dim) == (100, 512) else None,
+                               "traffic_source": f"replayed from profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command)",
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                               # what the hardware executes: CPB_BWD_MFMAS MFMAs of 32x32x16 (2 * 16384 flop) per (key, 32 queries)
-                               "executed_16bit": {"achieved": (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 1e12, "peak": 2500.0,
-                                                  "unit": "TFLOP/s", "frac": (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 2.5e15},
-                               "note": "achieved = algorithmic fp32 flops (4480 per pair, recompute not counted) against the fp32 "
-                                       "matrix (= vector) peak; the kernel runs them as split products on the 16-bit matrix pipe "
-                                       f"({CPB_BWD_MFMAS} fp16 / bf16 MFMAs + ~230 vector instructions per (key, 32 queries)), so frac can pass 1; "
-                                       f"executed_16bit prices the issued MFMAs against the dense 16-bit peak: the pipe is busy "
-                                       f"{100 * pipe:.0f} % of the kernel's time at 2.4 GHz, the rest is vector issue (on gfx950 "
-                                       "the two add up, DESIGN.md section 4)"}
+                               "issued_16bit": {"achieved": issued, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": issued / F16_MFMA_PEAK_TFLOPS},
+                               "note": "achieved = algorithmic flops (4480 per (query, key) pair and head, SURVEY 8(d), recompute not counted) / "
+                                       "HIP-event time of the kernel, against the dense 16-bit MFMA peak (the pipe its 12 MFMAs per (key, 32 "
+                                       "queries) issue on); issued_16bit prices the MFMAs actually executed.  The kernel is vector-issue "
+                                       "bound: ~230 VALU instructions per 12 MFMAs, two waves per SIMD."}
         if "deform_attn_fwd" in kt:
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
             ach = flop / (ms * 1e-3) / 1e12
             out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2, true>", "bound": "mfma", "achieved": ach,
-                                   "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                                   "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
                                    "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                                   "note": "priced against the fp32 peak although the position-bias layers run as split products on the "
-                                           "16-bit matrix pipe (one 32x32x16 MFMA does the work of eight fp32 ones), hence frac > 1 is "
-                                           "possible; 7 MFMAs + ~145 vector instructions per (key, 32 queries) incl. packing the ReLU bits for the backward, + the fp32 QK^T / PV MFMAs"}
+                                   "note": f"2496 algorithmic flop per pair (position-bias MLP 2240 + QK^T / PV 256) against the dense 16-bit "
+                                           f"MFMA peak; {CPB_FWD_MFMAS} 16-bit MFMAs + ~145 vector instructions per (key, 32 queries)"}
+        if world == 1 and not a.no_nystrom:
+            # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`)
+            out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096), nystrom_leg(pkg, dev, 4, 10000)]
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, in_dim)
+            out["cpu_baseline"] = cpu_baseline(pkg, in_dim, S)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

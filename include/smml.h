@@ -175,6 +175,17 @@ int smml_dwconv7_fwd_f32(const float* x, const float* wm, const float* bias, flo
 int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, float* db, int B, int H, int W, int C,
                                 void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Train-step glue: the gradient-modulation block of the reference's training loop,
+ * train_test.py:87-184 (task types diag2021 / grade / subtype), as one launch with no host synchronisation:
+ * per-branch logits feat_x W_x^T + b / 2, score_x = sum_b softmax(.)[label_b], ratio_t = score_t / score_i, and for
+ * every class row of classifier.weight.grad [C, 2 hs] whose tumor / immune halves have negative cosine similarity the
+ * projection + renormalisation of the weaker branch's half (:158-183), IN PLACE in weight_grad.
+ *   feat_t, feat_i [B, hs]   weight [C, 2 hs]   bias [C]   label [B] int64   weight_grad [C, 2 hs]
+ *   info (nullable) [4 + 2 C]: score_t, score_i, ratio_t, ratio_i, then (cosine similarity, branch taken 0 / 1 / 2) per row. */
+int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
+                           const long long* label, float* weight_grad, float* info, int B, int C, int hs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

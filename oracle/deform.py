@@ -31,6 +31,12 @@ def signed_log(d: torch.Tensor) -> torch.Tensor:
     return torch.sign(d) * torch.log(d.abs() + 1)
 
 
+# Tests set this to a dict to learn the NATURAL SCALE of d mlp.2.bias: that gradient is sum over all (query, key) pairs
+# of d bias, which is exactly 0 in exact arithmetic (softmax is shift invariant), so its size can only be judged against
+# sum |d bias| - collected here per bias tensor (key: id of the parameter tensor).
+GRAD_PROBE = None
+
+
 def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.") -> torch.Tensor:
     """The position-bias MLP  in -> 32 -> 32 -> heads//groups  (depth = 2).
 
@@ -38,7 +44,15 @@ def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.") -> torc
     ``pos`` is [..., in] and already signed-log transformed."""
     h = torch.relu(pos @ p[prefix + "mlp.0.0.weight"].t() + p[prefix + "mlp.0.0.bias"])
     h = torch.relu(h @ p[prefix + "mlp.1.0.weight"].t() + p[prefix + "mlp.1.0.bias"])
-    return h @ p[prefix + "mlp.2.weight"].t() + p[prefix + "mlp.2.bias"]
+    out = h @ p[prefix + "mlp.2.weight"].t() + p[prefix + "mlp.2.bias"]
+    if GRAD_PROBE is not None and out.requires_grad:
+        key = id(p[prefix + "mlp.2.bias"])
+        probe = GRAD_PROBE
+
+        def _hook(g, key=key, probe=probe):
+            probe[key] = probe.get(key, 0.0) + float(g.detach().abs().sum())
+        out.register_hook(_hook)
+    return out
 
 
 def out_len(s: int, ksize: int, r: int) -> int:

@@ -13,13 +13,15 @@ from .deform_attention import CPB, DeformCrossAttention1D, DeformCrossAttention2
 from .deform_cross_trans_mil import DeformCrossTransLayer, DeformCrossTransMIL, FusionNet, Pooler  # noqa: F401
 from .nystrom_attention import NystromAttention, PPEG, TransLayer, TransMIL, moore_penrose_iter_pinv  # noqa: F401
 from .coattention import MultiheadAttention  # noqa: F401
+from .cmta import CMTA, SNN_Block, Transformer_G, Transformer_P  # noqa: F401
 from .fusion import BilinearFusion, define_bifusion  # noqa: F401
 from .pathomic import DeformPathomicNet, MaxNet, define_net  # noqa: F401
 from .losses import BatchLoss, GatherLayer, OrthogonalLoss  # noqa: F401
 from .data_parallel import BagDataParallel  # noqa: F401
+from .train_step import PinnedBagStager, allreduce_scores_then_modulate, gradient_modulate  # noqa: F401
 
 __all__ = [
     "CPB", "Scale", "DeformCrossAttention1D", "DeformCrossAttention2D", "FusionNet", "DeformCrossTransLayer",
-    "DeformCrossTransMIL", "Pooler", "NystromAttention", "TransLayer", "PPEG", "TransMIL", "moore_penrose_iter_pinv", "MultiheadAttention", "BilinearFusion", "define_bifusion", "MaxNet", "DeformPathomicNet", "define_net", "BatchLoss", "GatherLayer",
-    "OrthogonalLoss", "BagDataParallel", "functional", "synth", "lib",
+    "DeformCrossTransMIL", "Pooler", "NystromAttention", "TransLayer", "PPEG", "TransMIL", "moore_penrose_iter_pinv", "MultiheadAttention", "CMTA", "Transformer_P", "Transformer_G", "SNN_Block", "BilinearFusion", "define_bifusion", "MaxNet", "DeformPathomicNet", "define_net", "BatchLoss", "GatherLayer",
+    "OrthogonalLoss", "BagDataParallel", "gradient_modulate", "PinnedBagStager", "functional", "synth", "lib",
 ]

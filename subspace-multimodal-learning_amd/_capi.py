@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsmml_hip.so")
+# SMML_LIB: measurement hook - load another build of the same C-ABI (tests/build_variants.py writes them to lib/variants/)
+LIB_PATH = os.environ.get("SMML_LIB") or os.path.join(_PKG, "lib", "libsmml_hip.so")
 
 _f = C.c_void_p          # device pointers travel as void*
 _i, _ll, _fl, _sz = C.c_int, C.c_longlong, C.c_float, C.c_size_t
@@ -49,6 +50,7 @@ SIGNATURES = {
     "smml_resconv_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_dwconv7_fwd_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_dwconv7_bwd_weight_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "smml_grad_modulate_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_event_create": (C.c_void_p, []),
     "smml_event_destroy": (_i, [_f]),
     "smml_event_record": (_i, [_f, _f]),
@@ -101,5 +103,6 @@ def fptr(t: Optional[torch.Tensor]):
     return ptr(t)
 
 
-def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """The current HIP stream of `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

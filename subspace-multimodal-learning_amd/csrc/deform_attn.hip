@@ -30,11 +30,12 @@
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
 #ifndef SMML_SPLIT_TERMS
-#define SMML_SPLIT_TERMS 3    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer: 3 = wh hh + wh hl + wm hh (what is
-                              // dropped is <= 2^-21 |w||h| per product, the size of the rounding an fp32 dot product of 32 terms
-                              // accumulates anyway); 5 adds wm hl + wl hh (<= 2^-23).  Measured against the fp64 oracle
-                              // (tests/diag_gpu.py) the two settings give the same errors to three digits on every tensor; 3 saves
-                              // 4 of 12 (forward) / 30 (backward) MFMAs per key
+#define SMML_SPLIT_TERMS 5    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer of the forward: 5 = all but wl hl
+                              // (<= 2^-23 |w||h| dropped); 3 = wh hh + wh hl + wm hh only (<= 2^-21).  The layer's VALUE does not care,
+                              // but its SIGN is the ReLU mask the backward consumes: with 3 terms the saved masks flip 4-5 x as often
+                              // as torch's fp32 evaluation flips its own, and the position-bias weight gradients came out 4-5 x
+                              // noisier than torch fp32 against an fp64 evaluation (tests/diag_gterms.py, profiles/r02_split_terms.txt:
+                              // dW1 1.1e-3 vs torch 2.0e-4; with 5 terms 2.07e-4).  Costs 4 MFMAs per key: +0.8 ms per 8-bag step.
 #endif
 #ifndef SMML_DELTA_FIX
 #define SMML_DELTA_FIX 0      // 1: re-centre the rows of d bias in the position-bias backward (d bias_k - P_k sum_k d bias_k).
@@ -170,6 +171,31 @@ __device__ __forceinline__ float drop_factor(const DropCfg& dc, unsigned long lo
   return (drop_hash(dc.seed, idx) >= dc.thresh) ? dc.keep_scale : 0.f;
 }
 
+// max over the 64 lanes (prologue use only)
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// Power-of-two lift of a constant MFMA operand that is split into fp16 terms: hi + mid (+ lo) only carries 22 (33) bits
+// while the residual terms stay NORMAL fp16 numbers (>= 2^-14); for weights of size 0.01 .. 0.1 the second term is already
+// subnormal (spacing 2^-24 absolute) and the split degrades to ~2^-20 relative.  Scaling the whole operand by 2^k so that its
+// largest element sits near `target` (a power of two; exact) keeps every kept term normal; the consumer undoes the scale.
+#ifndef SMML_LIFT_FWD
+#define SMML_LIFT_FWD 0       // lift of W2 in the forward's layer-2 product.  OFF: measured (profiles/r02_split_terms.txt) it makes the saved
+                              // ReLU masks flip MORE often against fp64 (dW1 1.06e-3 instead of 2.07e-4 with 5 terms) although every
+                              // term is more precise - not understood; the reference's init (N(0, 1/sqrt(32)) = 0.18) keeps the second
+                              // term of the unlifted split normal anyway
+#endif
+#ifndef SMML_LIFT_BWD
+#define SMML_LIFT_BWD 1       // lift of the chain-2 constants (W2 w3)^T in the backward: d vs 90 x closer to fp64 when every unit is active
+#endif
+__device__ __forceinline__ float pow2_lift(float amax, float target, float lo, float hi) {
+  if (!(amax > 0.f)) return 1.f;
+  const float k = floorf(log2f(target / amax));
+  return ldexpf(1.f, (int)fminf(fmaxf(k, lo), hi));      // an exact power of two (exp2f is the 1-ulp hardware approximation)
+}
+
 struct CpbParams {
   const float* w1;  // [32, PD]
   const float* b1;  // [32]
@@ -249,12 +275,23 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   }
   // W2 as the A operand of the fp16 form: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
   half8 w2h[2], w2m[2], w2l[2];
+  {
+    float amax = 0.f;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float wv[8];
+    for (int s = 0; s < 16; ++s) amax = fmaxf(amax, fabsf(cp.w2[c * CH + acc_row(s, hf)]));
+    // W2 2^k with the largest element in (2^12, 2^13]: hi / mid fp16 terms normal for elements down to 2^-16 of the largest, lo
+    // down to 2^-5 (below that its absolute error is 2^-37 of the largest element: irrelevant);
+    // the chain then delivers 2^k 2 (W2 h1 + b2): b2 rides in scaled, w3 carries 2^-k (powers of two: exact)
+    const float lift = SMML_LIFT_FWD ? pow2_lift(wave_max_all(amax), 8192.f, -8.f, 24.f) : 1.f, unlift = 1.f / lift;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
-    split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
+    for (int s = 0; s < 16; ++s) { b2acc[s] *= lift; w3v[s] *= unlift; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)] * lift;
+      split8_3(wv, w2h[kb], w2m[kb], w2l[kb]);
+    }
   }
   const float b3h = (hf == 0) ? cp.b3[oi] : 0.f;
 
@@ -843,21 +880,33 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   // 2 p and masked with 0x40002000 the word holds elements 2 p and 2 p + 1 as the fp16 pair {2^-7 or 0, 2.0 or 0} (single
   // bits 13 and 30): an MFMA operand without any conversion.  The constant operands carry the inverse scales per K slot
   // (128 for even slots, 0.5 for odd ones - powers of two, exact):
-  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out] * slot scale: A operand of chain 2
+  half8 w2th[2], w2tm[2], w2tl[2];     // W2[out = ch(8 kb + j)][in = c] * w3[out] * slot scale * lift: A operand of chain 2
   half8 idb[2];                        // scaled identity: mask (operand layout, lane = query) . I = mask^T as exact 0.0 / 1.0
+  float unlift2;                       // 2^-k of the chain-2 lift (pow2_lift): multiplies d bias where d h1 is consumed
+  {
+    float amax = 0.f;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float t[8];
+    for (int s = 0; s < 16; ++s) { const int ch = acc_row(s, hf); amax = fmaxf(amax, fabsf(cp.w2[ch * CH + c] * cp.w3[oi * CH + ch])); }
+    // largest |W2 w3| 2^k in (128, 256]: the even slots (x 128) top out at 2^15 < 65504, the odd ones (x 0.5) at 128 - both terms
+    // of the two-term split stay normal fp16 numbers (>= 2^-14) for elements down to 2^-10 of the largest
+    const float lift2 = SMML_LIFT_BWD ? pow2_lift(wave_max_all(amax), 256.f, -8.f, 24.f) : 1.f;
+    unlift2 = 1.f / lift2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = acc_row(8 * kb + j, hf);
-      const float sc = (j & 1) ? 0.5f : 128.f;
-      t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch] * sc;
-      idb[kb][j] = (ch == c) ? (_Float16)sc : (_Float16)0.0f;
+    for (int kb = 0; kb < 2; ++kb) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = acc_row(8 * kb + j, hf);
+        const float sc = (j & 1) ? 0.5f : 128.f;
+        t[j] = cp.w2[ch * CH + c] * cp.w3[oi * CH + ch] * sc * lift2;
+        idb[kb][j] = (ch == c) ? (_Float16)sc : (_Float16)0.0f;
+      }
+      split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
     }
-    split8_3(t, w2th[kb], w2tm[kb], w2tl[kb]);
   }
 
+  float big;                           // 2^100 in an SGPR (the clamp-multiply takes no literal)
+  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
   floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
   float2v aw1x[8], aw1y[8], ab1[8];    // channel pairs (registers 2 p, 2 p + 1)
 #pragma unroll
@@ -1013,14 +1062,15 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     // ---- layer-1 backward, d vs ----
     {
       float2v dp0v = {0.f, 0.f}, dp1v = {0.f, 0.f};
-      const float p0i = p0 * dbias, p1i = p1 * dbias;
+      const float dbl = dbias * unlift2;                    // d h1 arrives lifted by 2^k (chain-2 constants): undone here, once per key
+      const float p0i = p0 * dbl, p1i = p1 * dbl;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         float2v g1;
         g1[0] = on1[2 * p] ? dh[2 * p] : 0.f;
         g1[1] = on1[2 * p + 1] ? dh[2 * p + 1] : 0.f;
         const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);               // broadcast reads
-        ab1[p] = g1 * (float2v){dbias, dbias} + ab1[p];
+        ab1[p] = g1 * (float2v){dbl, dbl} + ab1[p];
         aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
         dp0v = g1 * (float2v){wx.x, wx.y} + dp0v;
         if (PD == 2) {
@@ -1029,9 +1079,12 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
           dp1v = g1 * (float2v){wy.x, wy.y} + dp1v;
         }
       }
+      // d/dx sign(x) log(|x| + 1) = 1 / (|x| + 1) - except that autograd's convention |x|' = 0, sign' = 0 at x == 0 makes the
+      // reference's gradient vanish where a query sits exactly on a sample position (DeformableAttention2D.py:148 through
+      // torch.sign / torch.abs).  Kept: [x != 0] as clamp(|x| 2^100), one fast-class multiply (subnormal distances aside).
       float2 v;
-      v.x = -(dp0v[0] + dp0v[1]) * dbias * srcp(fabsf(d0) + 1.f);
-      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbias * srcp(fabsf(d1) + 1.f) : 0.f;
+      v.x = -(dp0v[0] + dp0v[1]) * dbl * (srcp(fabsf(d0) + 1.f) * fminf(fmaxf(fabsf(d0) * big, 0.f), 1.f));
+      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbl * (srcp(fabsf(d1) + 1.f) * fminf(fmaxf(fabsf(d1) * big, 0.f), 1.f)) : 0.f;
       stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
     }
     if ((j & (CPB2_STG_KEYS - 1)) == CPB2_STG_KEYS - 1 || j == J - 1) {   // uniform: flush the staging tile

@@ -25,6 +25,8 @@ wo = rn(B, N, 512)
 if ALL_ACTIVE:
     t['b1'] = t['b1'].abs() + 4.0
     t['b2'] = t['b2'].abs() + 30.0
+if len(sys.argv) > 4 and sys.argv[4] == "small":      # keep the bias (and so the logits) O(1) although every unit is on
+    t['w3'] = t['w3'] * 0.03
 names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
 dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
 out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=0.0, dropout_seed=0)

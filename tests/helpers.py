@@ -1,5 +1,20 @@
-"""Shared helpers of the test-suite: golden-vector access and seeded inputs identical to the ones
-tests/golden/make_golden.py fed to the reference."""
+"""Shared helpers of the test-suite: golden-vector access, seeded inputs identical to the ones
+tests/golden/make_golden.py fed to the reference, and THE tolerance policy of the parity tests.
+
+Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exact)
+  * every comparison is relative to the tensor's own scale (max |ref|), and is recorded in REPORT - the table is printed at
+    the end of the pytest session and written to gpurun_out/parity_report.tsv (name, error, fp32 noise, ratio, bound);
+  * default bound: 1e-4;
+  * a tensor whose value the reference's OWN fp32 arithmetic does not determine to 1e-4 (measured: the fp32 reference /
+    oracle against an fp64 evaluation of the same quantity = its `noise`) gets max(1e-4, NOISE_FACTOR x noise) with
+    NOISE_FACTOR = 2, never more than NOISE_CAP - except where the reference's own noise already exceeds the cap / 2
+    (then 2 x noise, flagged `ill` in the report: the fixture itself cannot be reproduced closer by any fp32 program);
+  * where an fp64 truth is available the HIP result is ALSO held to the reference's own accuracy in the l2 norm:
+    l2(hip - fp64) <= max(1e-4, L2_FACTOR x l2(fp32 - fp64)) with L2_FACTOR = 1.5 - the kernels may not be noisier than
+    1.5 x torch's fp32 evaluation;
+  * a gradient that is exactly zero in exact arithmetic (d rel_pos_bias.mlp.2.bias: softmax shift invariance) must be
+    <= 1e-4 x its natural scale sum |d bias| (oracle.deform.GRAD_PROBE)."""
+import atexit
 import importlib
 import os
 
@@ -10,9 +25,77 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 smml = importlib.import_module("subspace-multimodal-learning_amd")
 synth = smml.synth
 
+TOL = 1e-4
+NOISE_FACTOR = 2.0
+NOISE_CAP = 1e-3
+L2_FACTOR = 1.5
+
+REPORT = []      # (test id, tensor, err, noise, bound, kind)
+
+
+def _current_test():
+    return os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::")[-1]
+
+
+def record(name, err, noise, bound, kind):
+    REPORT.append((_current_test(), name, float(err), (float(noise) if noise is not None else float("nan")), float(bound), kind))
+
+
+def bound_for(noise, floor=TOL):
+    """max-norm bound for a tensor whose fp32 reference sits `noise` away from fp64."""
+    if noise is None:
+        return floor
+    b = max(floor, NOISE_FACTOR * noise)
+    return b if noise > NOISE_CAP / NOISE_FACTOR else min(b, NOISE_CAP)
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def l2_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def assert_close(name, got, ref, tol=TOL):
+    e = rel_err(got, ref)
+    record(name, e, None, tol, "max")
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
+
+
+def assert_calibrated(name, got, ref32, ref64, floor=TOL):
+    """HIP result against the fp64 oracle: max-norm within max(floor, 2 x noise) (capped, see module docstring) and l2-norm
+    within max(floor, 1.5 x the fp32 oracle's own l2 distance to fp64)."""
+    if float(ref64.detach().abs().max()) < 1e-12:        # identically zero in exact arithmetic (e.g. one sampled key: d scores = 0)
+        gm = float(got.detach().abs().max())
+        record(name, gm, None, 1e-3, "zero")
+        assert gm < 1e-3, f"{name}: expected ~0 (rounding of cancelling terms), got {gm:.3e}"
+        return
+    noise = rel_err(ref32, ref64)
+    tol = bound_for(noise, floor)
+    e = rel_err(got, ref64)
+    record(name, e, noise, tol, "max" if noise <= NOISE_CAP / NOISE_FACTOR else "max,ill")
+    assert e <= tol, f"{name}: rel err vs fp64 oracle {e:.3e} > {tol:.3e} (fp32 oracle's own: {noise:.3e})"
+    n2 = l2_err(ref32, ref64)
+    tol2 = max(floor, L2_FACTOR * n2)
+    e2 = l2_err(got, ref64)
+    record(name, e2, n2, tol2, "l2")
+    assert e2 <= tol2, f"{name}: l2 err vs fp64 oracle {e2:.3e} > {tol2:.3e} = max({floor}, {L2_FACTOR} x fp32 oracle's own {n2:.3e})"
+
+
+def assert_zero_grad(name, got, natural_scale, frac=TOL):
+    """A gradient that vanishes in exact arithmetic: |got| <= frac x natural scale (the sum of the absolute summands)."""
+    g = float(got.detach().abs().max()) if got is not None else 0.0
+    bound = frac * float(natural_scale)
+    record(name, g / max(float(natural_scale), 1e-300), None, frac, "zero/natural")
+    assert g <= bound, f"{name}: |grad| {g:.3e} > {frac} x natural scale {natural_scale:.3e}"
+
 
 class Golden:
     def __init__(self, name):
+        self.name = name
         self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
 
     def keys(self, prefix=""):
@@ -24,27 +107,38 @@ class Golden:
     def array(self, key):
         return self.z[key]
 
-    def check(self, key, t: torch.Tensor, rtol=1e-4, atol_frac=1e-5, what=""):
-        """Compare tensor `t` with the stored strided subset + checksums of golden entry `key`.
-        Tolerance: |a - b| <= rtol * max|ref| elementwise on the subset (relative to the tensor's scale,
-        the north_star's 'fp32 within 1e-4 relative'), and the l2 norm within rtol.  Where the fixture carries
-        `noise` (distance between the fp32 and an fp64 evaluation of the same quantity) the tolerance is
-        max(rtol, 8 x noise): a gradient that fp32 arithmetic itself only determines to 3e-4 cannot be
-        required to 1e-4."""
-        if key + "/noise" in self.z.files:      # fp32-noise calibrated tolerance for ill-conditioned tensors
-            rtol = max(rtol, 8.0 * float(self.z[key + "/noise"]))
+    def has(self, key):
+        return key in self.z.files
+
+    def check(self, key, t: torch.Tensor, rtol=TOL, atol_frac=1e-5, what=""):
+        """Compare tensor `t` with the stored strided subset + checksums of golden entry `key` (the REFERENCE's fp32 output).
+        |a - b| <= bound x max|ref| elementwise on the subset and the l2 norm within the bound; bound per the module
+        docstring.  Where the fixture also carries the fp64 evaluation (`sub64`, stored for ill-conditioned tensors) the l2
+        distance to fp64 on the subset must be <= max(1e-4, 1.5 x the reference's own)."""
+        name = f"{self.name}:{what or key}"
+        noise = float(self.z[key + "/noise"]) if key + "/noise" in self.z.files else None
+        bound = bound_for(noise, rtol)
         sub = torch.from_numpy(self.z[key + "/sub"]).double()
         step = int(self.z[key + "/step"])
         shape = tuple(int(s) for s in self.z[key + "/shape"])
-        assert tuple(t.shape) == shape, f"{what or key}: shape {tuple(t.shape)} != golden {shape}"
+        assert tuple(t.shape) == shape, f"{name}: shape {tuple(t.shape)} != golden {shape}"
         f = t.detach().double().cpu().flatten()
         mine = f[::step]
         scale = max(float(sub.abs().max()), 1e-30)
         err = float((mine - sub).abs().max()) / scale
-        assert err <= rtol, f"{what or key}: max err relative to tensor scale {err:.3e} > {rtol}"
+        ill = noise is not None and noise > NOISE_CAP / NOISE_FACTOR
+        record(name, err, noise, bound, "max vs ref32" + (",ill" if ill else ""))
+        assert err <= bound, f"{name}: max err relative to tensor scale {err:.3e} > {bound:.3e} (reference's fp32 noise {noise})"
         l2 = float(self.z[key + "/l2"])
         l2m = float(f.pow(2).sum().sqrt())
-        assert abs(l2m - l2) <= rtol * max(l2, 1e-30) + atol_frac * scale, f"{what or key}: l2 {l2m} vs {l2}"
+        assert abs(l2m - l2) <= bound * max(l2, 1e-30) + atol_frac * scale, f"{name}: l2 {l2m} vs {l2}"
+        if key + "/sub64" in self.z.files:
+            s64 = torch.from_numpy(self.z[key + "/sub64"]).double()
+            n2 = float((sub - s64).norm() / s64.norm().clamp_min(1e-300))
+            e2 = float((mine - s64).norm() / s64.norm().clamp_min(1e-300))
+            tol2 = max(rtol, L2_FACTOR * n2)
+            record(name, e2, n2, tol2, "l2 vs fp64")
+            assert e2 <= tol2, f"{name}: l2 err vs fp64 {e2:.3e} > {tol2:.3e} = max({rtol}, {L2_FACTOR} x reference's own {n2:.3e})"
         return err
 
 
@@ -54,6 +148,27 @@ def params_for(module: torch.nn.Module, seed: int, tag: str):
     return synth.fill_params(shapes, seed=seed, tag=tag)
 
 
-def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+def format_report(rows=None, only_above=0.0):
+    rows = REPORT if rows is None else rows
+    out = ["test\ttensor\tkind\terr\tfp32_noise\terr/noise\tbound"]
+    for test, name, err, noise, bound, kind in rows:
+        if err < only_above:
+            continue
+        ratio = err / noise if noise == noise and noise > 0 else float("nan")
+        out.append(f"{test}\t{name}\t{kind}\t{err:.3e}\t{noise:.3e}\t{ratio:.2f}\t{bound:.3e}")
+    return "\n".join(out)
+
+
+def _dump_report():
+    if not REPORT:
+        return
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_report.tsv"), "w") as f:
+            f.write(format_report() + "\n")
+    except OSError:
+        pass
+
+
+atexit.register(_dump_report)

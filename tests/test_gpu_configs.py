@@ -1,0 +1,123 @@
+"""GPU parity at the sizes BASELINE.json's configs name (cfg 2, 4, 5; cfg 1 is the CPU plumbing case and cfg 3's shapes are
+test_mil_branch_larger_grid_vs_oracle + test_coattention[coattn_L200_S4096]).  The reference itself cannot run these sizes
+(N is hard-wired to 2500, DeformCrossTransMIL.py:104); the oracle - pinned to the reference at N = 2500 by the golden
+vectors - is the checker, run in fp32 and fp64 on the host for the calibrated tolerance of tests/helpers.py."""
+import math
+
+import pytest
+import torch
+
+import helpers
+from helpers import assert_calibrated, assert_close, params_for, rel_err, smml, synth
+from oracle.losses import batch_loss, orthogonal_loss
+from oracle.mil import deform_pathomic_net
+from oracle.nystrom import nystrom_attention
+from test_gpu_parity import _compare_param_grads, _load, cpb_probe
+from test_oracle_golden import pathomic_args
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+
+
+def _nystrom_vs_oracle(cuda, tag, B, n, in_dtype=torch.float32, seed=21):
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True, dropout=0.1)
+    params = params_for(mod, seed, tag)
+    mod = _load(mod, params, cuda)
+    x = (synth.normal((B, n, 512), seed, tag + ":x") * 0.5).to(in_dtype).float()     # values representable in the bag's dtype
+    wo = synth.normal((B, n, 512), seed, tag + ":wo")
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        xr = x.clone().to(dt).requires_grad_()
+        o = nystrom_attention(xr, pr, heads=8, dim_head=64, num_landmarks=256)
+        (o * wo.to(dt)).sum().backward()
+        run[dt] = (o.detach(), xr.grad, pr)
+    xd = x.to(cuda).to(in_dtype).requires_grad_()
+    out = mod(xd)
+    (out.float() * wo.to(cuda)).sum().backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    assert_calibrated(tag + " out", out, r32[0], r64[0])
+    if in_dtype == torch.float32:
+        assert_calibrated(tag + " dx", xd.grad, r32[1], r64[1])
+    else:   # the gradient is returned in the bag's dtype: one rounding to 8 / 11 bits on top of the fp32 result
+        assert xd.grad.dtype == in_dtype
+        eps = 2.0 ** -8 if in_dtype == torch.bfloat16 else 2.0 ** -11
+        assert_close(tag + " dx (16-bit)", xd.grad.float(), r64[1], 1e-4 + eps)
+    for k, p in mod.named_parameters():
+        assert_calibrated(tag + " d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
+
+
+@pytest.mark.parametrize("B,in_dtype", [(1, torch.float32), (2, torch.bfloat16)])
+def test_cfg2_nystrom_4096x512_m256(cuda, B, in_dtype):
+    """BASELINE config 2: NystromAttention fwd + bwd, bag 4096 x 512, 256 landmarks (l = 16, no padding), fp32 bag and bf16 bag
+    (two bags: the batch-global max of the pseudo-inverse initialisation couples them, NystromAttention.py:26)."""
+    _nystrom_vs_oracle(cuda, f"cfg2:{B}:{in_dtype}", B, 4096, in_dtype)
+
+
+def test_cfg5_nystrom_long_bag_50000(cuda):
+    """BASELINE config 5: one bag of 50 000 x 512 instances, 256 landmarks (front padding to 50 176, l = 196), fp16 bag.
+    Oracle comparison at the full length (fp32 + fp64 on the host) and size-independent properties: identical bags give
+    identical outputs, the front padding is a crop (zeros prepended by the caller give the same rows), linearity in v."""
+    n = 50000
+    _nystrom_vs_oracle(cuda, "cfg5", 1, n, torch.float16, seed=23)
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(cuda).eval()
+    torch.manual_seed(5)
+    x1 = torch.randn(1, n, 512, device=cuda) * 0.5
+    with torch.no_grad():
+        out2 = mod(torch.cat((x1, x1), 0))
+        assert out2.shape == (2, n, 512) and torch.isfinite(out2).all()
+        assert torch.equal(out2[0], out2[1])
+        out1 = mod(x1)
+        pad = (256 - n % 256) % 256
+        outp = mod(torch.cat((torch.zeros(1, pad, 512, device=cuda), x1), 1))
+        assert_close("front pad = crop", outp[:, -n:], out1, 1e-5)
+        # linearity in v: scale the v block of to_qkv by alpha -> (out - bias) scales by alpha
+        b = mod.to_out[0].bias
+        w = mod.to_qkv.weight.data
+        w[2 * 512:] *= 3.0
+        out3 = mod(x1)
+        w[2 * 512:] /= 3.0
+        assert_close("linear in v", out3 - b, 3.0 * (out1 - b), 2e-5)
+
+
+@pytest.mark.parametrize("B,S", [(2, 24), (1, 100)])
+def test_cfg4_full_fusion_10000x512(cuda, B, S):
+    """BASELINE config 4 (per-rank slice): full two-branch DeformPathomicNet on bags of 10 000 x 512 (100 x 100 grid, 625
+    sampled keys) + cross-entropy + both BatchLosses + an OrthogonalLoss term on the two branch vectors, forward and every
+    parameter gradient against the oracle (fp32 + fp64 host runs: ~3 minutes of host time for ONE bag, which is why the
+    full-size case runs B = 1 - a 1 x 1 BatchLoss is identically zero - and the two-bag case, where the BatchLosses
+    contribute, runs on a 24 x 24 grid).  The data-parallel side of config 4 is tests/test_gpu_data_parallel.py (2 ranks)
+    and tests/test_data_parallel_gloo.py."""
+    args = pathomic_args(input_path_dim=512, batch_size=B)
+    net = smml.DeformPathomicNet(args)
+    params = params_for(net, 17, "cfg4")
+    net = _load(net, params, cuda)
+    x_path = synth.bag(B, S * S, 512, 17, "cfg4:bag")
+    x_t = synth.normal((B, 59), 17, "cfg4:tumor"); x_i = synth.normal((B, 361), 17, "cfg4:immune")
+    label = torch.tensor([2, 0])[:B]
+
+    def total(feats, vt, vi, lg, bl, ol):
+        l_t, l_i = bl(lg[3], lg[4]), bl(lg[5], lg[6])
+        return (torch.nn.functional.cross_entropy(lg[2], label.to(lg[2].device)) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
+                + 0.1 * ol(vt, vi, vi, vt).sum()), l_t, l_i
+
+    run = {}
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            p = {k: (v.clone().to(dt).requires_grad_() if v.dtype.is_floating_point else v) for k, v in params.items()}
+            feats, vt, vi, lg = deform_pathomic_net(x_path.to(dt), x_t.to(dt), x_i.to(dt), p, grid_hw=(S, S), q_chunk=1024)
+            loss, l_t, l_i = total(feats, vt, vi, lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
+            loss.backward()
+            run[dt] = (feats.detach(), lg[2].detach(), lg[4].detach(), lg[6].detach(), l_t.detach(), l_i.detach(), loss.detach(), p)
+    feats, vt, vi, lg, _, _, _ = net(x_path=x_path.to(cuda), x_omic=None, x_omic_tumor=x_t.to(cuda), x_omic_immune=x_i.to(cuda))
+    bl, ol = smml.BatchLoss(B, 1), smml.OrthogonalLoss()
+    loss, l_t, l_i = total(feats, vt, vi, lg, bl, ol)
+    loss.backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    for name, got, i in (("features", feats, 0), ("haz", lg[2], 1), ("vgrid_t", lg[4], 2), ("vgrid_i", lg[6], 3),
+                         ("batchloss_t", l_t, 4), ("batchloss_i", l_i, 5), ("loss", loss, 6)):
+        assert_calibrated("cfg4 " + name, got, r32[i], r64[i])
+    assert lg[4].shape == (B * 8, 2, S // 4, S // 4)
+    with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
+    assert with_grad == {k for k, v in r64[7].items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
+    _compare_param_grads(net, r32[7], r64[7], skip=("cls_token",), probe=probe)

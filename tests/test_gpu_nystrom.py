@@ -184,3 +184,39 @@ def test_bf16_and_fp16_bags_are_accepted(cuda):
         ref.pow(2).mean().backward()
         assert out.dtype == torch.float32 and torch.equal(out, ref)
         assert x16.grad.dtype == dt and torch.allclose(x16.grad.float(), xr.grad, rtol=1e-2, atol=1e-6)
+
+
+def test_cmta_golden(cuda):
+    """The reference's default model (mode cmta): Transformer_P / Transformer_G encoders + decoders on the Nystrom kernels,
+    P_in_G / G_in_P co-attention, concat fusion - outputs and all 104 parameter gradients against the reference's own."""
+    from test_oracle_golden import CMTA_OUTPUTS, cmta_inputs, cmta_params
+    g = Golden("cmta_n150")
+    net = smml.CMTA(argparse.Namespace(label_dim=4))
+    net = _load(net, cmta_params(net), cuda)
+    x_path, x_omic, w = cmta_inputs()
+    xp, xo = x_path.to(cuda).requires_grad_(), x_omic.to(cuda).requires_grad_()
+    out = net(x_path=xp, x_omic=xo)
+    loss = (out[0] * w[0].to(cuda)).sum() + sum((out[2 + i] * w[i].to(cuda)).sum() for i in range(1, 5))
+    loss.backward()
+    for nm, o in zip(CMTA_OUTPUTS, out):
+        g.check(nm, o)
+    g.check("dx_path", xp.grad); g.check("dx_omic", xo.grad)
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
+    assert with_grad == {k[5:] for k in g.keys("grad:")}
+    for k, p in net.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
+def test_cmta_reference_bag_size_train_mode(cuda):
+    """CMTA on the reference's bag size (8 bags of 2500 x 1024, config_mine.yaml:2,38) in train() mode (Dropout 0.25 on the
+    wsi features, AlphaDropout in the SNN blocks, Nystrom output dropout 0.1): runs, finite, every parameter gets a gradient."""
+    torch.manual_seed(0)
+    net = smml.CMTA(argparse.Namespace(label_dim=4)).to(cuda).train()
+    xp = synth.bag(8, 2500, 1024, 3, "cmta:big").to(cuda); xo = synth.normal((8, 431), 3, "cmta:bigo").to(cuda)
+    out = net(x_path=xp, x_omic=xo)
+    assert out[0].shape == (8, 4) and out[3].shape == (8, 256)
+    l1 = torch.nn.functional.l1_loss(out[3], out[4].detach()) + torch.nn.functional.l1_loss(out[5], out[6].detach())   # train_test.py:371-373
+    (torch.nn.functional.cross_entropy(out[0], torch.randint(0, 4, (8,), device=cuda)) + l1).backward()
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k

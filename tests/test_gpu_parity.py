@@ -7,7 +7,9 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, params_for, rel_err, smml, synth
+import helpers
+import oracle.deform as odeform
+from helpers import Golden, assert_calibrated, assert_close, assert_zero_grad, l2_err, params_for, rel_err, smml, synth
 from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
 from oracle.losses import batch_loss
 from oracle.mil import deform_cross_trans_mil, deform_pathomic_net
@@ -24,32 +26,52 @@ def _load(mod, params, dev):
 
 
 def _assert_close(name, got, ref, tol=TOL):
-    e = rel_err(got, ref)
-    assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
+    assert_close(name, got, ref, tol)
 
 
 def _calibrated(name, got, ref32, ref64, floor=TOL):
-    """HIP result vs the fp64 oracle; tolerance = max(1e-4, 8 x the fp32 oracle's own distance to fp64):
-    gradients of the position-bias MLP are ReLU-gated sums over 1e6+ pairs with cancellation, which fp32
-    arithmetic itself only determines to a few 1e-4 of their scale (see tests/diag_gpu.py)."""
-    if float(ref64.detach().abs().max()) < 1e-12:        # identically zero in exact arithmetic (e.g. one sampled key: d scores = 0)
-        gm = float(got.detach().abs().max())
-        assert gm < 1e-3, f"{name}: expected ~0 (rounding of cancelling terms), got {gm:.3e}"
-        return
-    tol = max(floor, 8.0 * rel_err(ref32, ref64))
-    e = rel_err(got, ref64)
-    assert e <= tol, f"{name}: rel err vs fp64 oracle {e:.3e} > {tol:.3e}"
+    """HIP result vs the fp64 oracle under the policy of tests/helpers.py: max-norm within max(1e-4, 2 x the fp32 oracle's own
+    distance to fp64) (capped at 1e-3 unless the oracle itself is further off), l2-norm within max(1e-4, 1.5 x the fp32
+    oracle's own l2 distance)."""
+    assert_calibrated(name, got, ref32, ref64, floor)
 
 
-def _compare_param_grads(mod, p32, p64, skip=ZERO_GRADS):
+class cpb_probe:
+    """with cpb_probe() as pr: ... oracle backward ...; pr.scale(bias_param) = sum |d bias| over all (query, key) pairs."""
+
+    def __enter__(self):
+        self.d = {}
+        odeform.GRAD_PROBE = self.d
+        return self
+
+    def __exit__(self, *a):
+        odeform.GRAD_PROBE = None
+
+    def scale(self, tensor):
+        return self.d.get(id(tensor), 0.0)
+
+
+def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
+    """Every parameter gradient against the oracle (all tensors are compared and recorded before the first failure is
+    raised).  `rel_pos_bias.mlp.2.bias` is exactly zero in exact arithmetic (softmax shift invariance): it must stay below
+    1e-4 x its natural scale sum |d bias| (collected by `probe` from the fp64 run)."""
+    failures = []
     for k, p in mod.named_parameters():
         if k.endswith(skip):
             continue
-        if p32[k].grad is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-            continue
-        assert p.grad is not None, f"missing grad for {k}"
-        _calibrated("d" + k, p.grad, p32[k].grad, p64[k].grad)
+        try:
+            if k.endswith(ZERO_GRADS):
+                if probe is not None and p64[k].grad is not None:
+                    assert_zero_grad("d" + k, p.grad, probe.scale(p64[k]))
+                continue
+            if p32[k].grad is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            assert p.grad is not None, f"missing grad for {k}"
+            _calibrated("d" + k, p.grad, p32[k].grad, p64[k].grad)
+        except AssertionError as e:
+            failures.append(str(e).split("\n")[0])
+    assert not failures, f"{len(failures)} parameter gradients out of tolerance:\n  " + "\n  ".join(failures)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -191,13 +213,14 @@ def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     w_out = synth.normal((B, C, N), 7, tag + ":wo")
     # oracle, fp32 (the reference's arithmetic) and fp64 (truth for the tolerance calibration)
     run = {}
-    for dt in (torch.float32, torch.float64):
-        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
-        a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
-        o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww))
-        w_vg = synth.normal(tuple(vg_ref.shape), 7, tag + ":wvg")
-        ((o_ref * w_out.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
-        run[dt] = (o_ref, vg_ref, a.grad, b.grad, pref)
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+            o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww))
+            w_vg = synth.normal(tuple(vg_ref.shape), 7, tag + ":wvg")
+            ((o_ref * w_out.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
+            run[dt] = (o_ref, vg_ref, a.grad, b.grad, pref)
     r32, r64 = run[torch.float32], run[torch.float64]
     # HIP
     ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
@@ -205,7 +228,7 @@ def test_deform2d_vs_oracle(cuda, B, Hh, Ww):
     ((o * w_out.to(cuda)).sum() + (vg * w_vg.to(cuda)).sum()).backward()
     for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
         _calibrated(name, got, r32[i], r64[i])
-    _compare_param_grads(mod, r32[4], r64[4])
+    _compare_param_grads(mod, r32[4], r64[4], probe=probe)
     # integer path: corners of the kernel's own sample positions, bit-exact against the oracle's formula
     th, tw = vg.shape[-2:]
     vgc = vg.detach().cpu()
@@ -240,16 +263,17 @@ def test_deform2d_train_mode_dropout(cuda):
     frac = float(keep.mean())
     assert 0.88 < frac < 0.92, f"keep fraction {frac}"
     run = {}
-    for dt in (torch.float32, torch.float64):
-        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
-        a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
-        o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), attn_keep=keep, dropout_p=0.1)
-        (o_ref * w_out.to(dt)).sum().backward()
-        run[dt] = (o_ref, a.grad, b.grad, pref)
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+            o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), attn_keep=keep, dropout_p=0.1)
+            (o_ref * w_out.to(dt)).sum().backward()
+            run[dt] = (o_ref, a.grad, b.grad, pref)
     r32, r64 = run[torch.float32], run[torch.float64]
     for name, got, i in (("out", o, 0), ("dx1", ad.grad, 1), ("dx2", bd.grad, 2)):
         _calibrated(name, got, r32[i], r64[i])
-    _compare_param_grads(mod, r32[3], r64[3])
+    _compare_param_grads(mod, r32[3], r64[3], probe=probe)
     # a second forward draws a new seed (different mask), eval() switches dropout off
     o2 = mod(ad.detach(), bd.detach())
     assert not torch.equal(o2, o.detach())
@@ -275,7 +299,9 @@ def test_deform2d_golden_reference_grid(cuda):
     g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
     assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
     for k, p in mod.named_parameters():
-        if not k.endswith(ZERO_GRADS):
+        if k.endswith(ZERO_GRADS):
+            assert_zero_grad(f"{g.name}:d{k}", p.grad, g.scalar("natural:" + k))
+        else:
             g.check("grad:" + k, p.grad, what="d" + k)
     # integer path on the REFERENCE's vgrid: bit-exact corners / masks
     vgf = torch.from_numpy(g.array("vgrid_full"))
@@ -300,20 +326,21 @@ def test_deform1d_vs_oracle_lengths(cuda, B, n):
     x1 = synth.normal((B, C, n), 9, tag + ":x1"); x2 = synth.normal((B, C, n), 9, tag + ":x2")
     wo = synth.normal((B, C, n), 9, tag + ":wo")
     run = {}
-    for dt in (torch.float32, torch.float64):
-        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
-        a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
-        o_ref, vg_ref = deform_cross_attention_1d(a, b, pref, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
-        w_vg = synth.normal(tuple(vg_ref.shape), 9, tag + ":wvg")
-        ((o_ref * wo.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
-        run[dt] = (o_ref, vg_ref, a.grad, b.grad, pref)
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+            o_ref, vg_ref = deform_cross_attention_1d(a, b, pref, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+            w_vg = synth.normal(tuple(vg_ref.shape), 9, tag + ":wvg")
+            ((o_ref * wo.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
+            run[dt] = (o_ref, vg_ref, a.grad, b.grad, pref)
     r32, r64 = run[torch.float32], run[torch.float64]
     ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
     o, vg = mod(ad, bd, return_vgrid=True)
     ((o * wo.to(cuda)).sum() + (vg * w_vg.to(cuda)).sum()).backward()
     for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
         _calibrated(name, got, r32[i], r64[i])
-    _compare_param_grads(mod, r32[4], r64[4])
+    _compare_param_grads(mod, r32[4], r64[4], probe=probe)
 
 
 @pytest.mark.parametrize("tag,B,n", [("deform1d_n37", 2, 37), ("deform1d_n40", 2, 40), ("deform1d_n2501", 1, 2501)])
@@ -330,7 +357,9 @@ def test_deform1d_golden(cuda, tag, B, n):
     ((out * w_out).sum() + (vgrid * w_vg).sum()).backward()
     g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
     for k, p in mod.named_parameters():
-        if not k.endswith(ZERO_GRADS):
+        if k.endswith(ZERO_GRADS):
+            assert_zero_grad(f"{g.name}:d{k}", p.grad, g.scalar("natural:" + k))
+        else:
             g.check("grad:" + k, p.grad, what="d" + k)
 
 
@@ -382,7 +411,9 @@ def test_full_model_golden_reference_grid(cuda):
     with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
     assert with_grad == {k[5:] for k in g.keys("grad:")}, "set of parameters receiving a gradient differs"
     for k, p in net.named_parameters():
-        if p.grad is not None and not k.endswith(ZERO_GRADS):
+        if p.grad is not None and k.endswith(ZERO_GRADS):
+            assert_zero_grad(f"{g.name}:d{k}", p.grad, g.scalar("natural:" + k))
+        elif p.grad is not None:
             g.check("grad:" + k, p.grad, what="d" + k)
 
 
@@ -395,43 +426,19 @@ def test_mil_branch_larger_grid_vs_oracle(cuda):
     B, S = 1, 64
     path = synth.bag(B, S * S, 512, 3, "mil64:bag"); omic = torch.relu(synth.normal((B, 128), 3, "mil64:omic"))
     run = {}
-    for dt in (torch.float32, torch.float64):
-        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
-        enc_r, log_r, _, vg_r = deform_cross_trans_mil(path.to(dt), omic.to(dt), pref, grid_hw=(S, S))
-        (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
-        run[dt] = (enc_r, log_r, vg_r, pref)
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            enc_r, log_r, _, vg_r = deform_cross_trans_mil(path.to(dt), omic.to(dt), pref, grid_hw=(S, S))
+            (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
+            run[dt] = (enc_r, log_r, vg_r, pref)
     r32, r64 = run[torch.float32], run[torch.float64]
     enc, logits, _, omic_t, vg = mil(path.to(cuda), omic.to(cuda))
     (enc.sum() + (logits * logits).sum() + vg.pow(2).sum() * 1e-3).backward()
     for name, got, i in (("encoded", enc, 0), ("logits", logits, 1), ("vgrid", vg, 2)):
         _calibrated(name, got, r32[i], r64[i])
     assert omic_t.shape == (B, S * S, 128) and torch.equal(omic_t[0, 17].cpu(), omic[0])
-    _compare_param_grads(mil, r32[3], r64[3], skip=ZERO_GRADS + ("cls_token",))
-
-
-def test_mil_branch_full_size_vs_oracle(cuda):
-    """BASELINE's headline shape itself: one DeformCrossTransMIL branch on the 100 x 100 grid (N = 10 000, 625 sampled keys,
-    512-wide bag features), outputs and every parameter gradient against the CPU oracle (fp32 run, tolerances calibrated
-    by an fp64 run of the same oracle: about a minute of host time)."""
-    args = pathomic_args(input_path_dim=512, return_vgrid=True)
-    mil = smml.DeformCrossTransMIL(args)
-    params = params_for(mil, 5, "mil100")
-    mil = _load(mil, params, cuda)
-    B, S = 1, 100
-    path = synth.bag(B, S * S, 512, 5, "mil100:bag"); omic = torch.relu(synth.normal((B, 128), 5, "mil100:omic"))
-    run = {}
-    for dt in (torch.float32, torch.float64):
-        pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
-        enc_r, log_r, _, vg_r = deform_cross_trans_mil(path.to(dt), omic.to(dt), pref, grid_hw=(S, S))
-        (enc_r.sum() + (log_r * log_r).sum() + vg_r.pow(2).sum() * 1e-3).backward()
-        run[dt] = (enc_r, log_r, vg_r, pref)
-    r32, r64 = run[torch.float32], run[torch.float64]
-    enc, logits, _, omic_t, vg = mil(path.to(cuda), omic.to(cuda))
-    (enc.sum() + (logits * logits).sum() + vg.pow(2).sum() * 1e-3).backward()
-    assert vg.shape == (B * 8, 2, 25, 25)
-    for name, got, i in (("encoded", enc, 0), ("logits", logits, 1), ("vgrid", vg, 2)):
-        _calibrated(name, got, r32[i], r64[i])
-    _compare_param_grads(mil, r32[3], r64[3], skip=ZERO_GRADS + ("cls_token",))
+    _compare_param_grads(mil, r32[3], r64[3], skip=("cls_token",), probe=probe)
 
 
 def test_size_independent_properties_full_size(cuda):
@@ -536,9 +543,12 @@ def test_fused_core_random_shapes(cuda):
                 # (fp64) pre-activation of some (query, key, unit) lies within fp32 rounding of zero, no fp32 evaluation can
                 # determine that unit's mask - a flip moves single elements by 1e-4 ... 1e-2 of the tensor's scale in these
                 # small problems - so such a case only gets a sanity bound
-                l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
-                tol = max(TOL, 8.0 * l2(g32, g64)) if margin > 2e-6 else 5e-2
-                assert l2(g, g64) <= tol, f"{tag} d{n}: l2 err {l2(g, g64):.3e} > {tol:.3e} (margin {margin:.1e})"
+                # (with a handful of borderline units per case the 1.5 x l2 rule of the large tests is not a meaningful
+                # statistic here: 2 x the fp32 evaluation's own distance, floor 1e-4)
+                n32, e = l2_err(g32, g64), l2_err(g, g64)
+                tol = max(TOL, helpers.NOISE_FACTOR * n32) if margin > 2e-6 else 5e-2
+                helpers.record(tag + " d" + n, e, n32, tol, "l2" if margin > 2e-6 else "l2,undecidable-mask")
+                assert e <= tol, f"{tag} d{n}: l2 err {e:.3e} > {tol:.3e} (margin {margin:.1e})"
 
 
 def test_saved_relu_masks_match_reference(cuda):

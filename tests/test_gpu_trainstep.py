@@ -1,0 +1,94 @@
+"""GPU: train-step glue - the gradient-modulation kernel against the reference's own block
+(golden) and the oracle, and the pinned double-buffered bag stager."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, smml
+from oracle.trainstep import gradient_modulate as oracle_modulate
+from test_oracle_golden import gradmod_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _classifier(W, b, G, dev):
+    cls = torch.nn.Linear(W.shape[1], W.shape[0]).to(dev)
+    cls.weight.data.copy_(W); cls.bias.data.copy_(b); cls.weight.grad = G.clone().to(dev)
+    return cls
+
+
+def test_gradient_modulate_golden(cuda):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gradmod_b8.npz"))
+    for seed in range(1, 9):
+        ft, fi, W, b, label, G = gradmod_case(seed)
+        cls = _classifier(W, b, G, cuda)
+        info = smml.gradient_modulate(cls, ft.to(cuda), fi.to(cuda), label.to(cuda), return_info=True).cpu()
+        ref = torch.from_numpy(z[f"case{seed}/grad"])
+        assert_close(f"gradmod case {seed}", cls.weight.grad, ref, 1e-5)
+        assert abs(float(info[2]) - float(z[f"case{seed}/ratio_t"])) <= 1e-5 * float(info[2])
+        assert [bool(x) for x in info[5::2].tolist()] == list(z[f"case{seed}/changed_rows"])
+        # rows the reference left alone are untouched bit for bit
+        keep = ~torch.from_numpy(z[f"case{seed}/changed_rows"])
+        assert torch.equal(cls.weight.grad.cpu()[keep], G[keep])
+
+
+@pytest.mark.parametrize("B,C,hs", [(1, 3, 128), (5, 4, 64), (64, 4, 128), (8, 3, 200)])
+def test_gradient_modulate_shapes_vs_oracle(cuda, B, C, hs):
+    """Other batch sizes / class counts (grade and subtype have 3 classes) / widths, incl. a zero gradient row (cosine NaN ->
+    no edit, as in the reference)."""
+    gen = torch.Generator().manual_seed(B * 100 + C)
+    ft, fi = torch.randn(B, hs, generator=gen), torch.randn(B, hs, generator=gen)
+    W = torch.randn(C, 2 * hs, generator=gen) * 0.2; b = torch.randn(C, generator=gen) * 0.1
+    G = torch.randn(C, 2 * hs, generator=gen) * 0.05
+    G[C - 1, :hs] = 0.0
+    label = torch.randint(0, C, (B,), generator=gen)
+    ref, info = oracle_modulate(ft, fi, W, b, label, G)
+    cls = _classifier(W, b, G, cuda)
+    got = smml.gradient_modulate(cls, ft.to(cuda), fi.to(cuda), label.to(cuda), return_info=True).cpu()
+    assert_close(f"gradmod {B}x{C}x{hs}", cls.weight.grad, ref, 1e-5)
+    assert [int(x) for x in got[5::2].tolist()] == info["branch"]
+    assert torch.equal(cls.weight.grad[C - 1].cpu(), G[C - 1])
+
+
+def test_train_step_has_no_host_sync_between_backward_and_step(cuda):
+    """backward -> gradient_modulate -> optimizer.step() with the CUDA sync debug mode set to 'error': any .item() /
+    blocking copy in that window raises."""
+    torch.manual_seed(0)
+    B, hs, C = 8, 128, 4
+    cls = torch.nn.Linear(2 * hs, C).to(cuda)
+    opt = torch.optim.Adam(cls.parameters(), lr=1e-3, foreach=True)
+    ft = torch.randn(B, hs, device=cuda, requires_grad=True); fi = torch.randn(B, hs, device=cuda, requires_grad=True)
+    label = torch.randint(0, C, (B,), device=cuda)
+    loss = torch.nn.functional.cross_entropy(cls(torch.cat((ft, fi), 1)), label)
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss.backward()
+        smml.gradient_modulate(cls, ft, fi, label)
+        opt.step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.isfinite(cls.weight).all()
+
+
+def test_pinned_bag_stager(cuda):
+    """Batches arrive on the device with the host values, in order, through two pinned buffers; the bf16 option narrows the
+    bag on the host; buffers are reused (no allocation per step after the second batch)."""
+    torch.manual_seed(0)
+    batches = [(torch.randn(2, 300, 64), torch.randn(2, 7), torch.tensor([i, i + 1])) for i in range(5)]
+    st = smml.PinnedBagStager(batches, cuda)
+    ptrs = set()
+    for k, (bag, om, lab) in enumerate(st):
+        assert bag.is_cuda and torch.equal(bag.cpu(), batches[k][0]) and torch.equal(om.cpu(), batches[k][1])
+        assert torch.equal(lab.cpu(), batches[k][2])
+        ptrs.add(bag.data_ptr())
+        y = (bag * 2).sum()          # consumer work on the current stream
+    assert k == 4 and len(ptrs) == 2 and torch.isfinite(y)
+    st16 = smml.PinnedBagStager(batches[:2], cuda, bag_dtype=torch.bfloat16)
+    for k, (bag, om, lab) in enumerate(st16):
+        assert bag.dtype == torch.bfloat16 and torch.equal(bag.cpu(), batches[k][0].to(torch.bfloat16))
+    assert list(smml.PinnedBagStager([], cuda)) == []

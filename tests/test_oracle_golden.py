@@ -2,12 +2,13 @@
 (tests/golden/make_golden.py).  Tolerance: 1e-4 relative to each tensor's scale (north_star); the oracle
 actually agrees to ~2e-6."""
 import argparse
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, params_for, smml, synth
+from helpers import Golden, assert_zero_grad, params_for, smml, synth
 from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
 from oracle.losses import batch_loss, orthogonal_loss
 from oracle.mil import deform_pathomic_net
@@ -24,6 +25,8 @@ def _check_grads(g, params, prefix="grad:", rtol=1e-4):
     for key in g.keys(prefix):
         name = key[len(prefix):]
         if name.endswith(ZERO_GRADS):
+            if g.has("natural:" + name):       # exactly 0 in exact arithmetic: bounded by 1e-4 x sum |d bias|
+                assert_zero_grad(f"{g.name}:d{name}", params[name].grad, g.scalar("natural:" + name))
             continue
         assert params[name].grad is not None, name
         g.check(key, params[name].grad, rtol=rtol, what="d" + name)
@@ -207,3 +210,68 @@ def test_bilinear_fusion(tag, skip):
     out = bilinear_fusion(v1, v2, p, skip=skip); (out * w).sum().backward()
     g.check("out", out); g.check("dv1", v1.grad); g.check("dv2", v2.grad)
     _check_grads(g, p)
+
+
+def cmta_inputs():
+    B, n = 2, 150
+    x_path = synth.bag(B, n, 1024, 42, "cmta:bag")
+    x_omic = synth.normal((B, 431), 42, "cmta:omic")
+    w = [synth.normal((B, 4), 42, "cmta:w0")] + [synth.normal((B, 256), 42, f"cmta:w{i}") for i in range(1, 5)]
+    return x_path, x_omic, w
+
+
+def cmta_params(mod):
+    params = params_for(mod, 42, "cmta")
+    for k in params:
+        if k.endswith("cls_token"):
+            params[k] = params[k] * 1e-3
+    return params
+
+
+CMTA_OUTPUTS = ("logits", "hazards", "S", "cls_p_enc", "cls_p_dec", "cls_g_enc", "cls_g_dec")
+
+
+def test_cmta():
+    """CMTA (Transformer_P / Transformer_G encoders and decoders, the co-attention pair, concat fusion) vs the reference."""
+    from oracle.cmta import cmta
+    g = Golden("cmta_n150")
+    mod = smml.CMTA(argparse.Namespace(label_dim=4))
+    p = _req(cmta_params(mod))
+    x_path, x_omic, w = cmta_inputs()
+    x_path.requires_grad_(); x_omic.requires_grad_()
+    out = cmta(x_path, x_omic, p)
+    loss = (out[0] * w[0]).sum() + sum((out[2 + i] * w[i]).sum() for i in range(1, 5))
+    loss.backward()
+    for nm, o in zip(CMTA_OUTPUTS, out):
+        g.check(nm, o)
+    g.check("dx_path", x_path.grad); g.check("dx_omic", x_omic.grad)
+    assert abs(loss.item() - g.scalar("loss")) <= 1e-4 * abs(g.scalar("loss"))
+    _check_grads(g, p)
+
+
+def gradmod_case(seed):
+    """Inputs of tests/golden/make_golden.py::gradmod_case (B = 8, C = 4, hs = 128)."""
+    B, C, hs = 8, 4, 128
+    tag = f"gradmod:{seed}"
+    ft = synth.normal((B, hs), seed, tag + ":ft"); fi = synth.normal((B, hs), seed, tag + ":fi")
+    W = synth.normal((C, 2 * hs), seed, tag + ":W") * 0.2; b = synth.normal((C,), seed, tag + ":b") * 0.1
+    G = synth.normal((C, 2 * hs), seed, tag + ":G") * 0.05
+    label = (synth.normal((B,), seed, tag + ":lab").abs() * 1.7).long().clamp(max=C - 1)
+    return ft, fi, W, b, label, G
+
+
+def test_gradient_modulation_block():
+    """oracle/trainstep.py vs the output of the reference's own statements (train_test.py:87-184) on 8 synthetic cases
+    that take every branch (no conflict, tumor half projected, immune half projected)."""
+    from oracle.trainstep import gradient_modulate
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gradmod_b8.npz"))
+    seen = set()
+    for seed in range(1, 9):
+        ft, fi, W, b, label, G = gradmod_case(seed)
+        g, info = gradient_modulate(ft, fi, W, b, label, G)
+        ref = torch.from_numpy(z[f"case{seed}/grad"])
+        assert float((g - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), seed
+        assert abs(info["ratio_t"] - float(z[f"case{seed}/ratio_t"])) <= 1e-6 * info["ratio_t"]
+        assert [bool(x) for x in info["branch"]] == list(z[f"case{seed}/changed_rows"])
+        seen.update(info["branch"])
+    assert seen == {0, 1, 2}
