@@ -186,6 +186,16 @@ int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, flo
 int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
                            const long long* label, float* weight_grad, float* info, int B, int C, int hs, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-format step in front of the path: bags stored as packed bf16 rows, resampled to the fixed
+ * instance count on the device by the reference's index rule (data/dataset.py:151-175: i mod n when the bag is short,
+ * int(np.around(i * (n / fixdim))) when it is long - IEEE double, round-half-even; bit-exact integer path).
+ *   src [n_rows, dim] bf16 (as uint16)   dst [fixdim, dim] fp32 (out_is_f32 != 0) or bf16; dim % 8 == 0, 16-byte aligned.
+ * smml_fixdim_indices writes the fixdim source-row indices alone (int64), for the bit-exactness tests. */
+int smml_fixdim_indices(long long* out, long long n_rows, long long fixdim, void* stream);
+int smml_fixdim_gather_bf16(const unsigned short* src, long long n_rows, void* dst, int out_is_f32, long long fixdim, int dim,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

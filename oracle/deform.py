@@ -155,6 +155,7 @@ def deform_cross_attention_2d(
     return_aux: bool = False,
     attn_keep: Optional[torch.Tensor] = None,
     dropout_p: float = 0.0,
+    consistent_grid_norm: bool = False,
 ):
     """x1 (queries, fused stream) and x2 (keys/values, path stream): [B, C, N] channels-first as in
     the reference; returns (out [B, C, N], vgrid [(B g), 2, th, tw]) and optionally a dict of
@@ -188,6 +189,9 @@ def deform_cross_attention_2d(
     vsx = 2.0 * vgrid[:, 0] / max(th - 1, 1) - 1.0
     vsy = 2.0 * vgrid[:, 1] / max(tw - 1, 1) - 1.0
     J = th * tw
+    if consistent_grid_norm:      # corrected semantics (NOT the reference): pixel-centre convention, x by columns, y by rows
+        vsx = (2.0 * vgrid[:, 0] + 1.0) / tw - 1.0
+        vsy = (2.0 * vgrid[:, 1] + 1.0) / th - 1.0
     vsx, vsy = vsx.reshape(B * G, J), vsy.reshape(B * G, J)
 
     # bilinear sampling of the grouped path stream at the *full* map size (:268-274)
@@ -201,6 +205,9 @@ def deform_cross_attention_2d(
     # continuous position bias (:120-157,296-299); query grid normalised by the full map size
     qx = 2.0 * torch.arange(Ww, dtype=x1.dtype, device=x1.device) / max(Hh - 1, 1) - 1.0
     qy = 2.0 * torch.arange(Hh, dtype=x1.dtype, device=x1.device) / max(Ww - 1, 1) - 1.0
+    if consistent_grid_norm:
+        qx = (2.0 * torch.arange(Ww, dtype=x1.dtype, device=x1.device) + 1.0) / Ww - 1.0
+        qy = (2.0 * torch.arange(Hh, dtype=x1.dtype, device=x1.device) + 1.0) / Hh - 1.0
     gq = torch.stack((qx.view(1, Ww).expand(Hh, Ww), qy.view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(N, 2)
     vs = torch.stack((vsx, vsy), dim=-1)                                    # [(B g), J, 2]
     o = heads // G
@@ -243,6 +250,7 @@ def deform_cross_attention_1d(
     group_key_values: bool = False,
     q_chunk: int = 512,
     return_aux: bool = False,
+    true_1d_sampling: bool = False,
 ):
     """x1, x2 [B, C, n] -> (out [B, C, n], vgrid [(B g), t]).
 
@@ -269,6 +277,8 @@ def deform_cross_attention_1d(
     vs = 2.0 * vgrid / max(t - 1, 1) - 1.0                                          # :45-48,183
 
     feats = x2t.reshape(B, n, G, cg).permute(0, 2, 1, 3).reshape(B * G, n, 1, cg)   # H = n, W = 1
+    if true_1d_sampling:          # corrected semantics (NOT the reference): H = 1, W = n - vs runs along the tokens
+        feats = feats.reshape(B * G, 1, n, cg)
     kv = bilinear_gather(feats, vs, torch.zeros_like(vs))                           # [(B g), t, cg]
     kv = kv.reshape(B, G, t, cg).permute(0, 2, 1, 3).reshape(B, t, C)
 

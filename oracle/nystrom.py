@@ -21,13 +21,16 @@ import torch.nn.functional as F
 Params = Dict[str, torch.Tensor]
 
 
-def pinv_newton_schulz(x: torch.Tensor, iters: int = 6) -> torch.Tensor:
+def pinv_newton_schulz(x: torch.Tensor, iters: int = 6, per_bag: bool = False) -> torch.Tensor:
     """Iterative Moore-Penrose pseudo-inverse of x [..., m, m]  (NystromAttention.py:20-35).
 
     The initial scaling uses the max row/column abs-sum over the WHOLE tensor (:26), which couples
     all bags and heads in a batch - kept as is."""
     ax = x.abs()
-    z = x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())
+    if per_bag:                   # corrected semantics (NOT the reference): every bag scaled by its own maxima
+        z = x.transpose(-1, -2) / (ax.sum(dim=-1).amax(dim=(1, 2)) * ax.sum(dim=-2).amax(dim=(1, 2))).view(-1, 1, 1, 1)
+    else:
+        z = x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())
     eye = torch.eye(x.shape[-1], dtype=x.dtype, device=x.device)
     for _ in range(iters):
         xz = x @ z
@@ -46,6 +49,7 @@ def nystrom_attention(
     residual: bool = True,
     residual_conv_kernel: int = 33,
     return_aux: bool = False,
+    per_bag_pinv_scale: bool = False,
 ):
     """x [B, n, dim] -> [B, n, dim]   (NystromAttention.py:74-157, mask=None, dropout off).
 
@@ -72,7 +76,7 @@ def nystrom_attention(
     a1 = torch.softmax(q @ kl.transpose(-1, -2), dim=-1)   # [B, h, n', m]
     a2 = torch.softmax(ql @ kl.transpose(-1, -2), dim=-1)  # [B, h, m, m]
     a3 = torch.softmax(ql @ k.transpose(-1, -2), dim=-1)   # [B, h, m, n']
-    a2i = pinv_newton_schulz(a2, pinv_iterations)
+    a2i = pinv_newton_schulz(a2, pinv_iterations, per_bag_pinv_scale)
 
     out = (a1 @ a2i) @ (a3 @ v)                            # :140
     if residual:

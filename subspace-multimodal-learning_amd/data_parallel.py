@@ -2,18 +2,22 @@
 
 Replaces the reference's ``DDP(model, find_unused_parameters=True, broadcast_buffers=False)`` wrap
 (main.py:118-119) for this path:
-  * gradients are averaged with bucketed asynchronous all-reduces that are launched from
-    post-accumulate-grad hooks while backward is still running (buckets follow reverse parameter order,
-    i.e. classifier -> immune branch -> tumor branch -> omic encoders);
-  * every reduction has completed, and ``.grad`` holds the averaged value, before ``backward()`` returns -
-    the reference's train step reads ``model.module.classifier.weight.grad`` right after it
-    (train_test.py:158);
-  * parameters that receive no gradient in a step (42 tensors with attn_dim = 2: attn1d.*, cls_token,
-    _fc2, ...) enter their bucket as zeros and keep ``.grad = None`` - no graph traversal
-    (``find_unused_parameters``) is needed because the set is the same on every rank;
+  * gradients are averaged with bucketed asynchronous all-reduces launched from post-accumulate-grad hooks WHILE backward
+    is still running (buckets follow reverse parameter order, i.e. classifier -> immune branch -> tumor branch -> omic
+    encoders; `stats["launched_in_backward"]` counts them per step);
+  * every reduction has completed, and ``.grad`` holds the averaged value, before ``backward()`` returns - the reference's
+    train step reads ``model.module.classifier.weight.grad`` right after it (train_test.py:158);
+  * parameters that receive no gradient (42 tensors with attn_dim = 2: attn1d.*, cls_token, _fc2, ...) are
+    found in the FIRST step - the set is a property of the model, identical on every rank - and from then on they neither
+    hold a bucket back nor travel: their slots stay zero, buckets made only of them are skipped, ``.grad`` stays None.
+    No graph traversal (``find_unused_parameters``) is needed.  A parameter of that set that does get a gradient later
+    raises (call ``reset_unused()`` after changing what the model computes);
+  * the 1 / world factor is folded into the reduction (ReduceOp.AVG on RCCL; pre-scaled sum elsewhere): nothing runs
+    between the collective's completion and the return of backward() but the wait itself;
   * ``.module`` exposes the wrapped model as DDP does.
-The payload is ~4.65 MB per step, so the collective is latency-bound: few buckets (default 2 MiB) over
-all 7 xGMI links beat many small ones."""
+The payload is ~4.65 MB per step for DeformPathomicNet (1.96 MB for one DeformCrossTransMIL), so the collectives are
+latency-bound: the default bucket is 512 KiB - 4 to 9 buckets, enough for the first ones to be on the wire while the
+position-bias backward (the longest kernel of the step) of the other branch still runs."""
 from __future__ import annotations
 
 from typing import List
@@ -34,13 +38,15 @@ class _Bucket:
             o += p.numel()
         self.flat = None
         self.views = None
+        self.used = None                      # per parameter: receives a gradient (known after the first step)
         self.pending = 0
         self.ready = [False] * len(params)
         self.work = None
+        self.skip = False
 
 
 class BagDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, bucket_bytes: int = 2 << 20, process_group=None, broadcast: bool = True):
+    def __init__(self, module: nn.Module, bucket_bytes: int = 512 << 10, process_group=None, broadcast: bool = True):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -64,6 +70,9 @@ class BagDataParallel(nn.Module):
             for pi, p in enumerate(b.params):
                 self._where[p] = (bi, pi)
         self._armed = False
+        self._known = False                   # the grad-less set has been recorded
+        self._avg_op = None
+        self.stats = {"buckets": len(self._buckets), "launched_in_backward": 0, "skipped": 0, "steps": 0}
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -71,25 +80,44 @@ class BagDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def reset_unused(self):
+        """Forget which parameters are grad-less (after the model's control flow changed); the next step re-learns the set."""
+        self._known = False
+        for b in self._buckets:
+            b.used = None
+            b.skip = False
+
     # ---- hooks ------------------------------------------------------------------------------
     def _arm(self):
         if not self._armed:
             self._armed = True
+            self.stats["launched_in_backward"] = 0
             for b in self._buckets:
-                b.pending = len(b.params)
                 b.ready = [False] * len(b.params)
                 b.work = None
+                b.pending = len(b.params) if b.used is None else sum(b.used)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _on_grad(self, p: nn.Parameter):
         self._arm()
         bi, pi = self._where[p]
         b = self._buckets[bi]
+        if b.used is not None and not b.used[pi]:
+            raise RuntimeError("BagDataParallel: a parameter that received no gradient in the first step now has one; the set of "
+                               "grad-less parameters must be static (call reset_unused() after changing the model's control flow)")
         if not b.ready[pi]:
             b.ready[pi] = True
             b.pending -= 1
             if b.pending == 0:
                 self._launch(b)
+                self.stats["launched_in_backward"] += 1
+
+    def _reduce_op(self, t: torch.Tensor):
+        """(op, pre-scale): ReduceOp.AVG where the backend has it (RCCL), else SUM of pre-scaled values."""
+        if self._avg_op is None:
+            backend = dist.get_backend(self.group)
+            self._avg_op = (backend == "nccl")
+        return (dist.ReduceOp.AVG, None) if self._avg_op else (dist.ReduceOp.SUM, 1.0 / self.world)
 
     def _launch(self, b: _Bucket):
         ref = b.params[0]
@@ -100,28 +128,36 @@ class BagDataParallel(nn.Module):
         # ~100 launches per step); a gradient that already is the bucket's view (kept from the previous step) needs none
         live = [(v, p.grad) for v, p, r in zip(b.views, b.params, b.ready) if r and p.grad is not None]
         todo = [(v, g) for v, g in live if g.data_ptr() != v.data_ptr()]
-        if len(live) < len(b.params):           # slots of parameters without a gradient this step contribute zeros
-            if len(todo) == len(live):
-                b.flat.zero_()
-            else:                               # some gradients live in the bucket already: zero only the empty slots
-                for v, p, r in zip(b.views, b.params, b.ready):
-                    if not (r and p.grad is not None):
-                        v.zero_()
+        # slots without a gradient this step contribute zeros.  Slots of the static grad-less set were zeroed when the bucket
+        # was created and are never written; any other missing slot (first step, or a used parameter that got nothing this
+        # time) still holds the previous step's average and is cleared here
+        for v, p, r, u in zip(b.views, b.params, b.ready, b.used if b.used is not None else [True] * len(b.params)):
+            if u and not (r and p.grad is not None):
+                v.zero_()
         if todo:
             torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op, scale = self._reduce_op(b.flat)
+        if scale is not None:
+            b.flat.mul_(scale)
+        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
     def _finalize(self):
-        # runs at the end of backward(): flush incomplete buckets (grad-less parameters), then wait, average in place and
-        # hand every parameter the bucket's view as its .grad (no copy back)
+        # runs at the end of backward(): flush buckets that could not complete in the hooks (first step: grad-less parameters
+        # are not known yet), wait, and hand every parameter the bucket's view as its .grad (no copy back, no arithmetic)
         for b in self._buckets:
-            if b.work is None:
+            if b.work is None and not b.skip:
                 self._launch(b)
-        inv = 1.0 / self.world
         for b in self._buckets:
-            b.work.wait()
-            b.flat.mul_(inv)
-            for p, v, r in zip(b.params, b.views, b.ready):
+            if b.work is not None:
+                b.work.wait()
+            for p, v, r in zip(b.params, b.views or [], b.ready):
                 if r and p.grad is not None:
                     p.grad = v
+        if not self._known:
+            for b in self._buckets:
+                b.used = [bool(r and p.grad is not None) for p, r in zip(b.params, b.ready)]
+                b.skip = not any(b.used)
+            self._known = True
+            self.stats["skipped"] = sum(1 for b in self._buckets if b.skip)
+        self.stats["steps"] += 1
         self._armed = False

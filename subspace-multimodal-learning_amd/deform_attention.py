@@ -7,8 +7,17 @@ Same constructor keywords / defaults, forward signatures, tensor layouts and par
 so `state_dict`s are interchangeable.  The nn.Conv / nn.Linear sub-modules only hold the parameters
 (identical default initialisation); the arithmetic runs in the kernels behind `functional`.
 
-Additive knob (reference default kept): `grid_hw` - the reference hard-wires a 50 x 50 token grid
+Additive knobs (reference defaults kept): `grid_hw` - the reference hard-wires a 50 x 50 token grid
 (DeformableAttention2D.py:239-240,318); here the grid defaults to the square root of the token count.
+Corrected-semantics switches, OFF by default (bit-parity with the reference needs them off):
+  * DeformCrossAttention2D(consistent_grid_norm=True): the reference normalises sample positions with the
+    align_corners=True formula 2 v / (t - 1) - 1 (:100-108,265; x divided by rows - 1, y by cols - 1) but samples with
+    F.grid_sample(align_corners=False) (:268) - ~21 % of the corner fetches fall outside the map at initialisation.  With
+    the switch both the sample positions and the query grid use the pixel-centre convention (2 p + 1) / size - 1, x scaled
+    by the number of columns and y by the number of rows.
+  * DeformCrossAttention1D(true_1d_sampling=True): the reference's grid_sample_1d (:36-43) lays the features out
+    [H = n, W = 1] while the grid carries (x = vs, y = 0), so every "sampled" key is the centre token scaled; with the switch
+    the map is [H = 1, W = n] and vs interpolates along the tokens.
 """
 from __future__ import annotations
 
@@ -86,8 +95,9 @@ def _build_grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
 class DeformCrossAttention2D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=4,
                  offset_groups=8, offset_kernel_size=6, group_queries=True, group_key_values=True,
-                 grid_hw: Optional[Tuple[int, int]] = None):
+                 grid_hw: Optional[Tuple[int, int]] = None, consistent_grid_norm: bool = False):
         super().__init__()
+        self.consistent_grid_norm = bool(consistent_grid_norm)
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -134,11 +144,17 @@ class DeformCrossAttention2D(nn.Module):
         vgrid, vs = Fh.offsets(q.view(B, Hh, Ww, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
                                self.to_offsets[2].weight.reshape(2, -1), groups=G, ks=self.offset_kernel_size,
                                r=self.downsample_factor, posdim=2, offset_scale=self.offset_scale)
+        gq = _grid_queries_2d(Hh, Ww, x1t.device)
+        if self.consistent_grid_norm:          # corrected semantics (off by default): pixel-centre convention on both sides
+            th, tw = vgrid.shape[-2:]
+            vs = torch.stack(((2.0 * vgrid[:, 0] + 1.0) / tw - 1.0, (2.0 * vgrid[:, 1] + 1.0) / th - 1.0), dim=-1)
+            vs = vs.reshape(B * G, th * tw, 2).contiguous()
+            ar = lambda n: (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) + 1.0) / n - 1.0
+            gq = torch.stack((ar(Ww).view(1, Ww).expand(Hh, Ww), ar(Hh).view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(Hh * Ww, 2).contiguous()
         kv = Fh.bilinear_sample(x2t.reshape(B, Hh, Ww, C), vs, groups=G, posdim=2)                  # [B, J, C]
         gk = G if self.group_key_values else 1
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
-        gq = _grid_queries_2d(Hh, Ww, x1t.device)
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
                                 **_dropout_args(self))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
@@ -155,8 +171,9 @@ class DeformCrossAttention2D(nn.Module):
 class DeformCrossAttention1D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None,
                  offset_groups=4, offset_kernel_size=6, cpb_log_distance=True, group_queries=False,
-                 group_key_values=False):
+                 group_key_values=False, true_1d_sampling: bool = False):
         super().__init__()
+        self.true_1d_sampling = bool(true_1d_sampling)
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -196,8 +213,9 @@ class DeformCrossAttention1D(nn.Module):
         vgrid, vs = Fh.offsets(q.view(B, 1, n, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
                                self.to_offsets[2].weight.reshape(1, -1), groups=G, ks=self.offset_kernel_size,
                                r=self.downsample_factor, posdim=1, offset_scale=self.offset_scale)
-        # bug-compatible degenerate sampling (DeformableAttention1D.py:36-43): map laid out [H = n, W = 1]
-        kv = Fh.bilinear_sample(x2t.reshape(B, n, 1, C), vs, groups=G, posdim=1)
+        # bug-compatible degenerate sampling (DeformableAttention1D.py:36-43): map laid out [H = n, W = 1]; the corrected
+        # switch lays it out [H = 1, W = n] so that vs interpolates along the tokens
+        kv = Fh.bilinear_sample(x2t.reshape(B, 1, n, C) if self.true_1d_sampling else x2t.reshape(B, n, 1, C), vs, groups=G, posdim=1)
         gk = G if self.group_key_values else 1
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)

@@ -4,12 +4,16 @@ signatures, return tuples and parameter names.
 
 Additive knobs (reference defaults kept): `args.input_path_dim` (config/config_mine.yaml:25, default 1024)
 sizes `_fc1`; the token count is taken from the bag instead of the hard-wired 2500
-(DeformCrossTransMIL.py:104); `grid_hw` is forwarded to the 2-D attention.
+(DeformCrossTransMIL.py:104); `grid_hw` is forwarded to the 2-D attention.  `args.wrap_pad_to_square` (off by default;
+SURVEY.md 8(f) row 4) lets the 2-D branch take bags whose instance count is not a square: both token streams are
+wrap-padded to the next square as TransMIL does (models/mil.py:232-235), attended, and cropped back to N.
 
 Differences in mechanism, not in values: the 2500x tiled omic matrix is never fed through a GEMM - the
 fusion layer is evaluated as path @ W[:, :C]^T + (omic @ W[:, C:]^T + b) with the second term broadcast
 per bag - but the tiled tensor is still returned (BatchLoss consumes it, utils/loss.py:22)."""
 from __future__ import annotations
+
+import math
 
 import torch
 from torch import nn
@@ -94,10 +98,19 @@ class DeformCrossTransMIL(nn.Module):
             h = Fh.layer_norm(h[:, :1], self.norm.weight, self.norm.bias, self.norm.eps)[:, 0]
             logits = Fh.linear(h, self._fc2.weight, self._fc2.bias)
         elif self.args.attn_dim == 2:
+            pth = path
+            side = int(math.ceil(math.sqrt(N)))
+            wrap = bool(getattr(self.args, "wrap_pad_to_square", False)) and side * side != N and getattr(self.args, "grid_hw", None) is None
+            if wrap:                                   # h[:, :add] appended, as mil.py:232-235 does for TransMIL
+                add = side * side - N
+                h = torch.cat((h, h[:, :add]), dim=1)
+                pth = torch.cat((path, path[:, :add]), dim=1)
             if self.args.return_vgrid:
-                h, vgrid = self.layer3(h, path, 2, True)
+                h, vgrid = self.layer3(h, pth, 2, True)
             else:
-                h = self.layer3(h, path, 2, False)
+                h = self.layer3(h, pth, 2, False)
+            if wrap:
+                h = h[:, :N]
             avg = Fh.layer_norm_token_mean(h, self.norm.weight, self.norm.bias, self.norm.eps)
             h = Fh.linear(avg, self.pooler.dense.weight, self.pooler.dense.bias, act=Fh.ACT_TANH)
             logits = Fh.linear(h, self._fc2.weight, self._fc2.bias)

@@ -24,12 +24,18 @@ from torch import nn
 from . import functional as Fh
 
 
-def moore_penrose_iter_pinv(x, iters=6):
+def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
     """x [B, h, m, m] -> Newton-Schulz pseudo-inverse (NystromAttention.py:20-35).
     z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz))) evaluated as four GEMMs per iteration:
-    xz; a = 7 xz - xz xz; b = 15 xz - xz a; z = 3.25 z - 0.25 z b."""
+    xz; a = 7 xz - xz xz; b = 15 xz - xz a; z = 3.25 z - 0.25 z b.
+    per_bag=True (corrected semantics, off by default): the initial scale uses each bag's own max row / column sums instead
+    of the max over the whole batch (:26), so that a bag's result does not depend on which other bags share its batch."""
     ax = x.abs()
-    z = (x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())).contiguous()
+    if per_bag:
+        scale = ax.sum(dim=-1).amax(dim=(1, 2)) * ax.sum(dim=-2).amax(dim=(1, 2))
+        z = (x.transpose(-1, -2) / scale.view(-1, 1, 1, 1)).contiguous()
+    else:
+        z = (x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())).contiguous()
     for _ in range(iters):
         xz = Fh.matmul4(x, z)
         a = Fh.matmul4(xz, xz, xz, alpha=-1.0, beta=7.0)
@@ -40,9 +46,10 @@ def moore_penrose_iter_pinv(x, iters=6):
 
 class NystromAttention(nn.Module):
     def __init__(self, dim, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True,
-                 residual_conv_kernel=33, eps=1e-8, dropout=0.):
+                 residual_conv_kernel=33, eps=1e-8, dropout=0., per_bag_pinv_scale: bool = False):
         super().__init__()
         self.eps = eps
+        self.per_bag_pinv_scale = bool(per_bag_pinv_scale)     # corrected semantics (off by default), see moore_penrose_iter_pinv
         inner_dim = heads * dim_head
         self.num_landmarks = num_landmarks
         self.pinv_iterations = pinv_iterations
@@ -76,7 +83,7 @@ class NystromAttention(nn.Module):
         a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True, alpha=sc))       # [b, h, n', m]
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))      # [b, h, m, m]
         a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True, alpha=sc))       # [b, h, m, n']
-        z = moore_penrose_iter_pinv(a2, self.pinv_iterations)
+        z = moore_penrose_iter_pinv(a2, self.pinv_iterations, self.per_bag_pinv_scale)
         left = Fh.matmul4(a1, z)                               # [b, h, n', m]
         right = Fh.matmul4(a3, v)                              # [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None

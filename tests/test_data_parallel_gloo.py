@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
-    dp = smml.BagDataParallel(net, bucket_bytes=64)
+    dp = smml.BagDataParallel(net, bucket_bytes=32)
     xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
     out = {}
     for step in range(2):                      # twice: bucket state must re-arm
@@ -48,7 +48,9 @@ def _worker(rank, world, port, q):
         dp(xs[rank]).pow(2).sum().backward()
         # gradients are final as soon as backward() returns (train_test.py:158 reads .grad right away)
         out[f"ga{step}"] = net.a.weight.grad.clone()
+        out[f"in_bwd{step}"] = dp.stats["launched_in_backward"]
     out["unused_none"] = net.unused.weight.grad is None
+    out["buckets"] = dp.stats["buckets"]; out["skipped"] = dp.stats["skipped"]
     # a third step that keeps the gradient tensors (zero_grad(set_to_none=False)): they are the bucket's views by now, autograd
     # accumulates into them in place and the wrapper must neither copy nor clear them
     net.zero_grad(set_to_none=False)
@@ -101,8 +103,24 @@ def test_world_size_2_gloo():
     for r in range(world):
         o = res[r]
         assert o["has_module"] and o["unused_none"]
+        # the reductions must start DURING backward.  Step 0 learns the grad-less set (the bucket holding
+        # `unused` can only be flushed at the end); from step 1 on every bucket that carries gradients is launched from a hook
+        # before backward() ends and the bucket made only of grad-less parameters is skipped
+        assert o["buckets"] >= 4 and o["skipped"] >= 1
+        assert o["in_bwd1"] == o["buckets"] - o["skipped"], (o["in_bwd0"], o["in_bwd1"], o["buckets"], o["skipped"])
         for step in range(3):
             assert torch.allclose(o[f"ga{step}"], o["ref"], rtol=1e-5, atol=1e-6), f"rank {r} step {step}"
         assert torch.allclose(o["bl"], o["bl_ref"], rtol=1e-5)
         assert torch.allclose(o["domic"], o["domic_ref"], rtol=1e-5, atol=1e-7)
     assert torch.equal(res[0]["ga0"], res[1]["ga0"])
+
+
+def test_default_buckets_split_the_mil_model():
+    """DeformCrossTransMIL has 1.96 MB of parameters: the default bucket size must give several buckets (one 2 MiB bucket
+    could only ever be reduced after backward had finished)."""
+    import argparse
+    mil = smml.DeformCrossTransMIL(argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=512))
+    dp = smml.BagDataParallel(mil)
+    assert dp.stats["buckets"] >= 3
+    sizes = [b.numel * 4 for b in dp._buckets]
+    assert max(sizes) < (1 << 20) + (512 << 10)

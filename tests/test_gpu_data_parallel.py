@@ -38,36 +38,45 @@ def _data(smml, rank, B, S, in_dim):
     return path, omic, label
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import importlib
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0        # RCCL wants one device per rank; the gloo rehearsal shares cuda:0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     smml = importlib.import_module("subspace-multimodal-learning_amd")
     B, S, in_dim = 2, 16, 64
     mil = _build(smml, S, in_dim)
     dp = smml.BagDataParallel(mil, bucket_bytes=1 << 18)
     bl = smml.BatchLoss(B, world)
     path, omic, label = _data(smml, rank, B, S, in_dim)
-    loss = _loss(smml, dp, bl, path, omic, label)
-    loss.backward()
+    for step in range(2):                          # step 0 learns the grad-less set, step 1 overlaps (same data: same gradients)
+        mil.zero_grad(set_to_none=True)
+        loss = _loss(smml, dp, bl, path, omic, label)
+        loss.backward()
     grads = {k: p.grad.detach().cpu().numpy() for k, p in mil.named_parameters() if p.grad is not None}
-    q.put((rank, float(loss.item()), grads))
+    q.put((rank, float(loss.item()), grads, dict(dp.stats)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(cuda, smml):
+def _run_two_ranks(smml, backend):
+    import helpers
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, l, g = q.get(timeout=300)
+        r, l, g, st = q.get(timeout=300)
         res[r] = (l, g)
+        # every bucket that carries gradients was launched from a hook, i.e. while backward was still running
+        assert st["buckets"] >= 3 and st["launched_in_backward"] == st["buckets"] - st["skipped"] >= 2, st
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -87,10 +96,33 @@ def test_two_ranks_match_single_process(cuda, smml):
         assert abs(res[r][0] - float((ce[r] + blv).item())) <= 1e-4 * abs(res[r][0]), "per-rank loss"
     ref = {k: p.grad.detach().cpu() for k, p in mil.named_parameters() if p.grad is not None}
     assert set(ref) == set(res[0][1]) == set(res[1][1])
+    worst = []
     for k, v in ref.items():
-        if k.endswith("rel_pos_bias.mlp.2.bias"):
-            continue
         g0, g1 = torch.from_numpy(res[0][1][k]), torch.from_numpy(res[1][1][k])
         assert torch.equal(g0, g1), f"ranks disagree on {k}"
+        if k.endswith("rel_pos_bias.mlp.2.bias"):           # exactly 0 in exact arithmetic: both evaluations are rounding noise,
+            scale = float(ref["layer3.attn2d.rel_pos_bias.mlp.2.weight"].abs().max())      # bounded against the layer's weight gradient
+            assert float(g0.abs().max()) <= 1e-4 * scale and float(v.abs().max()) <= 1e-4 * scale, k
+            continue
         err = float((g0 - v).abs().max() / v.abs().max().clamp_min(1e-30))
-        assert err <= 2e-3, f"{k}: {err:.2e}"      # the BatchLoss gradient of identical-value tiles is ill-conditioned at B = 4
+        helpers.record(f"dp2[{backend}] d{k}", err, None, DP_TOL, "max vs single process")
+        if err > DP_TOL:
+            worst.append(f"{k}: {err:.2e}")
+    assert not worst, "two-rank gradients differ from the single-process run:\n  " + "\n  ".join(worst)
+
+
+# Both sides are HIP fp32 evaluations of the same sums in different orders (2 + 2 bags vs 4 bags per launch): they agree to fp32
+# rounding amplified by the conditioning of each gradient; every tensor's distance is recorded in the parity report
+DP_TOL = 1e-4
+
+
+def test_two_ranks_match_single_process(cuda, smml):
+    """2 ranks on ONE device over gloo (RCCL refuses two ranks per device)."""
+    _run_two_ranks(smml, "gloo")
+
+
+def test_two_ranks_over_rccl(cuda, smml):
+    """The same comparison over RCCL, one device per rank - runs wherever two GPUs are visible (the driver's 8-GPU node)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_two_ranks(smml, "nccl")

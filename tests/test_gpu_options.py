@@ -1,0 +1,143 @@
+"""GPU: the corrected-semantics switches.  All are OFF by default - the default paths are pinned to the
+reference by the golden tests - so these tests check (a) HIP vs the oracle's restatement of the corrected semantics and
+(b) the property each switch is there for."""
+import argparse
+
+import pytest
+import torch
+
+from helpers import assert_calibrated, assert_close, params_for, smml, synth
+from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
+from oracle.nystrom import nystrom_attention
+from test_gpu_parity import _compare_param_grads, _load, cpb_probe
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+
+
+def test_consistent_grid_norm_2d(cuda):
+    B, Hh, Ww, C = 2, 20, 28, 128
+    N = Hh * Ww
+    tag = "opt:cgn"
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww), consistent_grid_norm=True)
+    params = params_for(mod, 31, tag)
+    mod = _load(mod, params, cuda)
+    x1 = synth.normal((B, C, N), 31, tag + ":x1"); x2 = synth.normal((B, C, N), 31, tag + ":x2")
+    wo = synth.normal((B, C, N), 31, tag + ":wo")
+    run = {}
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+            o, vg = deform_cross_attention_2d(a, b, pr, grid_hw=(Hh, Ww), consistent_grid_norm=True)
+            (o * wo.to(dt)).sum().backward()
+            run[dt] = (o, vg, a.grad, b.grad, pr)
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    o, vg = mod(ad, bd, return_vgrid=True)
+    (o * wo.to(cuda)).sum().backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
+        assert_calibrated("cgn " + name, got, r32[i], r64[i])
+    _compare_param_grads(mod, r32[4], r64[4], probe=probe)
+    # what the switch is for: with zero offsets every sample sits on the centre of its r x r block, inside the map
+    th, tw = vg.shape[-2:]
+    gx = torch.arange(tw, dtype=torch.float32).view(1, tw).expand(th, tw).reshape(1, -1)
+    gy = torch.arange(th, dtype=torch.float32).view(th, 1).expand(th, tw).reshape(1, -1)
+    _, _, corners = sample_positions((2 * gx + 1) / tw - 1, (2 * gy + 1) / th - 1, Ww, Hh)
+    assert all(bool(c[3].all()) for c in corners), "pixel-centre positions must have all four corners in bounds"
+    _, _, corners_ref = sample_positions(2 * gx / max(th - 1, 1) - 1, 2 * gy / max(tw - 1, 1) - 1, Ww, Hh)
+    assert not all(bool(c[3].all()) for c in corners_ref), "the reference normalisation puts corners outside the map"
+
+
+def test_true_1d_sampling(cuda):
+    B, n, C = 2, 130, 128
+    tag = "opt:t1d"
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, true_1d_sampling=True)
+    params = params_for(mod, 33, tag)
+    mod = _load(mod, params, cuda)
+    x1 = synth.normal((B, C, n), 33, tag + ":x1"); x2 = synth.normal((B, C, n), 33, tag + ":x2")
+    wo = synth.normal((B, C, n), 33, tag + ":wo")
+    run = {}
+    with cpb_probe() as probe:
+        for dt in (torch.float32, torch.float64):
+            pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+            o, vg = deform_cross_attention_1d(a, b, pr, offset_scale=2.0, true_1d_sampling=True)
+            (o * wo.to(dt)).sum().backward()
+            run[dt] = (o, vg, a.grad, b.grad, pr)
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    o, vg = mod(ad, bd, return_vgrid=True)
+    (o * wo.to(cuda)).sum().backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
+        assert_calibrated("t1d " + name, got, r32[i], r64[i])
+    _compare_param_grads(mod, r32[4], r64[4], probe=probe)
+    # what the switch is for: the keys depend on MORE than the centre token (in the reference's layout d out / d x2 is
+    # non-zero at the centre token only)
+    touched = (bd.grad.abs().sum(dim=(0, 1)) > 0).sum().item()
+    assert touched > n // 2
+    ref_mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    ref_mod = _load(ref_mod, params, cuda)
+    b2 = x2.to(cuda).requires_grad_()
+    (ref_mod(x1.to(cuda), b2) * wo.to(cuda)).sum().backward()
+    assert (b2.grad.abs().sum(dim=(0, 1)) > 0).sum().item() <= 2
+
+
+def test_per_bag_pinv_scale(cuda):
+    B, n, dim, dh, m = 3, 200, 128, 16, 64
+    tag = "opt:pbp"
+    mod = smml.NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, per_bag_pinv_scale=True)
+    params = params_for(mod, 35, tag)
+    mod = _load(mod, params, cuda)
+    x = synth.normal((B, n, dim), 35, tag + ":x") * torch.tensor([0.3, 1.0, 2.5]).view(3, 1, 1)
+    wo = synth.normal((B, n, dim), 35, tag + ":wo")
+    run = {}
+    for dt in (torch.float32, torch.float64):
+        pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+        xr = x.clone().to(dt).requires_grad_()
+        o = nystrom_attention(xr, pr, heads=8, dim_head=dh, num_landmarks=m, per_bag_pinv_scale=True)
+        (o * wo.to(dt)).sum().backward()
+        run[dt] = (o, xr.grad, pr)
+    xd = x.to(cuda).requires_grad_()
+    out = mod(xd)
+    (out * wo.to(cuda)).sum().backward()
+    r32, r64 = run[torch.float32], run[torch.float64]
+    assert_calibrated("pbp out", out, r32[0], r64[0]); assert_calibrated("pbp dx", xd.grad, r32[1], r64[1])
+    for k, p in mod.named_parameters():
+        assert_calibrated("pbp d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
+    # what the switch is for: a bag's output no longer depends on its batch mates
+    with torch.no_grad():
+        alone = mod(x[1:2].to(cuda))
+        assert_close("bag independent of its batch", out[1:2].detach(), alone, 1e-5)
+        ref_mod = _load(smml.NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m), params, cuda)
+        coupled = float((ref_mod(x.to(cuda))[1:2] - ref_mod(x[1:2].to(cuda))).abs().max())
+        assert coupled > 1e-6, "with the reference's batch-global max the bags are coupled"
+
+
+def test_wrap_pad_to_square(cuda):
+    """A bag of 390 instances (not a square) through the 2-D branch: equals the run on the explicitly wrap-padded 20 x 20
+    bag, cropped; without the switch the module refuses."""
+    args = argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=64, wrap_pad_to_square=True)
+    mil = smml.DeformCrossTransMIL(args)
+    params = params_for(mil, 37, "opt:wrap")
+    mil = _load(mil, params, cuda)
+    B, N = 2, 390
+    path = synth.bag(B, N, 64, 37, "opt:wrap:bag").to(cuda); omic = torch.relu(synth.normal((B, 128), 37, "opt:wrap:omic")).to(cuda)
+    enc, logits, _, omic_t, vg = mil(path, omic)
+    assert omic_t.shape == (B, N, 128) and vg.shape == (B * 8, 2, 5, 5)
+    # reference construction by hand: fc1 -> fusion on the N tokens, wrap-pad both streams, attention on 20 x 20, crop, pool
+    with torch.no_grad():
+        p = Fh.linear(path, mil._fc1[0].weight, mil._fc1[0].bias, act=Fh.ACT_RELU)
+        h = mil.fusion_layer(p, omic)
+        h2 = torch.cat((h, h[:, :10]), 1); p2 = torch.cat((p, p[:, :10]), 1)
+        h2 = mil.layer3(h2, p2, 2, False)[:, :N]
+        avg = Fh.layer_norm_token_mean(h2, mil.norm.weight, mil.norm.bias, mil.norm.eps)
+        e2 = Fh.linear(Fh.linear(avg, mil.pooler.dense.weight, mil.pooler.dense.bias, act=Fh.ACT_TANH),
+                       mil.multimodal_projection.weight, mil.multimodal_projection.bias)
+    assert_close("wrap-pad encoded", enc.detach(), e2, 1e-6)
+    enc.sum().backward()
+    assert all(torch.isfinite(q.grad).all() for q in mil.parameters() if q.grad is not None)
+    args2 = argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=64)
+    mil2 = _load(smml.DeformCrossTransMIL(args2), params, cuda)
+    with pytest.raises(ValueError):
+        mil2(path, omic)
