@@ -53,8 +53,11 @@ int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
 /* test hook: 1 routes every product through the generic (any stride / any K) kernel instead of the tiled
  * fast path (K % 16 == 0, 16-byte aligned operands with a unit stride on k or on the row index). */
 void smml_gemm_force_generic(int on);
-/* test / tuning hook: 0 automatic (default), 1 fp32-MFMA tiled kernel only, 2 split-bf16 kernel wherever it applies */
+/* precision / tuning switch of the tiled kernels: 0 automatic (default: exact fp32 on the f32 MFMA, split-bf16 for large
+ * square-ish products), 1 fp32-MFMA kernel only, 2 split-bf16 (three terms, fp32-grade) wherever it applies, 3 single-term bf16
+ * (operands rounded to bf16 when staged, fp32 accumulation: the 16-bit compute mode of the Nystrom block). */
 void smml_gemm_set_mode(int mode);
+int smml_gemm_get_mode(void);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.
@@ -195,6 +198,24 @@ int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float
 int smml_fixdim_indices(long long* out, long long n_rows, long long fixdim, void* stream);
 int smml_fixdim_gather_bf16(const unsigned short* src, long long n_rows, void* dst, int out_is_f32, long long fixdim, int dim,
                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused softmax attention on the 16-bit matrix pipe: O = softmax(scale Q K^T) V with fp32 storage, bf16 (use_fp16 = 0) or
+ * fp16 (use_fp16 = 1) operands converted on the fly and fp32 accumulation; the [Lq, Lk] probability matrix is never written
+ * (forward keeps one base-2 log-sum-exp per query in lse2, backward recomputes).  Serves the two attention-shaped products of
+ * the Nystrom block in its 16-bit compute mode (models/NystromAttention.py:122-140): softmax(q kl^T) (z (attn3 v)) with
+ * (Lq, Lk) = (n', m) and softmax(ql k^T) v with (Lq, Lk) = (m, n').
+ *   q [BH, Lq, 64]   k, v [BH, Lk, 64]   dq [BH, Lq, 64]   dk, dv [BH, Lk, 64]   lse2 [BH, Lq]   (D must be 64)
+ *   out / dout: head-major [BH, Lq, 64] (heads_merged = 0) or heads merged [BH / H, Lq, H * 64] (heads_merged = H: the layout
+ *   the block's output projection consumes).  accumulate != 0: out += result (out already holds the residual convolution of
+ *   v, :144-145); the backward then takes that residual (same layout, nullable) to recover the attention output.
+ * Backward: dq / dk / dv overwritten; workspace of smml_attn16_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
+int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, int BH, int Lq, int Lk, int D,
+                        float scale, int use_fp16, int heads_merged, int accumulate, void* stream);
+size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk);
+int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* residual, const float* dout,
+                        const float* lse2, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, int BH, int Lq,
+                        int Lk, int D, float scale, int use_fp16, int heads_merged, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,12 @@ def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int):
     the HIP kernel evaluates the same sequence so indices/masks compare bit-exactly."""
     ix = ((vx + 1.0) * float(W) - 1.0) / 2.0
     iy = ((vy + 1.0) * float(H) - 1.0) / 2.0
+    if GRAD_PROBE is not None:
+        # bilinear interpolation has a kink at integer pixel coordinates: where a sample position lies within fp32 rounding of
+        # one, no fp32 evaluation determines which cell's slope the position gradient takes.  Tests read this margin.
+        with torch.no_grad():
+            d = torch.minimum((ix - torch.round(ix)).abs().min(), (iy - torch.round(iy)).abs().min() if H > 1 else ix.new_tensor(1.0))
+            GRAD_PROBE["boundary"] = min(GRAD_PROBE.get("boundary", 1.0), float(d))
     x0f, y0f = torch.floor(ix), torch.floor(iy)
     x0, y0 = x0f.to(torch.int64), y0f.to(torch.int64)
     x1, y1 = x0 + 1, y0 + 1

@@ -26,6 +26,10 @@ SIGNATURES = {
                            _ll, _ll, _ll, _ll, _i, _i, _ll, _i, _i, _i, _fl, _fl, _f]),
     "smml_gemm_force_generic": (None, [_i]),
     "smml_gemm_set_mode": (None, [_i]),
+    "smml_gemm_get_mode": (_i, []),
+    "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
+    "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smml_attn16_bwd_f32": (_i, [_f] * 10 + [_f, _sz, _i, _i, _i, _i, _fl, _i, _i, _f]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),
     "smml_layernorm_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _ll, _i, _ll, _fl, _i, _f]),
     "smml_colsum_f32": (_i, [_f, _f, _i, _ll, _i, _fl, _f]),

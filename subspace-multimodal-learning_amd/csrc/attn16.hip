@@ -1,0 +1,524 @@
+// Fused softmax attention on the 16-bit matrix pipe of gfx950 (v_mfma_f32_32x32x16_{bf16,f16}), forward and backward, for the two
+// attention-shaped products of the Nystrom landmark block (models/NystromAttention.py:122-140; dup cmta_utils.py:246-264):
+//
+//   a1 side   softmax(q kl^T) W        queries = the n' tokens,      keys = the m landmarks, values W = z (attn3 v)   [m, d]
+//   a3 side   softmax(ql k^T) v        queries = the m landmarks,    keys = the n' tokens,   values v                 [n', d]
+//
+// (out = (attn1 z)(attn3 v) of :140 is evaluated as attn1 (z (attn3 v)): the [n', m] x [m, m] product of the reference becomes an
+// [m, m] x [m, d] one; the [n', m] and [m, n'] probability matrices are never written to HBM - forward keeps one log-sum-exp
+// per query, backward recomputes the probabilities from it.)
+//
+// Storage stays fp32 (q, k, v, out, gradients; head-major [BH, L, 64]); operands are converted to bf16 / fp16 when a tile is
+// staged into LDS or a fragment is built in registers, products accumulate in fp32.  This is the "16-bit compute" path of the
+// block (BASELINE configs 2 / 4 / 5 name bf16 / fp16); the default fp32 path keeps the exact-fp32 GEMM composition.
+//
+// Orientation (as in deform_attn.hip): S^T = K Q^T puts keys on accumulator rows and queries on lanes, so the softmax
+// reduction is in-lane (16 registers + one cross-half exchange) and the probabilities are the B operand of O^T = V^T P^T as
+// they stand (converted pairwise to 16 bit; the k order of that fragment is acc_row(8 s + j, half), which the transposed
+// LDS reads of V^T reproduce).  head dim 64; 32 queries per wave, 4 waves per workgroup, 32-key tiles, double-buffered
+// LDS with the next tile's global loads in flight during the MFMAs.
+#include "smml_common.h"
+
+namespace {
+
+constexpr int AD = 64;        // head dim
+constexpr int AQ = 32;        // queries per wave
+constexpr int AW = 4;         // waves per workgroup
+constexpr int AK = 32;        // keys per tile
+constexpr int RLD = AD + 8;   // halves per row of a row-read image (144-byte rows: conflict-free ds_read_b128 of 32 rows)
+constexpr int TLD = AD + 32;  // halves per row of a transposed-read image (192-byte rows, see deform_attn.hip)
+constexpr float LOG2E_F = 1.4426950408889634f;
+constexpr float LN2_F = 0.6931471805599453f;
+
+// layout of O / dO (floats): element (bh, query, d) at (bh / H) * bs + (bh % H) * hs + query * rs + d.  Head-major [BH, Lq, 64] is
+// {H Lq 64, Lq 64, 64}; heads merged [B, Lq, H 64] - what the block's output projection consumes - is {Lq H 64, 64, H 64}.
+struct OLayout { long long bs, hs, rs; int H; };
+__device__ __forceinline__ size_t obase(const OLayout& L, int bh) { return (size_t)(bh / L.H) * L.bs + (size_t)(bh % L.H) * L.hs; }
+
+template <typename T> struct Pipe;
+template <> struct Pipe<__bf16> {
+  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Pipe<_Float16> {
+  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ floatx16 mfma(x8 a, x8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// 8 fp32 -> one 16-bit MFMA fragment (round to nearest even)
+template <typename T>
+__device__ __forceinline__ typename Pipe<T>::x8 pack8(const float (&x)[8]) {
+  typedef typename Pipe<T>::x2 x2;
+  uint4v w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2v v = {x[2 * i], x[2 * i + 1]};
+    w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x2));
+  }
+  return __builtin_bit_cast(typename Pipe<T>::x8, w);
+}
+template <typename T>
+__device__ __forceinline__ uint2v pack4(const float4 v) {
+  typedef typename Pipe<T>::x2 x2;
+  const float2v a = {v.x, v.y}, b = {v.z, v.w};
+  return (uint2v){__builtin_bit_cast(unsigned, __builtin_convertvector(a, x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(b, x2))};
+}
+// MFMA fragment of an operand stored k-major ([k][rows]) in LDS: two hardware-transposed reads (see smml_common.h lds_frag_tr)
+template <typename T>
+__device__ __forceinline__ typename Pipe<T>::x8 frag_tr(const T* p0, const T* p1) {
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) short4v lds_s4;
+  const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p0);
+  const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p1);
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  return __builtin_bit_cast(typename Pipe<T>::x8, r);
+}
+// this lane's 8 consecutive head-dim values of k-step s (d = 16 s + 8 half + j) of one fp32 row, times `mul`, as a fragment
+template <typename T>
+__device__ __forceinline__ typename Pipe<T>::x8 row_frag(const float* row, int s, int hf, float mul) {
+  const float4 a = *reinterpret_cast<const float4*>(row + 16 * s + 8 * hf), b = *reinterpret_cast<const float4*>(row + 16 * s + 8 * hf + 4);
+  const float x[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
+  return pack8<T>(x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: O = softmax(scale Q K^T) V, LSE2 = log2-sum-exp2 of the scaled scores per query (base 2: what the backward needs)
+//   Q [BH, Lq, 64]  K, V [BH, Lk, 64]  O [BH, Lq, 64]  LSE2 [BH, Lq]     grid (ceil(Lq / 128), BH)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, float* __restrict__ O,
+                                                            float* __restrict__ LSE2, int Lq, int Lk, float qscale, OLayout ol,
+                                                            int accumulate) {
+  typedef typename Pipe<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
+  __shared__ __attribute__((aligned(16))) T Vt[2][AK * TLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.y;
+  const int q0 = blockIdx.x * (AQ * AW) + wave * AQ;
+  const bool qvalid = (q0 + c) < Lq;
+  const int qi = qvalid ? (q0 + c) : (Lq - 1);
+  const float* Kb = K + (size_t)bh * Lk * AD;
+  const float* Vb = V + (size_t)bh * Lk * AD;
+
+  x8 qf[4];
+  {
+    const float* qrow = Q + ((size_t)bh * Lq + qi) * AD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = row_frag<T>(qrow, s, hf, qscale);
+  }
+  // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
+  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 kreg[2], vreg[2];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = j0 + skey + 16 * i;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
+      if (key < Lk) {
+        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * AD + sd4);
+        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * AD + sd4);
+      }
+    }
+  };
+  fetch(0);
+  floatx16 o0 = {0}, o1 = {0};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (Lk + AK - 1) / AK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * AK, buf = kt & 1;
+    const int nk = min(AK, Lk - j0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = skey + 16 * i;
+      *reinterpret_cast<uint2v*>(&Kr[buf][key * RLD + sd4]) = pack4<T>(kreg[i]);
+      *reinterpret_cast<uint2v*>(&Vt[buf][key * TLD + sd4]) = pack4<T>(vreg[i]);
+    }
+    __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2: one barrier per tile is enough
+    if (kt + 1 < ntiles) fetch(j0 + AK);
+    // S^T[key, query] = K (qscale Q)^T
+    floatx16 s = {0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) s = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Kr[buf][c * RLD + 16 * st + 8 * hf]), qf[st], s);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (acc_row(r, hf) >= nk) s[r] = -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = xhalf_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // O^T[d, query] += V^T P^T: the probabilities of k-step kb are accumulator registers 8 kb .. 8 kb + 7
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float p8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p8[j] = s[8 * kb + j];
+      const x8 pb = pack8<T>(p8);
+      const int ro = (16 * kb + 4 * hf + trq) * TLD + trc;
+      o0 = Pipe<T>::mfma(frag_tr<T>(&Vt[buf][ro], &Vt[buf][ro + 8 * TLD]), pb, o0);
+      o1 = Pipe<T>::mfma(frag_tr<T>(&Vt[buf][ro + 32], &Vt[buf][ro + 32 + 8 * TLD]), pb, o1);
+    }
+  }
+  l_run = xhalf_sum(l_run);
+  const float inv = 1.f / l_run;
+  if (qvalid) {
+    float* op = O + obase(ol, bh) + (size_t)qi * ol.rs;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      float4 a = make_float4(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+      float4 b = make_float4(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+      if (accumulate) {                       // O already holds the residual (depthwise convolution of v, NystromAttention.py:144-145)
+        const float4 ra = *reinterpret_cast<const float4*>(op + d), rb = *reinterpret_cast<const float4*>(op + 32 + d);
+        a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w; b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+      }
+      *reinterpret_cast<float4*>(op + d) = a;
+      *reinterpret_cast<float4*>(op + 32 + d) = b;
+    }
+    if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1 (query owners): P^T recomputed from LSE2, dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ = scale dS K;
+// also writes delta = rowsum(dO . O) [BH, Lq] for pass 2.          grid (ceil(Lq / 128), BH)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                               const float* __restrict__ V, const float* __restrict__ O,
+                                                               const float* __restrict__ dO, const float* __restrict__ LSE2,
+                                                               float* __restrict__ dQ, float* __restrict__ DELTA, int Lq, int Lk,
+                                                               float qscale, float scale, OLayout ol, const float* __restrict__ R) {
+  typedef typename Pipe<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
+  __shared__ __attribute__((aligned(16))) T Kt[2][AK * TLD];
+  __shared__ __attribute__((aligned(16))) T Vr[2][AK * RLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.y;
+  const int q0 = blockIdx.x * (AQ * AW) + wave * AQ;
+  const bool qvalid = (q0 + c) < Lq;
+  const int qi = qvalid ? (q0 + c) : (Lq - 1);
+  const float* Kb = K + (size_t)bh * Lk * AD;
+  const float* Vb = V + (size_t)bh * Lk * AD;
+  x8 qf[4], dof[4];
+  float delta = 0.f;
+  {
+    const size_t off = ((size_t)bh * Lq + qi) * AD;
+    const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = row_frag<T>(Q + off, s, hf, qscale);
+      dof[s] = row_frag<T>(dO + oo, s, hf, 1.f);
+      const float4 t0 = *reinterpret_cast<const float4*>(dO + oo + 16 * s + 8 * hf), t1 = *reinterpret_cast<const float4*>(dO + oo + 16 * s + 8 * hf + 4);
+      float4 u0 = *reinterpret_cast<const float4*>(O + oo + 16 * s + 8 * hf), u1 = *reinterpret_cast<const float4*>(O + oo + 16 * s + 8 * hf + 4);
+      if (R) {            // the forward accumulated a residual into O: delta needs the attention output alone
+        const float4 r0 = *reinterpret_cast<const float4*>(R + oo + 16 * s + 8 * hf), r1 = *reinterpret_cast<const float4*>(R + oo + 16 * s + 8 * hf + 4);
+        u0.x -= r0.x; u0.y -= r0.y; u0.z -= r0.z; u0.w -= r0.w; u1.x -= r1.x; u1.y -= r1.y; u1.z -= r1.z; u1.w -= r1.w;
+      }
+      delta += t0.x * u0.x + t0.y * u0.y + t0.z * u0.z + t0.w * u0.w + t1.x * u1.x + t1.y * u1.y + t1.z * u1.z + t1.w * u1.w;
+    }
+  }
+  delta = xhalf_sum(delta);
+  const float lse2 = LSE2[(size_t)bh * Lq + qi];
+  if (qvalid && hf == 0) DELTA[(size_t)bh * Lq + qi] = delta;
+  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 kreg[2], vreg[2];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = j0 + skey + 16 * i;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
+      if (key < Lk) {
+        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * AD + sd4);
+        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * AD + sd4);
+      }
+    }
+  };
+  fetch(0);
+  floatx16 dq0 = {0}, dq1 = {0};
+  const int ntiles = (Lk + AK - 1) / AK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * AK, buf = kt & 1;
+    const int nk = min(AK, Lk - j0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = skey + 16 * i;
+      const uint2v kp = pack4<T>(kreg[i]);
+      *reinterpret_cast<uint2v*>(&Kr[buf][key * RLD + sd4]) = kp;
+      *reinterpret_cast<uint2v*>(&Kt[buf][key * TLD + sd4]) = kp;
+      *reinterpret_cast<uint2v*>(&Vr[buf][key * RLD + sd4]) = pack4<T>(vreg[i]);
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) fetch(j0 + AK);
+    floatx16 s = {0}, dp = {0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Kr[buf][c * RLD + 16 * st + 8 * hf]), qf[st], s);
+      dp = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Vr[buf][c * RLD + 16 * st + 8 * hf]), dof[st], dp);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (acc_row(r, hf) < nk) ? __builtin_amdgcn_exp2f(s[r] - lse2) : 0.f;
+      ds[r] = p * (dp[r] - delta);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float d8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d8[j] = ds[8 * kb + j];
+      const x8 db = pack8<T>(d8);
+      const int ro = (16 * kb + 4 * hf + trq) * TLD + trc;
+      dq0 = Pipe<T>::mfma(frag_tr<T>(&Kt[buf][ro], &Kt[buf][ro + 8 * TLD]), db, dq0);
+      dq1 = Pipe<T>::mfma(frag_tr<T>(&Kt[buf][ro + 32], &Kt[buf][ro + 32 + 8 * TLD]), db, dq1);
+    }
+  }
+  if (qvalid) {
+    float* qp = dQ + ((size_t)bh * Lq + qi) * AD;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(qp + d) = make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale, dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale);
+      *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale, dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2 (key owners): a wave owns 32 keys (key on the lane axis) and sweeps one slice of the query tiles:
+//   S = (qscale Q) K^T, P = exp2(S - LSE2[q]), dP = dO V^T, dS = P (dP - delta[q]),
+//   dV^T += dO^T P, dK^T += (qscale Q)^T dS  (times ln 2 at the end: qscale carries log2 e).
+// Partial sums of the query slices go to slabs [nparts][BH, Lk, 64] (nparts == 1: straight into dK / dV).
+//   grid (ceil(Lk / 128), nparts, BH)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                const float* __restrict__ V, const float* __restrict__ dO,
+                                                                const float* __restrict__ LSE2, const float* __restrict__ DELTA,
+                                                                float* __restrict__ dKp, float* __restrict__ dVp, int Lq, int Lk,
+                                                                float qscale, int tiles_per_part, size_t part_stride, OLayout ol) {
+  typedef typename Pipe<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) T Qr[2][AQ * RLD];
+  __shared__ __attribute__((aligned(16))) T Qt[2][AQ * TLD];
+  __shared__ __attribute__((aligned(16))) T Dr[2][AQ * RLD];
+  __shared__ __attribute__((aligned(16))) T Dt[2][AQ * TLD];
+  __shared__ __attribute__((aligned(16))) float lsd[2][2][AQ];     // [buf][lse2 | delta][query]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.z, part = blockIdx.y;
+  const int j0 = blockIdx.x * (AK * AW) + wave * AK;
+  const bool kvalid = (j0 + c) < Lk;
+  const int key = min(j0 + c, Lk - 1);
+  const bool wave_has_keys = j0 < Lk;
+  x8 kf[4], vf[4];
+  {
+    const size_t off = ((size_t)bh * Lk + key) * AD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = row_frag<T>(K + off, s, hf, 1.f); vf[s] = row_frag<T>(V + off, s, hf, 1.f); }
+  }
+  const int nqt = (Lq + AQ - 1) / AQ;
+  const int qt_begin = part * tiles_per_part, qt_end = min(qt_begin + tiles_per_part, nqt);
+  const int srow = tid >> 4, sd4 = (tid & 15) * 4;
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const float* Qb = Q + (size_t)bh * Lq * AD;
+  const float* dOb = dO + obase(ol, bh);
+  float4 qreg[2], dreg[2];
+  float lreg = 0.f, ereg = 0.f;
+  auto fetch = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = q0 + srow + 16 * i;
+      qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); dreg[i] = qreg[i];
+      if (row < Lq) {
+        qreg[i] = *reinterpret_cast<const float4*>(Qb + (size_t)row * AD + sd4);
+        dreg[i] = *reinterpret_cast<const float4*>(dOb + (size_t)row * ol.rs + sd4);
+      }
+    }
+    if (tid < AQ) {
+      const int row = min(q0 + tid, Lq - 1);
+      lreg = LSE2[(size_t)bh * Lq + row];
+      ereg = DELTA[(size_t)bh * Lq + row];
+    }
+  };
+  floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  if (qt_begin < qt_end) fetch(qt_begin * AQ);
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int q0 = qt * AQ, buf = (qt - qt_begin) & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow + 16 * i;
+      const float4 qs = make_float4(qreg[i].x * qscale, qreg[i].y * qscale, qreg[i].z * qscale, qreg[i].w * qscale);
+      const uint2v qp = pack4<T>(qs), dp = pack4<T>(dreg[i]);
+      *reinterpret_cast<uint2v*>(&Qr[buf][row * RLD + sd4]) = qp;
+      *reinterpret_cast<uint2v*>(&Qt[buf][row * TLD + sd4]) = qp;
+      *reinterpret_cast<uint2v*>(&Dr[buf][row * RLD + sd4]) = dp;
+      *reinterpret_cast<uint2v*>(&Dt[buf][row * TLD + sd4]) = dp;
+    }
+    if (tid < AQ) { lsd[buf][0][tid] = lreg; lsd[buf][1][tid] = ereg; }
+    __syncthreads();
+    if (qt + 1 < qt_end) fetch(q0 + AQ);
+    if (wave_has_keys) {                                   // wave-uniform
+      floatx16 s = {0}, dp = {0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Qr[buf][c * RLD + 16 * st + 8 * hf]), kf[st], s);
+        dp = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Dr[buf][c * RLD + 16 * st + 8 * hf]), vf[st], dp);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 l4 = *reinterpret_cast<const float4*>(&lsd[buf][0][8 * rg + 4 * hf]);     // broadcast reads
+        const float4 e4 = *reinterpret_cast<const float4*>(&lsd[buf][1][8 * rg + 4 * hf]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * rg + i;
+          const bool ok = kvalid && (q0 + acc_row(r, hf)) < Lq;
+          const float pv = ok ? __builtin_amdgcn_exp2f(s[r] - lv[i]) : 0.f;
+          p[r] = pv;
+          ds[r] = pv * (dp[r] - ev[i]);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float p8[8], d8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p8[j] = p[8 * kb + j]; d8[j] = ds[8 * kb + j]; }
+        const x8 pb = pack8<T>(p8), db = pack8<T>(d8);
+        const int ro = (16 * kb + 4 * hf + trq) * TLD + trc;
+        dv0 = Pipe<T>::mfma(frag_tr<T>(&Dt[buf][ro], &Dt[buf][ro + 8 * TLD]), pb, dv0);
+        dv1 = Pipe<T>::mfma(frag_tr<T>(&Dt[buf][ro + 32], &Dt[buf][ro + 32 + 8 * TLD]), pb, dv1);
+        dk0 = Pipe<T>::mfma(frag_tr<T>(&Qt[buf][ro], &Qt[buf][ro + 8 * TLD]), db, dk0);
+        dk1 = Pipe<T>::mfma(frag_tr<T>(&Qt[buf][ro + 32], &Qt[buf][ro + 32 + 8 * TLD]), db, dk1);
+      }
+    }
+  }
+  if (kvalid) {
+    const size_t off = (size_t)part * part_stride + ((size_t)bh * Lk + (j0 + c)) * AD;
+    float* kp = dKp + off;
+    float* vp = dVp + off;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(kp + d) = make_float4(dk0[4 * rg] * LN2_F, dk0[4 * rg + 1] * LN2_F, dk0[4 * rg + 2] * LN2_F, dk0[4 * rg + 3] * LN2_F);
+      *reinterpret_cast<float4*>(kp + 32 + d) = make_float4(dk1[4 * rg] * LN2_F, dk1[4 * rg + 1] * LN2_F, dk1[4 * rg + 2] * LN2_F, dk1[4 * rg + 3] * LN2_F);
+      *reinterpret_cast<float4*>(vp + d) = make_float4(dv0[4 * rg], dv0[4 * rg + 1], dv0[4 * rg + 2], dv0[4 * rg + 3]);
+      *reinterpret_cast<float4*>(vp + 32 + d) = make_float4(dv1[4 * rg], dv1[4 * rg + 1], dv1[4 * rg + 2], dv1[4 * rg + 3]);
+    }
+  }
+}
+
+// dK = sum_part dKp[part], dV = sum_part dVp[part] in a fixed order (n4 float4 elements per part)
+__global__ void attn16_reduce_kernel(const float4* __restrict__ dKp, const float4* __restrict__ dVp, float4* __restrict__ dK,
+                                     float4* __restrict__ dV, size_t n4, int nparts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 sk = dKp[i], sv = dVp[i];
+  for (int p = 1; p < nparts; ++p) {
+    const float4 a = dKp[(size_t)p * n4 + i], b = dVp[(size_t)p * n4 + i];
+    sk.x += a.x; sk.y += a.y; sk.z += a.z; sk.w += a.w;
+    sv.x += b.x; sv.y += b.y; sv.z += b.z; sv.w += b.w;
+  }
+  dK[i] = sk; dV[i] = sv;
+}
+
+// query slices of pass 2: enough workgroups to fill the chip a few times over, at most 32 slabs
+static int attn16_parts(int BH, int Lq, int Lk) {
+  const long base = (long)((Lk + AK * AW - 1) / (AK * AW)) * BH;
+  const int nqt = (Lq + AQ - 1) / AQ;
+  long parts = (1024 + base - 1) / base;
+  if (parts < 1) parts = 1;
+  if (parts > 32) parts = 32;
+  if (parts > nqt) parts = nqt;
+  return (int)parts;
+}
+
+}  // namespace
+
+extern "C" {
+
+// scratch of smml_attn16_bwd_f32: delta [BH, Lq] + the dK / dV slabs of the query slices
+size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk) {
+  if (BH <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  const int parts = attn16_parts(BH, Lq, Lk);
+  const size_t delta = ((size_t)BH * Lq + 3) & ~(size_t)3;
+  const size_t slabs = parts > 1 ? (size_t)2 * parts * BH * Lk * AD : 0;
+  return (delta + slabs) * sizeof(float);
+}
+
+static int attn16_layout(const char* fn, int BH, int Lq, int heads_merged, OLayout* ol) {
+  SMML_REQUIRE(heads_merged >= 0, "%s: heads_merged must be 0 (head-major output) or the number of heads", fn);
+  if (heads_merged == 0) { *ol = OLayout{(long long)Lq * AD, 0, AD, 1}; return SMML_OK; }      // bh / 1 = bh
+  SMML_REQUIRE(BH % heads_merged == 0, "%s: BH (%d) is not a multiple of the head count (%d)", fn, BH, heads_merged);
+  *ol = OLayout{(long long)Lq * heads_merged * AD, AD, (long long)heads_merged * AD, heads_merged};
+  return SMML_OK;
+}
+
+int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, int BH, int Lq, int Lk, int D,
+                        float scale, int use_fp16, int heads_merged, int accumulate, void* stream) {
+  SMML_REQUIRE(q && k && v && out && lse2, "smml_attn16_fwd_f32: null pointer");
+  SMML_REQUIRE(BH > 0 && BH <= 65535 && Lq > 0 && Lk > 0, "smml_attn16_fwd_f32: bad sizes (BH=%d Lq=%d Lk=%d)", BH, Lq, Lk);
+  SMML_REQUIRE(D == AD, "smml_attn16_fwd_f32: head dim must be %d (got %d)", AD, D);
+  OLayout ol;
+  int rc = attn16_layout("smml_attn16_fwd_f32", BH, Lq, heads_merged, &ol);
+  if (rc) return rc;
+  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH), block(256);
+  const float qscale = scale * LOG2E_F;
+  if (use_fp16) hipLaunchKernelGGL(attn16_fwd_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate);
+  else hipLaunchKernelGGL(attn16_fwd_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate);
+  SMML_LAUNCH_CHECK("smml_attn16_fwd_f32");
+  return SMML_OK;
+}
+
+int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* residual, const float* dout,
+                        const float* lse2, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, int BH, int Lq,
+                        int Lk, int D, float scale, int use_fp16, int heads_merged, void* stream) {
+  SMML_REQUIRE(q && k && v && out && dout && lse2 && dq && dk && dv && workspace, "smml_attn16_bwd_f32: null pointer");
+  SMML_REQUIRE(BH > 0 && BH <= 65535 && Lq > 0 && Lk > 0, "smml_attn16_bwd_f32: bad sizes (BH=%d Lq=%d Lk=%d)", BH, Lq, Lk);
+  SMML_REQUIRE(D == AD, "smml_attn16_bwd_f32: head dim must be %d (got %d)", AD, D);
+  SMML_REQUIRE(workspace_bytes >= smml_attn16_bwd_workspace_bytes(BH, Lq, Lk), "smml_attn16_bwd_f32: workspace too small");
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_attn16_bwd_f32: workspace must be 16-byte aligned");
+  OLayout ol;
+  int rc = attn16_layout("smml_attn16_bwd_f32", BH, Lq, heads_merged, &ol);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float qscale = scale * LOG2E_F;
+  float* delta = reinterpret_cast<float*>(workspace);
+  float* slabs = delta + (((size_t)BH * Lq + 3) & ~(size_t)3);
+  dim3 block(256);
+  dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH);
+  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dq_kernel<_Float16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq, delta, Lq, Lk, qscale, scale, ol, residual);
+  else hipLaunchKernelGGL(attn16_bwd_dq_kernel<__bf16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq, delta, Lq, Lk, qscale, scale, ol, residual);
+  SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dq");
+  const int parts = attn16_parts(BH, Lq, Lk);
+  const int nqt = (Lq + AQ - 1) / AQ, tpp = (nqt + parts - 1) / parts;
+  const size_t per = (size_t)BH * Lk * AD;
+  float* dkp = parts > 1 ? slabs : dk;
+  float* dvp = parts > 1 ? slabs + (size_t)parts * per : dv;
+  dim3 gk((Lk + AK * AW - 1) / (AK * AW), parts, BH);
+  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dkv_kernel<_Float16>, gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, tpp, per, ol);
+  else hipLaunchKernelGGL(attn16_bwd_dkv_kernel<__bf16>, gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, tpp, per, ol);
+  SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dkv");
+  if (parts > 1) {
+    const size_t n4 = per / 4;
+    hipLaunchKernelGGL(attn16_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(dkp),
+                       reinterpret_cast<const float4*>(dvp), reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts);
+    SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/reduce");
+  }
+  return SMML_OK;
+}
+
+}  // extern "C"

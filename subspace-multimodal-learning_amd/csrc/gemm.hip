@@ -316,15 +316,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 //   row-contiguous operand [k][rows + 32]    as it comes from memory (plain 8-byte stores); the MFMA fragment is gathered
 //                                            by two ds_read_b64_tr_b16 (hardware transpose, tests/microbench/tr_probe.hip)
 // ------------------------------------------------------------------------------------------------
-template <int BN_, bool A_KC, bool B_KC>
+// TERMS = 1 ("bf1"): only the leading bf16 term of each operand and one product - the plain bf16 matrix-pipe GEMM with fp32
+// storage and fp32 accumulation (8 mantissa bits per operand element), used by the 16-bit compute mode of the Nystrom block.
+template <int BN_, bool A_KC, bool B_KC, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
   constexpr int FBM = 128, FBK = 32, NI = BN_ / 64;            // NI 32-column blocks per wave
   constexpr int A_LD = A_KC ? (FBK + 8) : (FBM + 32);          // halves per row of a plane
   constexpr int B_LD = B_KC ? (FBK + 8) : (BN_ + 32);
   constexpr int A_PLANE = (A_KC ? FBM : FBK) * A_LD, B_PLANE = (B_KC ? BN_ : FBK) * B_LD;
   constexpr int NA = 4, NB = BN_ / 32;                         // float4 per thread per K-tile
-  __shared__ __attribute__((aligned(16))) __bf16 As[3 * A_PLANE];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * B_PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 As[TERMS * A_PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS * B_PLANE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int zb = blockIdx.z / g.splitk, ks = blockIdx.z - zb * g.splitk;
@@ -384,8 +386,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       uint2v h, m, l;
       split4_bf3(ra[i], h, m, l);
       *reinterpret_cast<uint2v*>(&As[off]) = h;
-      *reinterpret_cast<uint2v*>(&As[A_PLANE + off]) = m;
-      *reinterpret_cast<uint2v*>(&As[2 * A_PLANE + off]) = l;
+      if (TERMS == 3) {
+        *reinterpret_cast<uint2v*>(&As[A_PLANE + off]) = m;
+        *reinterpret_cast<uint2v*>(&As[2 * A_PLANE + off]) = l;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -395,8 +399,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       uint2v h, m, l;
       split4_bf3(rb[i], h, m, l);
       *reinterpret_cast<uint2v*>(&Bs[off]) = h;
-      *reinterpret_cast<uint2v*>(&Bs[B_PLANE + off]) = m;
-      *reinterpret_cast<uint2v*>(&Bs[2 * B_PLANE + off]) = l;
+      if (TERMS == 3) {
+        *reinterpret_cast<uint2v*>(&Bs[B_PLANE + off]) = m;
+        *reinterpret_cast<uint2v*>(&Bs[2 * B_PLANE + off]) = l;
+      }
     }
   };
 
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       for (int mi = 0; mi < 2; ++mi) {
         const int rbase = wm * 64 + mi * 32;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < TERMS; ++p) {
           if (A_KC) af[mi][p] = *reinterpret_cast<const bf16x8*>(&As[p * A_PLANE + (rbase + c) * A_LD + 16 * kb + 8 * hf]);
           else {
             const __bf16* q0 = &As[p * A_PLANE + (16 * kb + 8 * hf + trq) * A_LD + rbase + trc];
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       for (int ni = 0; ni < NI; ++ni) {
         const int cbase = wn * (BN_ / 2) + ni * 32;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < TERMS; ++p) {
           if (B_KC) bf[ni][p] = *reinterpret_cast<const bf16x8*>(&Bs[p * B_PLANE + (cbase + c) * B_LD + 16 * kb + 8 * hf]);
           else {
             const __bf16* q0 = &Bs[p * B_PLANE + (16 * kb + 8 * hf + trq) * B_LD + cbase + trc];
@@ -447,11 +453,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           floatx16 d = acc[mi][ni];
-          d = mfma16b(af[mi][1], bf[ni][1], d);     // smallest terms first
-          d = mfma16b(af[mi][2], bf[ni][0], d);
-          d = mfma16b(af[mi][0], bf[ni][2], d);
-          d = mfma16b(af[mi][1], bf[ni][0], d);
-          d = mfma16b(af[mi][0], bf[ni][1], d);
+          if (TERMS == 3) {
+            d = mfma16b(af[mi][1], bf[ni][1], d);     // smallest terms first
+            d = mfma16b(af[mi][2], bf[ni][0], d);
+            d = mfma16b(af[mi][0], bf[ni][2], d);
+            d = mfma16b(af[mi][1], bf[ni][0], d);
+            d = mfma16b(af[mi][0], bf[ni][1], d);
+          }
           d = mfma16b(af[mi][0], bf[ni][0], d);
           acc[mi][ni] = d;
         }
@@ -487,9 +495,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
 }  // namespace
 
 static int g_force_generic = 0;   // test hook: route everything through the generic kernel
-static int g_mode = 0;            // 0: automatic, 1: fp32-MFMA tiled kernel only, 2: split-bf16 kernel wherever it applies
+static int g_mode = 0;            // 0: automatic, 1: fp32-MFMA tiled kernel only, 2: split-bf16 kernel wherever it applies,
+                                  // 3: single-term bf16 kernel wherever it applies (16-bit compute mode: 8-bit operand mantissas)
 extern "C" void smml_gemm_force_generic(int on) { g_force_generic = on; }
 extern "C" void smml_gemm_set_mode(int mode) { g_mode = mode; }
+extern "C" int smml_gemm_get_mode(void) { return g_mode; }
 
 extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                              int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
@@ -538,9 +548,11 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
     // (SMML_GEMM_MODE=1 vs automatic with that wider rule), the step is not faster (17.2 / 17.5 vs 17.6 / 17.5 ms) and
     // the errors against the oracle grow 2x.  So the automatic choice keeps it for large square-ish products only.
     const bool bf3 = (g_mode == 2) || (g_mode == 0 && K >= 2048 && M >= 1024 && N >= 1024);
+    const bool bf1 = (g_mode == 3);
 #define SMML_FAST(BNV, AK, BK2)                                                                   \
   do {                                                                                            \
-    if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g);      \
+    if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2, 1>), grid, dim3(256), 0, st, g);   \
+    else if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_fast_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g);     \
   } while (0)
     if (bn == 128) {

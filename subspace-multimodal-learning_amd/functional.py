@@ -106,6 +106,23 @@ def _gemm(A, B, C, *, M, N, K, sam, sak, sbk, sbn, ldc, bias=None, bias_mode=0, 
         bias_mode, rows_per_bias, bias_ld, act, splitk, accumulate, float(alpha), float(beta), capi.stream()), "gemm")
 
 
+class _prec:
+    """GEMM precision mode (include/smml.h smml_gemm_set_mode) for the launches issued inside the block; mode 0 / None = leave."""
+
+    def __init__(self, mode):
+        self.mode = int(mode or 0)
+
+    def __enter__(self):
+        if self.mode:
+            L = capi.lib()
+            self.prev = L.smml_gemm_get_mode()
+            L.smml_gemm_set_mode(self.mode)
+
+    def __exit__(self, *a):
+        if self.mode:
+            capi.lib().smml_gemm_set_mode(self.prev)
+
+
 def _splitk_for(out_rows: int, out_cols: int, k: int, batches: int = 1) -> int:
     tiles = ((out_rows + 127) // 128) * ((out_cols + 63) // 64) * batches
     want = max(1, 1024 // max(tiles, 1))
@@ -126,8 +143,9 @@ def colsum(x2d_or_3d: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, rows_per_bias, residual):
+    def forward(ctx, x, weight, bias, act, rows_per_bias, residual, prec=0):
         x = _c(x); weight = _c(weight)
+        ctx.prec = prec
         K = x.shape[-1]
         M = x.numel() // K
         N = weight.shape[0]
@@ -137,8 +155,9 @@ class _Linear(torch.autograd.Function):
             bias = _c(bias)
             bias_mode = 2 if bias.dim() == 2 else 1
         res = _c(residual) if residual is not None else None
-        _gemm(x, weight, y, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, bias=bias, bias_mode=bias_mode,
-              rows_per_bias=rows_per_bias, bias_ld=N, residual=res, ldr=N, act=act)
+        with _prec(prec):
+            _gemm(x, weight, y, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, bias=bias, bias_mode=bias_mode,
+                  rows_per_bias=rows_per_bias, bias_ld=N, residual=res, ldr=N, act=act)
         ctx.act, ctx.rows_per_bias, ctx.bias_mode = act, rows_per_bias, bias_mode
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -161,22 +180,25 @@ class _Linear(torch.autograd.Function):
         else:
             dpre = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _gemm(dpre, weight, dx, M=M, N=K, K=N, sam=N, sak=1, sbk=K, sbn=1, ldc=K)
-        if ctx.needs_input_grad[1]:
-            dw = _zeros_like(weight)
-            _gemm(dpre, x, dw, M=N, N=K, K=M, sam=1, sak=N, sbk=K, sbn=1, ldc=K, splitk=_splitk_for(N, K, M))
+        with _prec(ctx.prec):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _gemm(dpre, weight, dx, M=M, N=K, K=N, sam=N, sak=1, sbk=K, sbn=1, ldc=K)
+            if ctx.needs_input_grad[1]:
+                dw = _zeros_like(weight)
+                _gemm(dpre, x, dw, M=N, N=K, K=M, sam=1, sak=N, sbk=K, sbn=1, ldc=K, splitk=_splitk_for(N, K, M))
         if ctx.bias_mode and ctx.needs_input_grad[2]:
             if ctx.bias_mode == 1:
                 db = colsum(dpre.reshape(1, M, N))[0]
             else:
                 db = colsum(dpre.reshape(M // ctx.rows_per_bias, ctx.rows_per_bias, N))
-        return dx, dw, db, None, None, dres
+        return dx, dw, db, None, None, dres, None
 
 
-def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, residual=None):
-    return _Linear.apply(x, weight, bias, act, rows_per_bias, residual)
+def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, residual=None, prec: int = 0):
+    """act(x W^T + bias) (+ residual).  prec: GEMM precision mode of the forward and backward products (0 automatic / exact
+    fp32, 2 three-term split bf16, 3 single-term bf16 operands - the 16-bit compute mode)."""
+    return _Linear.apply(x, weight, bias, act, rows_per_bias, residual, prec)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -609,6 +631,75 @@ def matmul4(A, B, R=None, *, ta=False, tb=False, alpha=1.0, beta=1.0, merged=Fal
     """alpha * op(A) @ op(B) + beta * R for [nb0, nb1, rows, cols] tensors (size-1 batch dims broadcast);
     merged=True lays the result out as [nb0, M, nb1 * N] (heads merged)."""
     return _MatMul.apply(A, B, R, ta, tb, alpha, beta, merged)
+
+
+class gemm_precision:
+    """with gemm_precision(3): ...  - every tiled product launched inside runs with single-term bf16 operands (fp32 storage and
+    accumulation); 2 = three-term split (fp32-grade); 0 restores the automatic choice.  Kernel selection happens on the host at
+    launch time, so the switch covers exactly the launches issued inside the block (linear(..., prec=mode) re-enters it in its
+    backward, so that the gradient products use the same operand precision as the forward one)."""
+
+    def __init__(self, mode: int):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        L = capi.lib()
+        self.prev = L.smml_gemm_get_mode()
+        L.smml_gemm_set_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        capi.lib().smml_gemm_set_mode(self.prev)
+
+
+class _Attention16(torch.autograd.Function):
+    """softmax(scale q k^T) v (+ residual) on the 16-bit matrix pipe, fp32 storage (csrc/attn16.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, residual, scale, fp16, merged):
+        q, k, v = _c(q), _c(k), _c(v)
+        Bn, H, Lq, D = q.shape
+        Lk = k.shape[2]
+        if D != 64 or k.shape != (Bn, H, Lk, D) or v.shape != (Bn, H, Lk, D):
+            raise RuntimeError("attention16: q [B, h, Lq, 64], k / v [B, h, Lk, 64] expected")
+        if residual is not None:
+            if not merged or tuple(residual.shape) != (Bn, Lq, H * D):
+                raise RuntimeError("attention16: the residual is added in the heads-merged layout [B, Lq, h * 64]")
+            out = _c(residual).clone()
+        else:
+            out = torch.empty((Bn, Lq, H * D) if merged else (Bn, H, Lq, D), device=q.device, dtype=torch.float32)
+        lse2 = torch.empty(Bn * H, Lq, device=q.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_attn16_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(out), capi.fptr(lse2), Bn * H, Lq,
+                                                  Lk, D, float(scale), int(bool(fp16)), H if merged else 0,
+                                                  1 if residual is not None else 0, capi.stream()), "attn16_fwd")
+        ctx.cfg = (float(scale), int(bool(fp16)), H if merged else 0, residual is not None)
+        ctx.save_for_backward(q, k, v, out, lse2, _c(residual) if residual is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse2, residual = ctx.saved_tensors
+        scale, fp16, merged, has_res = ctx.cfg
+        Bn, H, Lq, D = q.shape
+        Lk = k.shape[2]
+        dout = _c(dout)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        L = capi.lib()
+        wsb = L.smml_attn16_bwd_workspace_bytes(Bn * H, Lq, Lk)
+        ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
+        capi.check(L.smml_attn16_bwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(out), capi.fptr(residual), capi.fptr(dout),
+                                         capi.fptr(lse2), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(ws), wsb, Bn * H, Lq, Lk,
+                                         D, scale, fp16, merged, capi.stream()), "attn16_bwd")
+        return dq, dk, dv, (dout if has_res else None), None, None, None
+
+
+def attention16(q, k, v, *, scale: float, fp16: bool = False, merged: bool = False, residual=None):
+    """softmax(scale q k^T) v for q [B, h, Lq, 64], k / v [B, h, Lk, 64] with bf16 (or fp16) matrix-pipe operands and fp32
+    accumulation; no [Lq, Lk] matrix is materialised.  merged=True returns [B, Lq, h * 64]; `residual` (that layout) is added."""
+    return _Attention16.apply(q, k, v, residual, scale, fp16, merged)
+
+
+NYSTROM_PIPE = "f32"          # set by the Nystrom block's 16-bit compute mode (bench.py reads it to pick the roofline peak)
 
 
 class _SoftmaxRows(torch.autograd.Function):

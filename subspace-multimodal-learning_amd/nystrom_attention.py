@@ -11,7 +11,17 @@ similarity products, the six Newton-Schulz iterations of the pseudo-inverse writ
 epilogues, (attn1 z)(attn3 v), output projection) runs on the matrix cores through smml_gemm_f32; softmax,
 landmark means, the 33-tap residual convolution and PPEG's merged 7x7 depthwise pass are HBM-bound kernels.
 Kept as in the reference: zero padding in FRONT of the sequence (:82), the batch-global max in the
-pseudo-inverse initialisation (:26).  Not built: the `mask` argument (no caller in the reference passes it)."""
+pseudo-inverse initialisation (:26).  Not built: the `mask` argument (no caller in the reference passes it).
+
+16-bit compute mode (BASELINE configs 2 / 4 / 5 quote bf16 / fp16 bags): `compute_dtype` 'bf16' / 'fp16', or a bag that
+arrives in that dtype, routes the n'-sized contractions to the 16-bit matrix pipe with fp32 storage and accumulation:
+  * softmax(q kl^T) and softmax(ql k^T) v become two calls of the fused attention kernel (csrc/attn16.hip): the [n', m] and
+    [m, n'] probability matrices are never written, out = attn1 (z (attn3 v)) replaces (attn1 z)(attn3 v) (same value, the
+    [n', m] x [m, m] product becomes [m, m] x [m, d]);
+  * the qkv / output projections run with single-term bf16 operands (bf16 mode; fp16 mode keeps them exact);
+  * the m x m part - sim2, its softmax and the Newton-Schulz iteration - stays exact fp32 (it is precision-fragile and small).
+Accuracy of that mode: bf16 ~ 1e-2, fp16 ~ 2e-3 of a tensor's scale (8 / 11 mantissa bits on the operands); the default
+fp32 path is unchanged and is what the 1e-4 parity tests cover."""
 from __future__ import annotations
 
 import math
@@ -46,9 +56,12 @@ def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
 
 class NystromAttention(nn.Module):
     def __init__(self, dim, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True,
-                 residual_conv_kernel=33, eps=1e-8, dropout=0., per_bag_pinv_scale: bool = False):
+                 residual_conv_kernel=33, eps=1e-8, dropout=0., per_bag_pinv_scale: bool = False, compute_dtype=None):
         super().__init__()
         self.eps = eps
+        if compute_dtype not in (None, "fp32", "bf16", "fp16"):
+            raise ValueError("compute_dtype must be None (follow the bag's dtype), 'fp32', 'bf16' or 'fp16'")
+        self.compute_dtype = compute_dtype
         self.per_bag_pinv_scale = bool(per_bag_pinv_scale)     # corrected semantics (off by default), see moore_penrose_iter_pinv
         inner_dim = heads * dim_head
         self.num_landmarks = num_landmarks
@@ -69,6 +82,9 @@ class NystromAttention(nn.Module):
             raise NotImplementedError("the mask argument is not built on the HIP path (no caller in the reference uses it)")
         b, n, dim = x.shape
         h, m, d = self.heads, self.num_landmarks, self.dim_head
+        mode = self.compute_dtype or {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(x.dtype, "fp32")
+        if mode != "fp32" and d == 64 and not return_attn:
+            return self._forward16(x, mode == "fp16")
         pad = (m - n % m) % m
         if pad:
             x = F.pad(x, (0, 0, pad, 0), value=0)              # zero rows in FRONT (:82)
@@ -95,6 +111,34 @@ class NystromAttention(nn.Module):
             attn = Fh.matmul4(left, a3)
             return out, attn
         return out
+
+
+    def _forward16(self, x, fp16: bool):
+        """16-bit compute mode (module docstring): same op order as forward() up to the re-association of the output product."""
+        b, n, dim = x.shape
+        h, m, d = self.heads, self.num_landmarks, self.dim_head
+        Fh.NYSTROM_PIPE = "f16" if fp16 else "bf16"
+        pad = (m - n % m) % m
+        x = x.float()
+        if pad:
+            x = F.pad(x, (0, 0, pad, 0), value=0)
+        npad = n + pad
+        l = math.ceil(n / m)
+        gm = 0 if fp16 else 3                                   # projections: exact in fp16 mode, single-term bf16 in bf16 mode
+        qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
+        q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
+        ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
+        sc = self.scale
+        a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
+        z = moore_penrose_iter_pinv(a2, self.pinv_iterations, self.per_bag_pinv_scale)
+        right = Fh.attention16(ql, k, v, scale=sc, fp16=fp16)                                  # softmax(ql k^T) v   [b, h, m, d]
+        w = Fh.matmul4(z, right)                                                               # z (attn3 v)          [b, h, m, d]
+        res = Fh.resconv(v, self.res_conv.weight) if self.residual else None                   # [b, n', h d]
+        out = Fh.attention16(q, kl, w, scale=sc, fp16=fp16, merged=True, residual=res)         # softmax(q kl^T) w + res
+        wo, bo = self.to_out[0].weight, self.to_out[0].bias
+        out = Fh.linear(out, wo, bo, prec=gm)
+        out = self.to_out[1](out)
+        return out[:, -n:]
 
 
 class TransLayer(nn.Module):

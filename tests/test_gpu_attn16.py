@@ -1,0 +1,112 @@
+"""GPU: the 16-bit matrix-pipe attention kernels (csrc/attn16.hip) and the 16-bit compute mode of the Nystrom block.
+
+Tolerances per dtype (stated, not calibrated): operands are rounded to bf16 (8 significand bits, relative rounding 2^-9 = 2e-3
+per element) or fp16 (11 bits, 2^-12 = 2.4e-4), products accumulate in fp32.  A softmax-weighted average of K such roundings
+lands at BF16_TOL = 1.5e-2 / FP16_TOL = 2e-3 of the tensor's scale for outputs and gradients (max-norm); l2 errors are ~4x
+smaller.  The fp32 path keeps the 1e-4 gate of tests/helpers.py."""
+import pytest
+import torch
+
+import helpers
+from helpers import assert_close, l2_err, params_for, rel_err, smml, synth
+from oracle.nystrom import nystrom_attention
+from test_gpu_parity import _load
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+TOL = {False: 1.5e-2, True: 2e-3}      # [fp16]
+
+
+def _ref_attention(q, k, v, scale, residual=None, merged=False):
+    s = (q @ k.transpose(-1, -2)) * scale
+    o = torch.softmax(s, dim=-1) @ v
+    if merged:
+        B, H, L, D = o.shape
+        o = o.permute(0, 2, 1, 3).reshape(B, L, H * D)
+        if residual is not None:
+            o = o + residual
+    return o
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 1, 1), (2, 3, 33, 70), (1, 8, 300, 256), (2, 8, 256, 1000), (1, 2, 129, 31), (1, 1, 2000, 16)])
+def test_attention16_vs_fp64(cuda, fp16, B, H, Lq, Lk):
+    """Ragged query / key counts (partial tiles, a single key, more query slices than tiles), head-major output."""
+    gen = torch.Generator().manual_seed(Lq * 1000 + Lk)
+    q = torch.randn(B, H, Lq, 64, generator=gen); k = torch.randn(B, H, Lk, 64, generator=gen); v = torch.randn(B, H, Lk, 64, generator=gen)
+    wo = torch.randn(B, H, Lq, 64, generator=gen)
+    ref = [t.clone().double().requires_grad_() for t in (q, k, v)]
+    o64 = _ref_attention(*ref, 0.125)
+    (o64 * wo.double()).sum().backward()
+    dev = [t.clone().to(cuda).requires_grad_() for t in (q, k, v)]
+    o = Fh.attention16(*dev, scale=0.125, fp16=fp16)
+    (o * wo.to(cuda)).sum().backward()
+    tol = TOL[fp16]
+    tag = f"attn16[{'f16' if fp16 else 'bf16'}] {B}x{H}x{Lq}x{Lk}"
+    assert_close(tag + " out", o, o64, tol)
+    for n, a, b in zip("qkv", dev, ref):
+        if float(b.grad.abs().max()) < 1e-12:                     # one key: d q = scale P (dP - delta) k is exactly 0; what is left is
+            assert float(a.grad.abs().max()) < 4 * tol            # the operand rounding of dP = V dO^T against delta = dO . O (|dP| ~ 8)
+            continue
+        assert_close(tag + " d" + n, a.grad, b.grad, tol)
+        assert l2_err(a.grad, b.grad) <= tol / 2
+
+
+def test_attention16_merged_layout_and_residual(cuda):
+    gen = torch.Generator().manual_seed(5)
+    B, H, Lq, Lk = 2, 8, 200, 96
+    q = torch.randn(B, H, Lq, 64, generator=gen); k = torch.randn(B, H, Lk, 64, generator=gen); v = torch.randn(B, H, Lk, 64, generator=gen)
+    res = torch.randn(B, Lq, H * 64, generator=gen); wo = torch.randn(B, Lq, H * 64, generator=gen)
+    ref = [t.clone().double().requires_grad_() for t in (q, k, v, res)]
+    o64 = _ref_attention(ref[0], ref[1], ref[2], 0.125, ref[3], merged=True)
+    (o64 * wo.double()).sum().backward()
+    dev = [t.clone().to(cuda).requires_grad_() for t in (q, k, v, res)]
+    o = Fh.attention16(dev[0], dev[1], dev[2], scale=0.125, fp16=True, merged=True, residual=dev[3])
+    (o * wo.to(cuda)).sum().backward()
+    assert_close("attn16 merged out", o, o64, TOL[True])
+    for n, a, b in zip(("q", "k", "v"), dev, ref):
+        assert_close("attn16 merged d" + n, a.grad, b.grad, TOL[True])
+    assert torch.equal(dev[3].grad.cpu(), wo)                     # the residual's gradient is the incoming one, untouched
+    assert torch.equal(res, dev[3].detach().cpu())               # and the residual itself is not modified in place
+
+
+@pytest.mark.parametrize("mode,B,n", [("bf16", 2, 1000), ("fp16", 1, 4096), ("bf16", 1, 300)])
+def test_nystrom_16bit_mode_vs_oracle(cuda, mode, B, n):
+    """NystromAttention(compute_dtype=...) against the fp64 oracle, tolerance per dtype; the same module in its default
+    fp32 mode stays within 1e-4 on the same inputs (the two modes share every parameter)."""
+    tag = f"nys16:{mode}:{B}:{n}"
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256, dropout=0.1, compute_dtype=mode)
+    params = params_for(mod, 41, tag)
+    mod = _load(mod, params, cuda)
+    x = synth.normal((B, n, 512), 41, tag + ":x") * 0.5
+    wo = synth.normal((B, n, 512), 41, tag + ":wo")
+    pr = {k: v.clone().double().requires_grad_() for k, v in params.items()}
+    xr = x.clone().double().requires_grad_()
+    o64 = nystrom_attention(xr, pr, heads=8, dim_head=64, num_landmarks=256)
+    (o64 * wo.double()).sum().backward()
+    xd = x.to(cuda).requires_grad_()
+    out = mod(xd)
+    (out * wo.to(cuda)).sum().backward()
+    tol = TOL[mode == "fp16"]
+    assert Fh.NYSTROM_PIPE == ("f16" if mode == "fp16" else "bf16")
+    assert_close(tag + " out", out, o64, tol)
+    assert_close(tag + " dx", xd.grad, xr.grad, tol)
+    for k, p in mod.named_parameters():
+        assert_close(tag + " d" + k, p.grad, pr[k].grad, 2 * tol)      # weight gradients sum B n' rounded products
+    mod32 = _load(smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256, dropout=0.1), params, cuda)
+    with torch.no_grad():
+        assert_close(tag + " fp32 mode out", mod32(x.to(cuda)), o64, 1e-4)
+
+
+def test_nystrom_16bit_mode_follows_the_bag_dtype(cuda):
+    """A bf16 / fp16 bag selects the 16-bit compute mode (BASELINE configs 2, 5); compute_dtype='fp32' keeps the exact path."""
+    torch.manual_seed(0)
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(cuda).eval()
+    x = torch.randn(1, 700, 512, device=cuda) * 0.5
+    with torch.no_grad():
+        ref = mod(x)
+        o16 = mod(x.to(torch.bfloat16))
+        assert o16.dtype == torch.float32 and Fh.NYSTROM_PIPE == "bf16"
+        assert rel_err(o16, ref) < 3e-2 and not torch.equal(o16, ref)
+        mod.compute_dtype = "fp32"
+        assert torch.equal(mod(x.to(torch.bfloat16)), mod(x.to(torch.bfloat16).float()))

@@ -36,21 +36,27 @@ def _nystrom_vs_oracle(cuda, tag, B, n, in_dtype=torch.float32, seed=21):
     out = mod(xd)
     (out.float() * wo.to(cuda)).sum().backward()
     r32, r64 = run[torch.float32], run[torch.float64]
-    assert_calibrated(tag + " out", out, r32[0], r64[0])
     if in_dtype == torch.float32:
+        assert_calibrated(tag + " out", out, r32[0], r64[0])
         assert_calibrated(tag + " dx", xd.grad, r32[1], r64[1])
-    else:   # the gradient is returned in the bag's dtype: one rounding to 8 / 11 bits on top of the fp32 result
+        for k, p in mod.named_parameters():
+            assert_calibrated(tag + " d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
+    else:
+        # a 16-bit bag selects the 16-bit compute mode of the block (operands rounded to bf16 / fp16 on the matrix pipe, fp32
+        # accumulation): tolerance per dtype as stated in tests/test_gpu_attn16.py; the gradient comes back in the bag's dtype
+        tol = 1e-2 if in_dtype == torch.bfloat16 else 2e-3
         assert xd.grad.dtype == in_dtype
-        eps = 2.0 ** -8 if in_dtype == torch.bfloat16 else 2.0 ** -11
-        assert_close(tag + " dx (16-bit)", xd.grad.float(), r64[1], 1e-4 + eps)
-    for k, p in mod.named_parameters():
-        assert_calibrated(tag + " d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
+        assert_close(tag + " out (16-bit mode)", out, r64[0], tol)
+        assert_close(tag + " dx (16-bit mode)", xd.grad.float(), r64[1], tol + (2.0 ** -8 if in_dtype == torch.bfloat16 else 2.0 ** -11))
+        for k, p in mod.named_parameters():
+            assert_close(tag + " d" + k + " (16-bit mode)", p.grad, r64[2][k].grad, 2 * tol)
 
 
 @pytest.mark.parametrize("B,in_dtype", [(1, torch.float32), (2, torch.bfloat16)])
 def test_cfg2_nystrom_4096x512_m256(cuda, B, in_dtype):
-    """BASELINE config 2: NystromAttention fwd + bwd, bag 4096 x 512, 256 landmarks (l = 16, no padding), fp32 bag and bf16 bag
-    (two bags: the batch-global max of the pseudo-inverse initialisation couples them, NystromAttention.py:26)."""
+    """BASELINE config 2: NystromAttention fwd + bwd, bag 4096 x 512, 256 landmarks (l = 16, no padding): the fp32 bag on the
+    exact path (1e-4 gate) and the bf16 bag the config names on the 16-bit matrix pipe (two bags: the batch-global max of the
+    pseudo-inverse initialisation couples them, NystromAttention.py:26)."""
     _nystrom_vs_oracle(cuda, f"cfg2:{B}:{in_dtype}", B, 4096, in_dtype)
 
 

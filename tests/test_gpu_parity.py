@@ -50,12 +50,20 @@ class cpb_probe:
     def scale(self, tensor):
         return self.d.get(id(tensor), 0.0)
 
+    def boundary_margin(self):
+        """Smallest distance of a sample position's pixel coordinate to an integer (any oracle run inside the block)."""
+        return self.d.get("boundary", 1.0)
+
 
 def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
     """Every parameter gradient against the oracle (all tensors are compared and recorded before the first failure is
     raised).  `rel_pos_bias.mlp.2.bias` is exactly zero in exact arithmetic (softmax shift invariance): it must stay below
     1e-4 x its natural scale sum |d bias| (collected by `probe` from the fp64 run)."""
     failures = []
+    # a sample position within fp32 rounding of a pixel boundary (|ix - round(ix)| of the order of ulp(ix)): its position gradient
+    # takes the slope of one of two cells and fp32 arithmetic does not determine which (F.grid_sample's kink) - every gradient
+    # upstream of the sample positions then carries a finite, legitimate jump; such inputs only get a sanity bound
+    undecidable = probe is not None and probe.boundary_margin() < 2e-5
     for k, p in mod.named_parameters():
         if k.endswith(skip):
             continue
@@ -68,7 +76,12 @@ def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
                 continue
             assert p.grad is not None, f"missing grad for {k}"
-            _calibrated("d" + k, p.grad, p32[k].grad, p64[k].grad)
+            if undecidable:
+                e2 = l2_err(p.grad, p64[k].grad)
+                helpers.record("d" + k, e2, l2_err(p32[k].grad, p64[k].grad), 2e-2, "l2,sample-on-cell-boundary")
+                assert e2 <= 2e-2, f"d{k}: l2 err {e2:.3e} > 2e-2 (sanity bound: a sample position lies on a cell boundary)"
+            else:
+                _calibrated("d" + k, p.grad, p32[k].grad, p64[k].grad)
         except AssertionError as e:
             failures.append(str(e).split("\n")[0])
     assert not failures, f"{len(failures)} parameter gradients out of tolerance:\n  " + "\n  ".join(failures)
