@@ -105,12 +105,14 @@ def cpu_baseline(pkg, in_dim, S, seconds_budget=90.0):
                       f"after 1 warm-up, {dt:.2f} s/bag, torch.set_num_threads({cores})"}
 
 
-def nystrom_leg(pkg, dev, B, n, steps=10, warmup=3):
-    """NystromAttention(dim 512, 8 heads x 64, 256 landmarks) forward + backward on B bags of n x 512 (BASELINE config 2 shape
-    and the N = 10 000 bag): ms per step from HIP events on the launch stream, algorithmic flops per SURVEY.md 8(d)."""
+def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
+    """NystromAttention(dim 512, 8 heads x 64, 256 landmarks) forward + backward on B bags of n x 512 in `dtype` (BASELINE config
+    2 shape and the N = 10 000 bag; a bf16 / fp16 bag selects the block's 16-bit compute mode): ms per step from HIP events on
+    the launch stream, algorithmic flops per SURVEY.md 8(d)."""
     torch.manual_seed(7)
     mod = pkg.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(dev).eval()
-    x = (torch.randn(B, n, 512, device=dev) * 0.5).requires_grad_()
+    pkg.functional.NYSTROM_PIPE = "f32"
+    x = (torch.randn(B, n, 512, device=dev) * 0.5).to(dtype).requires_grad_()
 
     def step():
         mod.zero_grad(set_to_none=True); x.grad = None
@@ -128,7 +130,7 @@ def nystrom_leg(pkg, dev, B, n, steps=10, warmup=3):
     tf = 3 * total * B / (ms * 1e-3) / 1e12
     pipe = getattr(pkg.functional, "NYSTROM_PIPE", "f32")            # which matrix pipe the contractions issue on
     peak = F16_MFMA_PEAK_TFLOPS if pipe != "f32" else F32_MFMA_PEAK_TFLOPS
-    return {"workload": f"NystromAttention fwd+bwd, {B} x {n} x 512, 256 landmarks", "ms_per_step": ms, "bags_per_s": B / (ms * 1e-3),
+    return {"workload": f"NystromAttention fwd+bwd, {B} x {n} x 512 {str(dtype).replace('torch.', '')}, 256 landmarks", "ms_per_step": ms, "bags_per_s": B / (ms * 1e-3),
             "algorithmic_TFLOPs": tf, "pipe": pipe, "peak_TFLOPs": peak, "frac": tf / peak,
             "qkav_share_of_flops": qkav / total}
 
@@ -254,7 +256,8 @@ def main():
                                            f"MFMA peak; {CPB_FWD_MFMAS} 16-bit MFMAs + ~145 vector instructions per (key, 32 queries)"}
         if world == 1 and not a.no_nystrom:
             # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`)
-            out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096), nystrom_leg(pkg, dev, 4, 10000)]
+            out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
+                              nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, in_dim, S)
         print(json.dumps(out))

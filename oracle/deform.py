@@ -48,6 +48,7 @@ def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.") -> torc
     if GRAD_PROBE is not None and out.requires_grad:
         key = id(p[prefix + "mlp.2.bias"])
         probe = GRAD_PROBE
+        probe["cpb_units"] = probe.get("cpb_units", 0) + 2 * h.numel()       # ReLU units evaluated (both hidden layers)
 
         def _hook(g, key=key, probe=probe):
             probe[key] = probe.get(key, 0.0) + float(g.detach().abs().sum())
@@ -84,9 +85,13 @@ def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int):
     if GRAD_PROBE is not None:
         # bilinear interpolation has a kink at integer pixel coordinates: where a sample position lies within fp32 rounding of
         # one, no fp32 evaluation determines which cell's slope the position gradient takes.  Tests read this margin.
-        with torch.no_grad():
-            d = torch.minimum((ix - torch.round(ix)).abs().min(), (iy - torch.round(iy)).abs().min() if H > 1 else ix.new_tensor(1.0))
-            GRAD_PROBE["boundary"] = min(GRAD_PROBE.get("boundary", 1.0), float(d))
+        with torch.no_grad():      # only coordinates that carry a gradient matter (the 1-D module's y coordinate is the constant 0)
+            d = 1.0
+            if vx.requires_grad:
+                d = min(d, float((ix - torch.round(ix)).abs().min()))
+            if vy.requires_grad:
+                d = min(d, float((iy - torch.round(iy)).abs().min()))
+            GRAD_PROBE["boundary"] = min(GRAD_PROBE.get("boundary", 1.0), d)
     x0f, y0f = torch.floor(ix), torch.floor(iy)
     x0, y0 = x0f.to(torch.int64), y0f.to(torch.int64)
     x1, y1 = x0 + 1, y0 + 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box trip: parity tests, smoke, a short bench, and a rocprofv3 kernel-trace of the same bench.
-# Steps after a timeout / kill (exit 124 / 137) are skipped: a hung GPU must not be hit again.
+# Steps after a timeout or a death by signal (exit 124 or >= 128) are skipped: a hung or faulted GPU must not be hit again.
 set -u
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
@@ -8,7 +8,9 @@ run() {  # name, timeout, cmd...
   local name=$1 t=$2; shift 2
   echo "=== $name"; timeout -k 10 "$t" "$@" > "gpurun_out/$name.log" 2>&1; local rc=$?
   echo "rc=$rc"; tail -n "${TAILN:-25}" "gpurun_out/$name.log"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "!!! $name timed out / killed: stopping"; exit $rc; fi
+  # a timeout (124) or any death by signal (>= 128: 134 abort, 137 kill, 139 segfault after a GPU memory fault) leaves the GPU in an
+  # unknown state: nothing else is started on it, the tail of the log above is the evidence
+  if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "!!! $name timed out or died by signal (rc $rc): stopping"; exit $rc; fi
   return $rc
 }
 run pytest_gpu 900 python -m pytest tests -m gpu -q -x ${PYTEST_ARGS:-}

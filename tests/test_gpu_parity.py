@@ -50,9 +50,19 @@ class cpb_probe:
     def scale(self, tensor):
         return self.d.get(id(tensor), 0.0)
 
+    def cpb_units(self):
+        """ReLU units of the position-bias MLP evaluated by the oracle runs inside the block (fp32 + fp64 runs: twice the
+        problem's count)."""
+        return self.d.get("cpb_units", 0)
+
     def boundary_margin(self):
         """Smallest distance of a sample position's pixel coordinate to an integer (any oracle run inside the block)."""
         return self.d.get("boundary", 1.0)
+
+
+CPB_PARAMS = ("rel_pos_bias.mlp.0.0.weight", "rel_pos_bias.mlp.0.0.bias", "rel_pos_bias.mlp.1.0.weight", "rel_pos_bias.mlp.1.0.bias",
+              "rel_pos_bias.mlp.2.weight")
+FEW_FLIPS_MAX, FEW_FLIPS_L2 = 2e-3, 1e-3
 
 
 def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
@@ -64,6 +74,12 @@ def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
     # takes the slope of one of two cells and fp32 arithmetic does not determine which (F.grid_sample's kink) - every gradient
     # upstream of the sample positions then carries a finite, legitimate jump; such inputs only get a sanity bound
     undecidable = probe is not None and probe.boundary_margin() < 2e-5
+    # The five parameter gradients of the position-bias MLP are sums over all (query, key) pairs of ReLU-gated terms; a unit whose
+    # pre-activation lies within fp32 rounding of zero flips between any two fp32 evaluations and moves them by a finite quantum.
+    # With >= 1e8 units per evaluation the flips average out and the kernels are held to 1.5 x torch-fp32's own distance from
+    # fp64 (l2) like every other tensor; below that a handful of flips decides the ratio - such problems get the fixed caps
+    # FEW_FLIPS_MAX / FEW_FLIPS_L2 instead of a multiple of a noise figure that is itself a small-number statistic.
+    few_flips = probe is not None and probe.cpb_units() / 2 < 1e8
     for k, p in mod.named_parameters():
         if k.endswith(skip):
             continue
@@ -76,7 +92,13 @@ def _compare_param_grads(mod, p32, p64, skip=(), probe=None):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
                 continue
             assert p.grad is not None, f"missing grad for {k}"
-            if undecidable:
+            if few_flips and k.endswith(CPB_PARAMS) and not undecidable and float(p64[k].grad.abs().max()) > 1e-12:
+                n_max, n_l2 = rel_err(p32[k].grad, p64[k].grad), l2_err(p32[k].grad, p64[k].grad)
+                e_max, e_l2 = rel_err(p.grad, p64[k].grad), l2_err(p.grad, p64[k].grad)
+                b_max, b_l2 = max(helpers.bound_for(n_max), FEW_FLIPS_MAX), max(TOL, helpers.L2_FACTOR * n_l2, FEW_FLIPS_L2)
+                helpers.record("d" + k, e_max, n_max, b_max, "max,few-flips"); helpers.record("d" + k, e_l2, n_l2, b_l2, "l2,few-flips")
+                assert e_max <= b_max and e_l2 <= b_l2, f"d{k}: max {e_max:.3e} (bound {b_max:.1e}) l2 {e_l2:.3e} (bound {b_l2:.1e})"
+            elif undecidable and float(p64[k].grad.abs().max()) > 1e-12:
                 e2 = l2_err(p.grad, p64[k].grad)
                 helpers.record("d" + k, e2, l2_err(p32[k].grad, p64[k].grad), 2e-2, "l2,sample-on-cell-boundary")
                 assert e2 <= 2e-2, f"d{k}: l2 err {e2:.3e} > 2e-2 (sanity bound: a sample position lies on a cell boundary)"
