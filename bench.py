@@ -31,7 +31,7 @@ PKG = "subspace-multimodal-learning_amd"
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix) = FP32 vector, dense
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA - the pipe every contraction of the dominant kernels issues on
 CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 1 + 1 + 2 + 4 + 4
-CPB_FWD_MFMAS = 11                  # deform_attn_fwd_kernel: 1 (layer 1) + 10 (layer 2, five-term split) 16-bit MFMAs per (key, 32 queries)
+CPB_FWD_MFMAS = 9                   # deform_attn_fwd_kernel: 1 (layer 1) + 8 (layer 2, four-term split) 16-bit MFMAs per (key, 32 queries)
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
 TRAFFIC_FILE = "r02_hbm_traffic.json"
@@ -77,7 +77,11 @@ def cpu_baseline(pkg, in_dim, S, seconds_budget=90.0):
     training-step loss, all cores; one warm-up on the reference's 50 x 50 grid (pages the code in), then >= 3 timed iterations
     (fewer only if the budget runs out)."""
     from oracle.mil import deform_cross_trans_mil
-    cores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    # PyTorch's CPU kernels for this op mix (ReLU / Linear over [pairs, 32] chunks) stop scaling near 32 threads and get SLOWER
+    # beyond: measured on the 256-thread EPYC 9575F GPU box, 141.9 s per bag with all 256 threads against ~20 s with 32
+    # (profiles/r02_a_bench_b8.json vs r02_b) - the baseline is given the thread count that serves it best, both counts stated
+    cores = min(host_cores, int(os.environ.get("SMML_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
     mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
     params = pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench")
@@ -100,7 +104,7 @@ def cpu_baseline(pkg, in_dim, S, seconds_budget=90.0):
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         model = "unknown"
-    return {"value": 1.0 / dt, "unit": "bags/s", "cores": cores, "kind": "port", "cpu": model,
+    return {"value": 1.0 / dt, "unit": "bags/s", "cores": cores, "host_cores": host_cores, "kind": "port", "cpu": model,
             "sample": f"oracle (plain PyTorch fp32) fwd+bwd of 1 bag of {S * S} x {in_dim} ({S}x{S} grid), {len(times)} timed iterations "
                       f"after 1 warm-up, {dt:.2f} s/bag, torch.set_num_threads({cores})"}
 

@@ -30,12 +30,13 @@
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
 #ifndef SMML_SPLIT_TERMS
-#define SMML_SPLIT_TERMS 5    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer of the forward: 5 = all but wl hl
-                              // (<= 2^-23 |w||h| dropped); 3 = wh hh + wh hl + wm hh only (<= 2^-21).  The layer's VALUE does not care,
-                              // but its SIGN is the ReLU mask the backward consumes: with 3 terms the saved masks flip 4-5 x as often
-                              // as torch's fp32 evaluation flips its own, and the position-bias weight gradients came out 4-5 x
-                              // noisier than torch fp32 against an fp64 evaluation (tests/diag_gterms.py, profiles/r02_split_terms.txt:
-                              // dW1 1.1e-3 vs torch 2.0e-4; with 5 terms 2.07e-4).  Costs 4 MFMAs per key: +0.8 ms per 8-bag step.
+#define SMML_SPLIT_TERMS 4    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer of the forward:
+                              //   3 = wh hh + wh hl + wm hh (<= 2^-21 |w||h| dropped), 4 adds wm hl (W2 and h both to 22 bits: <= 2^-23
+                              //   dropped), 5 adds wl hh (W2 to 33 bits).  The layer's VALUE does not care, but its SIGN is the ReLU mask
+                              //   the backward consumes: with 3 terms the saved masks flip 4-5 x as often as torch's fp32 evaluation flips
+                              //   its own and the position-bias weight gradients came out 4-5 x noisier than torch fp32 against an fp64
+                              //   evaluation (tests/diag_gterms.py, profiles/r02_split_terms.txt: dW1 1.1e-3 vs torch 2.0e-4); with 4
+                              //   terms 2.2e-4, with 5 terms 2.07e-4.  4 costs two MFMAs per key over 3 (+0.5 ms per 8-bag step), 5 four.
 #endif
 #ifndef SMML_DELTA_FIX
 #define SMML_DELTA_FIX 0      // 1: re-centre the rows of d bias in the position-bias backward (d bias_k - P_k sum_k d bias_k).
@@ -139,7 +140,9 @@ __device__ __forceinline__ void split8_3(const float (&x)[8], half8& hi, half8& 
 __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, half8 bh, half8 bl, floatx16 d) {
 #if SMML_SPLIT_TERMS == 5
   d = mfma16(wl, bh, d);
-  d = mfma16(wm, bl, d);
+#endif
+#if SMML_SPLIT_TERMS >= 4
+  d = mfma16(wm, bl, d);        // 4: W2 to 22 bits (hi + mid; <= 2^-23 |w| dropped, below fp32's own product rounding), h to 22 bits
 #endif
   d = mfma16(wm, bh, d);
   d = mfma16(wh, bl, d);

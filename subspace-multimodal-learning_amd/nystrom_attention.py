@@ -34,10 +34,52 @@ from torch import nn
 from . import functional as Fh
 
 
+class _NewtonSchulz(torch.autograd.Function):
+    """z_{k+1} = 1/4 z_k (13 I - x z_k (15 I - x z_k (7 I - x z_k))), `iters` times, as four batched GEMMs per iteration with the
+    affine parts in the GEMM epilogues (xz; a = 7 xz - xz xz; b = 15 xz - xz a; z' = 3.25 z - 0.25 z b), and a hand-written
+    backward of eight GEMMs + one elementwise add per iteration (autograd through the same products needed ~2 elementwise
+    launches per GEMM to scale and accumulate the five uses of xz):
+        dz = 3.25 dz' - 0.25 dz' b^T        db = -0.25 z^T dz'
+        dxz = 15 db - db a^T                da = -xz^T db
+        dxz += 7 da - da xz^T - xz^T da
+        dx += dxz z^T                       dz += x^T dxz"""
+
+    @staticmethod
+    def forward(ctx, x, z0, iters):
+        z = z0
+        saved = []
+        for _ in range(iters):
+            xz = Fh.matmul4(x, z)
+            a = Fh.matmul4(xz, xz, xz, alpha=-1.0, beta=7.0)
+            b = Fh.matmul4(xz, a, xz, alpha=-1.0, beta=15.0)
+            saved += [z, xz, a, b]
+            z = Fh.matmul4(z, b, z, alpha=-0.25, beta=3.25)
+        ctx.iters = iters
+        ctx.save_for_backward(x, *saved)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, *saved = ctx.saved_tensors
+        dz = dz.contiguous()
+        dx = None
+        for k in reversed(range(ctx.iters)):
+            z, xz, a, b = saved[4 * k:4 * k + 4]
+            dzk = Fh.matmul4(dz, b, dz, tb=True, alpha=-0.25, beta=3.25)
+            db = Fh.matmul4(z, dz, ta=True, alpha=-0.25)
+            dxz = Fh.matmul4(db, a, db, tb=True, alpha=-1.0, beta=15.0)
+            da = Fh.matmul4(xz, db, ta=True, alpha=-1.0)
+            t = Fh.matmul4(da, xz, dxz, tb=True, alpha=-1.0)
+            t = Fh.matmul4(xz, da, t, ta=True, alpha=-1.0)
+            dxz = torch.add(t, da, alpha=7.0)
+            dx = Fh.matmul4(dxz, z, dx, tb=True)
+            dz = Fh.matmul4(x, dxz, dzk, ta=True)
+        return dx, dz, None
+
+
 def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
     """x [B, h, m, m] -> Newton-Schulz pseudo-inverse (NystromAttention.py:20-35).
-    z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz))) evaluated as four GEMMs per iteration:
-    xz; a = 7 xz - xz xz; b = 15 xz - xz a; z = 3.25 z - 0.25 z b.
+    z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz))) evaluated as four GEMMs per iteration (see _NewtonSchulz).
     per_bag=True (corrected semantics, off by default): the initial scale uses each bag's own max row / column sums instead
     of the max over the whole batch (:26), so that a bag's result does not depend on which other bags share its batch."""
     ax = x.abs()
@@ -46,12 +88,9 @@ def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
         z = (x.transpose(-1, -2) / scale.view(-1, 1, 1, 1)).contiguous()
     else:
         z = (x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())).contiguous()
-    for _ in range(iters):
-        xz = Fh.matmul4(x, z)
-        a = Fh.matmul4(xz, xz, xz, alpha=-1.0, beta=7.0)
-        b = Fh.matmul4(xz, a, xz, alpha=-1.0, beta=15.0)
-        z = Fh.matmul4(z, b, z, alpha=-0.25, beta=3.25)
-    return z
+    if iters <= 0:
+        return z
+    return _NewtonSchulz.apply(x.contiguous(), z, iters)
 
 
 class NystromAttention(nn.Module):
