@@ -12,7 +12,9 @@
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant;
  *   - return value 0 = ok, negative = error; the message is read with smml_last_error()
  *     (thread-local); no exception crosses the boundary;
- *   - "accumulated into" outputs must be zeroed (or hold a running sum) by the caller.
+ *   - "accumulated into" outputs must be zeroed (or hold a running sum) by the caller;
+ *   - fixed widths of the two fused attention families (no other value is built, the entry points return an error):
+ *     head dim 64; position-bias MLP posdim -> 32 -> 32 -> heads / groups (the reference's dim = 128), heads / groups <= 2.
  */
 #ifndef SMML_H_
 #define SMML_H_
