@@ -212,8 +212,10 @@ int smml_fixdim_gather_bf16(const unsigned short* src, long long n_rows, void* d
  *   the block's output projection consumes).  accumulate != 0: out += result (out already holds the residual convolution of
  *   v, :144-145); the backward then takes that residual (same layout, nullable) to recover the attention output.
  * Backward: dq / dk / dv overwritten; workspace of smml_attn16_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
-int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, int BH, int Lq, int Lk, int D,
-                        float scale, int use_fp16, int heads_merged, int accumulate, void* stream);
+size_t smml_attn16_fwd_workspace_bytes(int BH, int Lq, int Lk);   /* 0 unless the shape runs key-split (few queries, many keys) */
+int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, void* workspace,
+                        size_t workspace_bytes, int BH, int Lq, int Lk, int D, float scale, int use_fp16, int heads_merged,
+                        int accumulate, void* stream);
 size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk);
 int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* residual, const float* dout,
                         const float* lse2, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, int BH, int Lq,

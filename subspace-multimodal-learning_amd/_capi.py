@@ -27,7 +27,8 @@ SIGNATURES = {
     "smml_gemm_force_generic": (None, [_i]),
     "smml_gemm_set_mode": (None, [_i]),
     "smml_gemm_get_mode": (_i, []),
-    "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
+    "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
     "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_bwd_f32": (_i, [_f] * 10 + [_f, _sz, _i, _i, _i, _i, _fl, _i, _i, _f]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),

@@ -92,7 +92,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, float* __restrict__ O,
                                                             float* __restrict__ LSE2, int Lq, int Lk, float qscale, OLayout ol,
-                                                            int accumulate) {
+                                                            int accumulate, int chunk, float* __restrict__ Opart,
+                                                            float* __restrict__ Lpart) {
   typedef typename Pipe<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
   __shared__ __attribute__((aligned(16))) T Vt[2][AK * TLD];
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
   const int q0 = blockIdx.x * (AQ * AW) + wave * AQ;
   const bool qvalid = (q0 + c) < Lq;
   const int qi = qvalid ? (q0 + c) : (Lq - 1);
-  const float* Kb = K + (size_t)bh * Lk * AD;
-  const float* Vb = V + (size_t)bh * Lk * AD;
+  // key range of this workgroup: the whole row, or one of gridDim.z chunks (few queries, many keys - the [m, n'] side of the
+  // Nystrom block has only m / 32 waves per head: the chunks' partial results are merged by attn16_merge_kernel)
+  const int kbeg = blockIdx.z * chunk, kend = min(Lk, kbeg + chunk);
+  const float* Kb = K + ((size_t)bh * Lk + kbeg) * AD;
+  const float* Vb = V + ((size_t)bh * Lk + kbeg) * AD;
+  Lk = kend - kbeg;                                   // from here on: keys of this chunk only
 
   x8 qf[4];
   {
@@ -174,6 +179,20 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
   }
   l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
+  if (Opart) {                                        // partial result of this chunk: normalised rows + their log-sum-exp
+    if (qvalid) {
+      const size_t row = ((size_t)blockIdx.z * gridDim.y + bh) * Lq + qi;
+      float* op = Opart + row * AD;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = 8 * rg + 4 * hf;
+        *reinterpret_cast<float4*>(op + d) = make_float4(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 + d) = make_float4(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+      }
+      if (hf == 0) Lpart[row] = m_run + __builtin_amdgcn_logf(l_run);
+    }
+    return;
+  }
   if (qvalid) {
     float* op = O + obase(ol, bh) + (size_t)qi * ol.rs;
 #pragma unroll
@@ -192,6 +211,33 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
   }
 }
 
+// merges the chunks of a key-split forward: lse = log2 sum_s 2^lse_s, O = sum_s 2^(lse_s - lse) O_s   (thread = 4 head-dim values)
+__global__ void attn16_merge_kernel(const float* __restrict__ Opart, const float* __restrict__ Lpart, float* __restrict__ O,
+                                    float* __restrict__ LSE2, int BH, int Lq, int nsplit, OLayout ol, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t rows = (size_t)BH * Lq;
+  if (i >= rows * (AD / 4)) return;
+  const size_t row = i / (AD / 4);
+  const int d4 = (int)(i % (AD / 4)) * 4;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, Lpart[(size_t)s * rows + row]);
+  float den = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __builtin_amdgcn_exp2f(Lpart[(size_t)s * rows + row] - m);
+    const float4 o = *reinterpret_cast<const float4*>(Opart + ((size_t)s * rows + row) * AD + d4);
+    den += w;
+    acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y); acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
+  }
+  const float inv = 1.f / den;
+  const int bh = (int)(row / Lq), qi = (int)(row % Lq);
+  float* op = O + obase(ol, bh) + (size_t)qi * ol.rs + d4;
+  float4 r = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(op); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+  *reinterpret_cast<float4*>(op) = r;
+  if (d4 == 0) LSE2[row] = m + __builtin_amdgcn_logf(den);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward pass 1 (query owners): P^T recomputed from LSE2, dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ = scale dS K;
 // also writes delta = rowsum(dO . O) [BH, Lq] for pass 2.          grid (ceil(Lq / 128), BH)
@@ -201,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
                                                                const float* __restrict__ V, const float* __restrict__ O,
                                                                const float* __restrict__ dO, const float* __restrict__ LSE2,
                                                                float* __restrict__ dQ, float* __restrict__ DELTA, int Lq, int Lk,
-                                                               float qscale, float scale, OLayout ol, const float* __restrict__ R) {
+                                                               float qscale, float scale, OLayout ol, const float* __restrict__ R,
+                                                               int chunk) {
   typedef typename Pipe<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
   __shared__ __attribute__((aligned(16))) T Kt[2][AK * TLD];
@@ -211,8 +258,11 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
   const int q0 = blockIdx.x * (AQ * AW) + wave * AQ;
   const bool qvalid = (q0 + c) < Lq;
   const int qi = qvalid ? (q0 + c) : (Lq - 1);
-  const float* Kb = K + (size_t)bh * Lk * AD;
-  const float* Vb = V + (size_t)bh * Lk * AD;
+  // key range: the whole row or one of gridDim.z chunks (partial dQ slabs [chunk][BH, Lq, 64], added by attn16_sum_kernel)
+  const int kbeg = blockIdx.z * chunk, kend = min(Lk, kbeg + chunk);
+  const float* Kb = K + ((size_t)bh * Lk + kbeg) * AD;
+  const float* Vb = V + ((size_t)bh * Lk + kbeg) * AD;
+  Lk = kend - kbeg;
   x8 qf[4], dof[4];
   float delta = 0.f;
   {
@@ -233,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
   }
   delta = xhalf_sum(delta);
   const float lse2 = LSE2[(size_t)bh * Lq + qi];
-  if (qvalid && hf == 0) DELTA[(size_t)bh * Lq + qi] = delta;
+  if (qvalid && hf == 0 && blockIdx.z == 0) DELTA[(size_t)bh * Lq + qi] = delta;
   const int skey = tid >> 4, sd4 = (tid & 15) * 4;
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   float4 kreg[2], vreg[2];
@@ -288,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
     }
   }
   if (qvalid) {
-    float* qp = dQ + ((size_t)bh * Lq + qi) * AD;
+    float* qp = dQ + (((size_t)blockIdx.z * gridDim.y + bh) * Lq + qi) * AD;       // gridDim.z == 1: dQ itself
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int d = 8 * rg + 4 * hf;
@@ -435,6 +485,29 @@ __global__ void attn16_reduce_kernel(const float4* __restrict__ dKp, const float
   dK[i] = sk; dV[i] = sv;
 }
 
+// out = sum of nparts slabs of n4 float4 each, in a fixed order
+__global__ void attn16_sum_kernel(const float4* __restrict__ parts, float4* __restrict__ out, size_t n4, int nparts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = parts[i];
+  for (int p = 1; p < nparts; ++p) { const float4 a = parts[(size_t)p * n4 + i]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+  out[i] = s;
+}
+
+// key chunks of the query-owner kernels (forward, pass 1): only when there are too few query tiles to fill the chip
+static int attn16_ksplit(int BH, int Lq, int Lk, int* chunk) {
+  const long waves = (long)BH * ((Lq + AQ - 1) / AQ);
+  long ns = (2048 + waves - 1) / waves;
+  const long maxs = (Lk + 255) / 256;                 // at least 256 keys per chunk
+  if (ns > maxs) ns = maxs;
+  if (ns > 16) ns = 16;
+  if (ns < 1) ns = 1;
+  int c = (int)((Lk + ns - 1) / ns);
+  c = (c + AK - 1) / AK * AK;                         // whole 32-key tiles
+  *chunk = c;
+  return (int)((Lk + c - 1) / c);
+}
+
 // query slices of pass 2: enough workgroups to fill the chip a few times over, at most 32 slabs
 static int attn16_parts(int BH, int Lq, int Lk) {
   const long base = (long)((Lk + AK * AW - 1) / (AK * AW)) * BH;
@@ -450,13 +523,24 @@ static int attn16_parts(int BH, int Lq, int Lk) {
 
 extern "C" {
 
-// scratch of smml_attn16_bwd_f32: delta [BH, Lq] + the dK / dV slabs of the query slices
+// scratch of smml_attn16_fwd_f32: the partial outputs + log-sum-exps of a key-split launch (0 when the launch is not split)
+size_t smml_attn16_fwd_workspace_bytes(int BH, int Lq, int Lk) {
+  if (BH <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  int chunk;
+  const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
+  return ns > 1 ? (size_t)ns * BH * Lq * (AD + 1) * sizeof(float) : 0;
+}
+
+// scratch of smml_attn16_bwd_f32: delta [BH, Lq] + the dQ slabs of a key-split pass 1 + the dK / dV slabs of the query slices
 size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk) {
   if (BH <= 0 || Lq <= 0 || Lk <= 0) return 0;
   const int parts = attn16_parts(BH, Lq, Lk);
+  int chunk;
+  const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
   const size_t delta = ((size_t)BH * Lq + 3) & ~(size_t)3;
+  const size_t qslabs = ns > 1 ? (size_t)ns * BH * Lq * AD : 0;
   const size_t slabs = parts > 1 ? (size_t)2 * parts * BH * Lk * AD : 0;
-  return (delta + slabs) * sizeof(float);
+  return (delta + qslabs + slabs) * sizeof(float);
 }
 
 static int attn16_layout(const char* fn, int BH, int Lq, int heads_merged, OLayout* ol) {
@@ -467,19 +551,36 @@ static int attn16_layout(const char* fn, int BH, int Lq, int heads_merged, OLayo
   return SMML_OK;
 }
 
-int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, int BH, int Lq, int Lk, int D,
-                        float scale, int use_fp16, int heads_merged, int accumulate, void* stream) {
+int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, void* workspace,
+                        size_t workspace_bytes, int BH, int Lq, int Lk, int D, float scale, int use_fp16, int heads_merged,
+                        int accumulate, void* stream) {
   SMML_REQUIRE(q && k && v && out && lse2, "smml_attn16_fwd_f32: null pointer");
   SMML_REQUIRE(BH > 0 && BH <= 65535 && Lq > 0 && Lk > 0, "smml_attn16_fwd_f32: bad sizes (BH=%d Lq=%d Lk=%d)", BH, Lq, Lk);
   SMML_REQUIRE(D == AD, "smml_attn16_fwd_f32: head dim must be %d (got %d)", AD, D);
   OLayout ol;
   int rc = attn16_layout("smml_attn16_fwd_f32", BH, Lq, heads_merged, &ol);
   if (rc) return rc;
-  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH), block(256);
+  int chunk;
+  const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
+  float *opart = nullptr, *lpart = nullptr;
+  if (ns > 1) {
+    SMML_REQUIRE(workspace && workspace_bytes >= smml_attn16_fwd_workspace_bytes(BH, Lq, Lk) && (reinterpret_cast<size_t>(workspace) & 15) == 0,
+                 "smml_attn16_fwd_f32: this shape runs key-split and needs a 16-byte aligned workspace of %zu bytes",
+                 smml_attn16_fwd_workspace_bytes(BH, Lq, Lk));
+    opart = reinterpret_cast<float*>(workspace);
+    lpart = opart + (size_t)ns * BH * Lq * AD;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, ns), block(256);
   const float qscale = scale * LOG2E_F;
-  if (use_fp16) hipLaunchKernelGGL(attn16_fwd_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate);
-  else hipLaunchKernelGGL(attn16_fwd_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate);
+  if (use_fp16) hipLaunchKernelGGL(attn16_fwd_kernel<_Float16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
+  else hipLaunchKernelGGL(attn16_fwd_kernel<__bf16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
   SMML_LAUNCH_CHECK("smml_attn16_fwd_f32");
+  if (ns > 1) {
+    const size_t n = (size_t)BH * Lq * (AD / 4);
+    hipLaunchKernelGGL(attn16_merge_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, opart, lpart, out, lse2, BH, Lq, ns, ol, accumulate);
+    SMML_LAUNCH_CHECK("smml_attn16_fwd_f32/merge");
+  }
   return SMML_OK;
 }
 
@@ -496,13 +597,23 @@ int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const fl
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const float qscale = scale * LOG2E_F;
+  int chunk;
+  const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
   float* delta = reinterpret_cast<float*>(workspace);
-  float* slabs = delta + (((size_t)BH * Lq + 3) & ~(size_t)3);
+  float* qslabs = delta + (((size_t)BH * Lq + 3) & ~(size_t)3);
+  float* slabs = qslabs + (ns > 1 ? (size_t)ns * BH * Lq * AD : 0);
   dim3 block(256);
-  dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH);
-  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dq_kernel<_Float16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq, delta, Lq, Lk, qscale, scale, ol, residual);
-  else hipLaunchKernelGGL(attn16_bwd_dq_kernel<__bf16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq, delta, Lq, Lk, qscale, scale, ol, residual);
+  dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH, ns);
+  float* dq_out = ns > 1 ? qslabs : dq;
+  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dq_kernel<_Float16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq_out, delta, Lq, Lk, qscale, scale, ol, residual, chunk);
+  else hipLaunchKernelGGL(attn16_bwd_dq_kernel<__bf16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq_out, delta, Lq, Lk, qscale, scale, ol, residual, chunk);
   SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dq");
+  if (ns > 1) {
+    const size_t n4 = (size_t)BH * Lq * AD / 4;
+    hipLaunchKernelGGL(attn16_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(qslabs),
+                       reinterpret_cast<float4*>(dq), n4, ns);
+    SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dq_sum");
+  }
   const int parts = attn16_parts(BH, Lq, Lk);
   const int nqt = (Lq + AQ - 1) / AQ, tpp = (nqt + parts - 1) / parts;
   const size_t per = (size_t)BH * Lk * AD;

@@ -669,9 +669,12 @@ class _Attention16(torch.autograd.Function):
         else:
             out = torch.empty((Bn, Lq, H * D) if merged else (Bn, H, Lq, D), device=q.device, dtype=torch.float32)
         lse2 = torch.empty(Bn * H, Lq, device=q.device, dtype=torch.float32)
-        capi.check(capi.lib().smml_attn16_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(out), capi.fptr(lse2), Bn * H, Lq,
-                                                  Lk, D, float(scale), int(bool(fp16)), H if merged else 0,
-                                                  1 if residual is not None else 0, capi.stream()), "attn16_fwd")
+        L = capi.lib()
+        wsb = L.smml_attn16_fwd_workspace_bytes(Bn * H, Lq, Lk)
+        ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32) if wsb else None
+        capi.check(L.smml_attn16_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(out), capi.fptr(lse2), capi.fptr(ws), wsb,
+                                         Bn * H, Lq, Lk, D, float(scale), int(bool(fp16)), H if merged else 0,
+                                         1 if residual is not None else 0, capi.stream()), "attn16_fwd")
         ctx.cfg = (float(scale), int(bool(fp16)), H if merged else 0, residual is not None)
         ctx.save_for_backward(q, k, v, out, lse2, _c(residual) if residual is not None else None)
         return out
