@@ -58,6 +58,11 @@
                               // is unchanged to three digits vs 3 terms (tests/diag_gterms.py: it is set by ReLU mask flips
                               // and by delta = rowsum(dO . O)), and the kernel is 10 % faster.  3: fp32-grade summands.
 #endif
+#ifndef SMML_FWD_QK16
+#define SMML_FWD_QK16 1       // forward QK^T / PV on the 16-bit matrix pipe: every operand as fp16 hi + lo (RNE, 22 bits), three of the
+                              // four cross products (hi hi, hi lo, lo hi; <= 2^-22 dropped) - 24 MFMAs of 32 cycles per 32-key tile
+                              // instead of 64 fp32 MFMAs of 64 cycles (which run at the vector rate and share the ALUs).  0: fp32 MFMA.
+#endif
 #ifndef SMML_FMA_MIX
 #define SMML_FMA_MIX 1          // residual of the fp16 split by v_fma_mix_f32 (one instruction per value instead of convert + subtract)
 #endif
@@ -136,6 +141,28 @@ __device__ __forceinline__ void split8_3(const float (&x)[8], half8& hi, half8& 
     hi[i] = h; mid[i] = m; lo[i] = l;
   }
 }
+// four fp32 -> fp16 hi / lo planes (8 bytes each), both round-to-nearest
+__device__ __forceinline__ void split4_h2(const float4 v, uint2v& hi, uint2v& lo) {
+  const float2v a = {v.x, v.y}, b = {v.z, v.w};
+  const half2v ha = __builtin_convertvector(a, half2v), hb = __builtin_convertvector(b, half2v);
+  const float2v ra = {a[0] - (float)ha[0], a[1] - (float)ha[1]}, rb = {b[0] - (float)hb[0], b[1] - (float)hb[1]};
+  const half2v la = __builtin_convertvector(ra, half2v), lb = __builtin_convertvector(rb, half2v);
+  hi = (uint2v){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  lo = (uint2v){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+// fp16 MFMA fragment of an operand stored k-major in LDS: two hardware-transposed reads (see smml_common.h lds_frag_tr)
+__device__ __forceinline__ half8 lds_frag_tr_h(const _Float16* p0, const _Float16* p1) {
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) short4v lds_s4;
+  const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p0);
+  const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p1);
+  const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  return __builtin_bit_cast(half8, r);
+}
+constexpr int FRLD = 64 + 8;    // halves per row of a row-read fp16 image (144-byte rows)
+constexpr int FTLD = 64 + 32;   // halves per row of a transposed-read fp16 image (192-byte rows)
+
 // D += W . h with W = wh + wm + wl (exact) and h = bh + bl: all products down to 2^-22 of the leading one
 __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, half8 bh, half8 bl, floatx16 d) {
 #if SMML_SPLIT_TERMS == 5
@@ -217,11 +244,17 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
     float* __restrict__ LSE, float* __restrict__ LT, unsigned short* __restrict__ MK, int N, int J, int H, int G, int NST,
     float scale, DropCfg dc) {
+#if SMML_FWD_QK16
+  __shared__ __attribute__((aligned(16))) _Float16 Kp[2][KT * FRLD];         // K tile, fp16 hi / lo planes, row image (A operand of S^T)
+  __shared__ __attribute__((aligned(16))) _Float16 Vp[2][KT * FTLD];         // V tile, hi / lo planes, read transposed (A operand of O^T)
+  __shared__ __attribute__((aligned(16))) _Float16 Qp[WAVES][2][QT * FRLD];  // per-wave scaled Q tile, hi / lo planes, row image
+#else
   __shared__ float Ks[DH][KT + 1];           // K tile, d-major (A operand of S^T)
   __shared__ float Vs[KT][DH];               // V tile, key-major (A operand of O^T)
+  __shared__ float Qs[WAVES][DH][QT];        // per-wave scaled Q tile, d-major
+#endif
   __shared__ float vsl[KT][2];               // sample positions of the tile's keys
   __shared__ float biasT[WAVES][KT][QT];     // per-wave bias tile [key][query]
-  __shared__ float Qs[WAVES][DH][QT];        // per-wave scaled Q tile, d-major
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -238,10 +271,20 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4) {
       const float4 t = qp[s4];
+#if SMML_FWD_QK16
+      uint2v hi, lo;
+      split4_h2(make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale), hi, lo);
+      *reinterpret_cast<uint2v*>(&Qp[wave][0][c * FRLD + 32 * hf + 4 * s4]) = hi;
+      *reinterpret_cast<uint2v*>(&Qp[wave][1][c * FRLD + 32 * hf + 4 * s4]) = lo;
+#else
       Qs[wave][32 * hf + 4 * s4 + 0][c] = t.x * scale; Qs[wave][32 * hf + 4 * s4 + 1][c] = t.y * scale;
       Qs[wave][32 * hf + 4 * s4 + 2][c] = t.z * scale; Qs[wave][32 * hf + 4 * s4 + 3][c] = t.w * scale;
+#endif
     }
   }
+#if SMML_FWD_QK16
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // transposed-read lane map
+#endif
   const float gq0 = GQ[(size_t)qi * PD];
   const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
 
@@ -323,8 +366,16 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
         kv = *reinterpret_cast<const float4*>(Kb + (size_t)(j0 + key) * HD + d4);
         vv = *reinterpret_cast<const float4*>(Vb + (size_t)(j0 + key) * HD + d4);
       }
+#if SMML_FWD_QK16
+      uint2v hi, lo;
+      split4_h2(kv, hi, lo);
+      *reinterpret_cast<uint2v*>(&Kp[0][key * FRLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Kp[1][key * FRLD + d4]) = lo;
+      split4_h2(vv, hi, lo);
+      *reinterpret_cast<uint2v*>(&Vp[0][key * FTLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Vp[1][key * FTLD + d4]) = lo;
+#else
       Ks[d4 + 0][key] = kv.x; Ks[d4 + 1][key] = kv.y; Ks[d4 + 2][key] = kv.z; Ks[d4 + 3][key] = kv.w;
       *reinterpret_cast<float4*>(&Vs[key][d4]) = vv;
+#endif
     }
     if (tid < KT) {
       const int key = j0 + tid;
@@ -335,8 +386,20 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 
     // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
+#if SMML_FWD_QK16
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int o = c * FRLD + 16 * st + 8 * hf;
+      const half8 kh = *reinterpret_cast<const half8*>(&Kp[0][o]), kl = *reinterpret_cast<const half8*>(&Kp[1][o]);
+      const half8 qh = *reinterpret_cast<const half8*>(&Qp[wave][0][o]), ql = *reinterpret_cast<const half8*>(&Qp[wave][1][o]);
+      s = mfma16(kl, qh, s);
+      s = mfma16(kh, ql, s);
+      s = mfma16(kh, qh, s);
+    }
+#else
 #pragma unroll
     for (int st = 0; st < 32; ++st) s = mfma32(Ks[32 * hf + st][c], Qs[wave][32 * hf + st][c], s);
+#endif
 
     // continuous position bias: one MFMA chain per key.  On gfx950 v_mfma_f32_32x32x2_f32 runs at the fp32
     // vector rate and does NOT overlap VALU work of the same SIMD (tests/microbench/mfma_probe.hip: every
@@ -427,12 +490,28 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     for (int r = 0; r < 16; ++r) { oacc0[r] *= alpha; oacc1[r] *= alpha; }
 
     // O^T[d, query] += V^T . P^T   (accumulator registers of P^T are the B operand as they stand)
+#if SMML_FWD_QK16
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {            // accumulator registers 8 kb .. 8 kb + 7 of P^T are the B fragment of k-step kb
+      float p8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p8[j] = s[8 * kb + j];
+      half8 ph, pl;
+      split8(p8, ph, pl);
+      const int ro = (16 * kb + 4 * hf + trq) * FTLD + trc;
+      const half8 vh0 = lds_frag_tr_h(&Vp[0][ro], &Vp[0][ro + 8 * FTLD]), vl0 = lds_frag_tr_h(&Vp[1][ro], &Vp[1][ro + 8 * FTLD]);
+      const half8 vh1 = lds_frag_tr_h(&Vp[0][ro + 32], &Vp[0][ro + 32 + 8 * FTLD]), vl1 = lds_frag_tr_h(&Vp[1][ro + 32], &Vp[1][ro + 32 + 8 * FTLD]);
+      oacc0 = mfma16(vl0, ph, oacc0); oacc0 = mfma16(vh0, pl, oacc0); oacc0 = mfma16(vh0, ph, oacc0);
+      oacc1 = mfma16(vl1, ph, oacc1); oacc1 = mfma16(vh1, pl, oacc1); oacc1 = mfma16(vh1, ph, oacc1);
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = acc_row(r, hf);
       oacc0 = mfma32(Vs[key][c], s[r], oacc0);
       oacc1 = mfma32(Vs[key][32 + c], s[r], oacc1);
     }
+#endif
     wave_lds_fence();
   }
 
