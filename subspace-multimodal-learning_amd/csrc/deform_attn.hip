@@ -1125,6 +1125,17 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       e = mfma16b(am[t], g3, e);
       e = mfma16b(am[t], g2, e);
       e = mfma16b(am[t], g1, e);
+#elif SMML_G_TERMS == 1
+      // one bf16 term (measurement switch, NOT accurate enough): 8 mantissa bits per summand.  The gradient is a sum of
+      // random-sign terms (|sum| ~ sqrt(pairs) rms), so the relative error of the sum is the per-term rounding, 2^-9 / sqrt(3):
+      // measured dW2 5.4e-3 vs 2.7e-4 with two terms (profiles/r02_split_terms.txt) - though 0.75 ms per step faster
+      uint4v g1w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2v v = {g8[2 * i], g8[2 * i + 1]};
+        g1w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+      }
+      e = mfma16b(am[t], __builtin_bit_cast(bf16x8, g1w), e);
 #else
       // two bf16 terms: 16 mantissa bits per summand (<= 2^-17 relative, unbiased round-to-nearest) against the exact mask
       uint4v g1w, g2w;
