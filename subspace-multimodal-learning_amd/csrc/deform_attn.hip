@@ -94,14 +94,7 @@ __device__ __forceinline__ float srcp(float x) { return 1.0f / x; }
 // 2 relu(x) = x + |x|, exact.  On gfx950 v_add_f32 (with its free |.| modifier) is in the fast issue class (~1.1 ns per
 // instruction per SIMD with two resident waves) while v_max_f32 is in the slow one (~2.0 ns) -
 // tests/microbench/valu_mix_probe.hip; the factor 2 is folded into the constants downstream (powers of two: exact).
-// The empty asm pins the sum as an opaque scalar: left to itself the SLP vectoriser pairs the adds into v_pk_add_f32, which has
-// no |.| source modifier - two v_and_b32 + one v_pk_add_f32 per pair instead of two v_add_f32 (34 extra instructions per key in
-// the forward's loop).
-__device__ __forceinline__ float relu2(float x) {
-  float r = x + __builtin_fabsf(x);
-  asm("" : "+v"(r));
-  return r;
-}
+__device__ __forceinline__ float relu2(float x) { return x + __builtin_fabsf(x); }
 
 constexpr int DH = 64;       // head dim (fixed: dim_head = 64 in both reference modules)
 constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
