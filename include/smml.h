@@ -60,6 +60,9 @@ void smml_gemm_force_generic(int on);
  * (operands rounded to bf16 when staged, fp32 accumulation: the 16-bit compute mode of the Nystrom block). */
 void smml_gemm_set_mode(int mode);
 int smml_gemm_get_mode(void);
+/* tile-height switch of the tiled kernels: 0 automatic (64-row tiles for launches that the 128-row tiling leaves below two
+ * workgroups per CU, e.g. the batched 256^3 products of the Nystrom pseudo-inverse), 1 never, 2 wherever it applies. */
+void smml_gemm_set_small_tile(int v);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.

@@ -27,6 +27,7 @@ SIGNATURES = {
     "smml_gemm_force_generic": (None, [_i]),
     "smml_gemm_set_mode": (None, [_i]),
     "smml_gemm_get_mode": (_i, []),
+    "smml_gemm_set_small_tile": (None, [_i]),
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
     "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -82,6 +83,8 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if os.environ.get("SMML_GEMM_MODE"):       # measurement switch: 1 = fp32-MFMA GEMM only, 2 = split-bf16 wherever it applies
             handle.smml_gemm_set_mode(int(os.environ["SMML_GEMM_MODE"]))
+        if os.environ.get("SMML_GEMM_SMALL_TILE"):  # measurement switch: 1 = never the 64-row tile, 2 = wherever it applies
+            handle.smml_gemm_set_small_tile(int(os.environ["SMML_GEMM_SMALL_TILE"]))
         _lib = handle
     return _lib
 

@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // Requirements (checked on the host): K % 16 == 0, 16-byte aligned operands with the unit stride on k or on
 // the row index and all other strides multiples of 4 elements.
 // ------------------------------------------------------------------------------------------------
-template <int BN_, bool A_KC, bool B_KC>
+template <int BN_, bool A_KC, bool B_KC, int FBM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
-  constexpr int FBM = 128, FBK = 16, NI = BN_ / 64;          // NI 32-column blocks per wave
+  constexpr int FBK = 16, NI = BN_ / 64, MI = FBM / 64;      // MI x NI 32x32 blocks per wave; FBM = 64: the small-problem tile
+  constexpr int NA = FBM / 64;                               // float4 of A per thread per K-tile
   constexpr int A_LD = A_KC ? (FBK + 4) : (FBM + 4);
   constexpr int B_LD = B_KC ? (FBK + 4) : (BN_ + 4);
   __shared__ __attribute__((aligned(16))) float As[(A_KC ? FBM : FBK) * A_LD];
@@ -158,19 +159,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   // staging maps (2 float4 of A, NI float4 of B per thread).  Everything that does not depend on the K-tile - row / column
   // clamps, 64-bit row offsets, which of the three forms a row-contiguous float4 takes - is worked out once here: the
   // fp32 MFMA shares its ALUs with vector work, so address arithmetic inside the K loop costs matrix throughput.
-  float4 ra[2], rb[NI];
-  const float* pa[2];            // k-contiguous: row base (+ 4 kq); row-contiguous: column base (+ 4 mq), advanced by k * stride
+  float4 ra[NA], rb[NI];
+  const float* pa[NA];            // k-contiguous: row base (+ 4 kq); row-contiguous: column base (+ 4 mq), advanced by k * stride
   const float* pb[NI];
-  int ka[2], kb_[NI];            // the k index (within a tile) this thread stages
-  int fa[2], fb[NI];             // row-contiguous operands: 0 = nothing to read, 1 = one float4, 2 = ragged edge (scalar reads)
+  int ka[NA], kb_[NI];            // the k index (within a tile) this thread stages
+  int fa[NA], fb[NI];             // row-contiguous operands: 0 = nothing to read, 1 = one float4, 2 = ragged edge (scalar reads)
+  constexpr int MQ = FBM / 4;                                // float4 per k-row of a row-contiguous A tile
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NA; ++i) {
     if (A_KC) {
       const int row = (tid >> 2) + 64 * i, kq = tid & 3;
       pa[i] = A + (long long)min(m0 + row, g.M - 1) * g.sam + 4 * kq;
       ka[i] = 4 * kq; fa[i] = 1;
     } else {
-      const int k = (tid >> 5) + 8 * i, mq = tid & 31, gm = m0 + 4 * mq;
+      const int idx = tid + 256 * i, k = idx / MQ, mq = idx - k * MQ, gm = m0 + 4 * mq;
       pa[i] = A + min(gm, g.M - 1);
       ka[i] = k; fa[i] = (gm >= g.M) ? 0 : (gm + 3 < g.M ? 1 : 2);
     }
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   auto load_tile = [&](int kt) {
     const int k0 = kt * FBK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       if (A_KC) {
         ra[i] = (k0 + ka[i] < g.K) ? *reinterpret_cast<const float4*>(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
         const float* p = pa[i] + (long long)min(k, g.K - 1) * g.sak;
         if (k >= g.K || fa[i] == 0) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);               // K tail / tile wider than the operand: nothing to read
         else if (fa[i] == 1) ra[i] = *reinterpret_cast<const float4*>(p);
-        else { const int gm = m0 + 4 * (tid & 31), last = g.M - 1 - gm;           // ragged edge: gm <= M - 1 < gm + 3
+        else { const int gm = m0 + 4 * ((tid + 256 * i) % MQ), last = g.M - 1 - gm;   // ragged edge: gm <= M - 1 < gm + 3
                ra[i] = make_float4(p[0], p[min(1, last)], p[min(2, last)], p[min(3, last)]); }
       }
     }
@@ -219,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       if (A_KC) { const int row = (tid >> 2) + 64 * i, kq = tid & 3; *reinterpret_cast<float4*>(&As[row * A_LD + 4 * kq]) = ra[i]; }
-      else { const int k = (tid >> 5) + 8 * i, mq = tid & 31; *reinterpret_cast<float4*>(&As[k * A_LD + 4 * mq]) = ra[i]; }
+      else { const int idx = tid + 256 * i, k = idx / MQ, mq = idx - k * MQ; *reinterpret_cast<float4*>(&As[k * A_LD + 4 * mq]) = ra[i]; }
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
     }
   };
 
-  floatx16 acc[2][NI];
+  floatx16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = floatx16{0};
 
@@ -243,10 +245,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
     store_tile();
     __syncthreads();
     if (kt + 1 < kt1) load_tile(kt + 1);   // in flight during the MFMAs below
-    float af[2][8], bf[NI][8];
+    float af[MI][8], bf[NI][8];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int row = wm * 64 + mi * 32 + c;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wm * (FBM / 2) + mi * 32 + c;
       if (A_KC) {
         const float4 x = *reinterpret_cast<const float4*>(&As[row * A_LD + 8 * hf]);
         const float4 y = *reinterpret_cast<const float4*>(&As[row * A_LD + 8 * hf + 4]);
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 #pragma unroll
     for (int st = 0; st < 8; ++st)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(af[mi][st], bf[ni][st], acc[mi][ni]);
   }
@@ -285,11 +287,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
   // round trips per accumulator: +7 us on a 20 us launch of the Nystrom pseudo-inverse products, tests/diag_smallgemm.py).
   if (!g.atomic && m0 + FBM <= g.M && n0 + BN_ <= g.N) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * (BN_ / 2) + ni * 32 + c;
-        const int mb = m0 + wm * 64 + mi * 32;
+        const int mb = m0 + wm * (FBM / 2) + mi * 32;
         float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) rv[r] = res ? res[(long long)(mb + acc_row(r, hf)) * g.ldr + n] : 0.f;
@@ -305,14 +307,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
     return;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn * (BN_ / 2) + ni * 32 + c;
       if (n >= g.N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + acc_row(r, hf);
+        const int m = m0 + wm * (FBM / 2) + mi * 32 + acc_row(r, hf);
         if (m >= g.M) continue;
         float v = g.alpha * acc[mi][ni][r];
         if (g.atomic) {
@@ -342,13 +344,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 // TERMS = 1 ("bf1"): only the leading bf16 term of each operand and one product - the plain bf16 matrix-pipe GEMM with fp32
 // storage and fp32 accumulation (8 mantissa bits per operand element), used by the 16-bit compute mode of the Nystrom block.
-template <int BN_, bool A_KC, bool B_KC, int TERMS = 3>
+template <int BN_, bool A_KC, bool B_KC, int TERMS = 3, int FBM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
-  constexpr int FBM = 128, FBK = 32, NI = BN_ / 64;            // NI 32-column blocks per wave
+  constexpr int FBK = 32, NI = BN_ / 64, MI = FBM / 64;        // MI x NI 32x32 blocks per wave; FBM = 64: the small-problem tile
   constexpr int A_LD = A_KC ? (FBK + 8) : (FBM + 32);          // halves per row of a plane
   constexpr int B_LD = B_KC ? (FBK + 8) : (BN_ + 32);
   constexpr int A_PLANE = (A_KC ? FBM : FBK) * A_LD, B_PLANE = (B_KC ? BN_ : FBK) * B_LD;
-  constexpr int NA = 4, NB = BN_ / 32;                         // float4 per thread per K-tile
+  constexpr int NA = FBM / 32, NB = BN_ / 32, MQ = FBM / 4;    // float4 per thread per K-tile; float4 per k-row of a row-contiguous A tile
   __shared__ __attribute__((aligned(16))) __bf16 As[TERMS * A_PLANE];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[TERMS * B_PLANE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
         const long long gm = min(m0 + row, g.M - 1);
         ra[i] = (k0 + 4 * kq < g.K) ? *reinterpret_cast<const float4*>(A + gm * g.sam + k0 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        const int k = idx >> 5, mq = idx & 31;
+        const int k = idx / MQ, mq = idx - k * MQ;
         const int gm = m0 + 4 * mq;
         const float* p = A + (long long)min(k0 + k, g.K - 1) * g.sak;
         if (k0 + k >= g.K) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int idx = tid + 256 * i;
-      const int off = A_KC ? ((idx >> 3) * A_LD + 4 * (idx & 7)) : ((idx >> 5) * A_LD + 4 * (idx & 31));
+      const int off = A_KC ? ((idx >> 3) * A_LD + 4 * (idx & 7)) : ((idx / MQ) * A_LD + 4 * (idx % MQ));
       uint2v h, m, l;
       split4_bf3(ra[i], h, m, l);
       *reinterpret_cast<uint2v*>(&As[off]) = h;
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
     }
   };
 
-  floatx16 acc[2][NI];
+  floatx16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = floatx16{0};
 
@@ -447,10 +449,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
     if (kt + 1 < kt1) load_tile(kt + 1);   // in flight during the MFMAs below
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 af[2][3], bf[NI][3];
+      bf16x8 af[MI][3], bf[NI][3];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int rbase = wm * 64 + mi * 32;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int rbase = wm * (FBM / 2) + mi * 32;
 #pragma unroll
         for (int p = 0; p < TERMS; ++p) {
           if (A_KC) af[mi][p] = *reinterpret_cast<const bf16x8*>(&As[p * A_PLANE + (rbase + c) * A_LD + 16 * kb + 8 * hf]);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
         }
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           floatx16 d = acc[mi][ni];
@@ -497,11 +499,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
   // round trips per accumulator: +7 us on a 20 us launch of the Nystrom pseudo-inverse products, tests/diag_smallgemm.py).
   if (!g.atomic && m0 + FBM <= g.M && n0 + BN_ <= g.N) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * (BN_ / 2) + ni * 32 + c;
-        const int mb = m0 + wm * 64 + mi * 32;
+        const int mb = m0 + wm * (FBM / 2) + mi * 32;
         float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) rv[r] = res ? res[(long long)(mb + acc_row(r, hf)) * g.ldr + n] : 0.f;
@@ -517,14 +519,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
     return;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn * (BN_ / 2) + ni * 32 + c;
       if (n >= g.N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + acc_row(r, hf);
+        const int m = m0 + wm * (FBM / 2) + mi * 32 + acc_row(r, hf);
         if (m >= g.M) continue;
         float v = g.alpha * acc[mi][ni][r];
         if (g.atomic) {
@@ -548,6 +550,8 @@ static int g_mode = 0;            // 0: automatic, 1: fp32-MFMA tiled kernel onl
 extern "C" void smml_gemm_force_generic(int on) { g_force_generic = on; }
 extern "C" void smml_gemm_set_mode(int mode) { g_mode = mode; }
 extern "C" int smml_gemm_get_mode(void) { return g_mode; }
+static int g_small_tile = 0;      // 0: automatic, 1: never use the 64-row tile, 2: use it wherever it applies (measurement hooks)
+extern "C" void smml_gemm_set_small_tile(int v) { g_small_tile = v; }
 
 extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                              int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn,
@@ -585,10 +589,15 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
     // 128-wide column tiles only when they still fill the chip a few times over (2 workgroups per CU resident)
     const int bn = (N > 64 && gx * ((N + 127) / 128) * gz >= 1024) ? 128 : 64;
     const long long fy = (N + bn - 1) / bn;
+    // 64-row tiles for launches whose 128 x 64 tiling leaves the chip short of two workgroups per CU (the 32 x 256^3 products of
+    // the Nystrom pseudo-inverse: 256 workgroups, one wave per SIMD, every global-load latency exposed): twice the workgroups,
+    // half the work each
+    const bool small = bn == 64 && M > 64 && (g_small_tile == 2 || (g_small_tile == 0 && gx * fy * gz < 512));
+    const long long fx = small ? (M + 63) / 64 : gx;
     const int fswap = fy > 65535;
-    SMML_REQUIRE((fswap ? gx : fy) <= 65535, "smml_gemm_f32: grid too large");
+    SMML_REQUIRE((fswap ? fx : fy) <= 65535, "smml_gemm_f32: grid too large");
     g.swap_xy = fswap;
-    dim3 grid((unsigned)(fswap ? fy : gx), (unsigned)(fswap ? gx : fy), (unsigned)gz);
+    dim3 grid((unsigned)(fswap ? fy : fx), (unsigned)(fswap ? fx : fy), (unsigned)gz);
     hipStream_t st = (hipStream_t)stream;
     // Measured: in isolation (tests/bench_gemm.py) the split-bf16 kernel beats the fp32 MFMA kernel wherever K >= 128 and the
     // tile is not a 64-column sliver (107 vs 92 TF on the 80 000 x 128 x 512 projections of the headline step, 150 vs 118
@@ -603,7 +612,16 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
     else if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_fast_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g);     \
   } while (0)
-    if (bn == 128) {
+#define SMML_SMALL(AK, BK2)                                                                          \
+  do {                                                                                               \
+    if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 1, 64>), grid, dim3(256), 0, st, g);   \
+    else if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 3, 64>), grid, dim3(256), 0, st, g); \
+    else hipLaunchKernelGGL((gemm_f32_fast_kernel<64, AK, BK2, 64>), grid, dim3(256), 0, st, g);     \
+  } while (0)
+    if (small) {
+      if (a_kc && b_kc) SMML_SMALL(true, true); else if (a_kc) SMML_SMALL(true, false);
+      else if (b_kc) SMML_SMALL(false, true); else SMML_SMALL(false, false);
+    } else if (bn == 128) {
       if (a_kc && b_kc) SMML_FAST(128, true, true); else if (a_kc) SMML_FAST(128, true, false);
       else if (b_kc) SMML_FAST(128, false, true); else SMML_FAST(128, false, false);
     } else {
@@ -611,6 +629,7 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
       else if (b_kc) SMML_FAST(64, false, true); else SMML_FAST(64, false, false);
     }
 #undef SMML_FAST
+#undef SMML_SMALL
     SMML_LAUNCH_CHECK("smml_gemm_f32/fast");
     return SMML_OK;
   }

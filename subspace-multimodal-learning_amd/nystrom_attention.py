@@ -25,6 +25,7 @@ fp32 path is unchanged and is what the 1e-4 parity tests cover."""
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -93,6 +94,45 @@ def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
     return _NewtonSchulz.apply(x.contiguous(), z, iters)
 
 
+_SIDE_STREAMS = {}
+PINV_OVERLAP = os.environ.get("SMML_NYSTROM_OVERLAP", "1") != "0"     # measurement switch
+
+
+class _PinvFork:
+    """The pseudo-inverse is a chain of 24 (backward: 54) dependent 256^3 batched products, each too small to fill the chip (512
+    workgroups, ~17 us), and nothing else in the block needs its result before the last product: it runs on a second HIP stream
+    beside the n'-sized kernels (softmax(ql k^T) v, the residual convolution, their backward passes - autograd replays every
+    node on the stream of its forward).  fork() makes the side stream wait for what the main stream has produced so far; join()
+    makes the main stream wait for the side stream and tells the caching allocator that the tensors are now in use there."""
+
+    def __init__(self, like: torch.Tensor):
+        self.on = bool(PINV_OVERLAP and like.is_cuda)
+        if not self.on:
+            return
+        dev = like.device
+        self.main = torch.cuda.current_stream(dev)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.side = _SIDE_STREAMS.get(key)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        self.side.wait_stream(self.main)
+
+    def run(self, fn, *inputs):
+        if not self.on:
+            return fn(*inputs)
+        for t in inputs:
+            if torch.is_tensor(t):
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            return fn(*inputs)
+
+    def join(self, *outputs):
+        if self.on:
+            self.main.wait_stream(self.side)
+            for t in outputs:
+                t.record_stream(self.main)
+
+
 class NystromAttention(nn.Module):
     def __init__(self, dim, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True,
                  residual_conv_kernel=33, eps=1e-8, dropout=0., per_bag_pinv_scale: bool = False, compute_dtype=None):
@@ -135,13 +175,15 @@ class NystromAttention(nn.Module):
         q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)   # each [b, h, n', d]
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)  # landmarks (:102-118); ql unscaled
         sc = self.scale
-        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True, alpha=sc))       # [b, h, n', m]
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))      # [b, h, m, m]
+        fork = _PinvFork(a2)                                   # the pseudo-inverse runs beside the n'-sized products below
+        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
+        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True, alpha=sc))       # [b, h, n', m]
         a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True, alpha=sc))       # [b, h, m, n']
-        z = moore_penrose_iter_pinv(a2, self.pinv_iterations, self.per_bag_pinv_scale)
-        left = Fh.matmul4(a1, z)                               # [b, h, n', m]
         right = Fh.matmul4(a3, v)                              # [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None
+        fork.join(z)
+        left = Fh.matmul4(a1, z)                               # [b, h, n', m]
         out = Fh.matmul4(left, right, res, merged=True)        # [b, n', h*d]  (:140,144-146)
         out = Fh.linear(out, self.to_out[0].weight, self.to_out[0].bias)
         out = self.to_out[1](out)
@@ -169,10 +211,12 @@ class NystromAttention(nn.Module):
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
         sc = self.scale
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
-        z = moore_penrose_iter_pinv(a2, self.pinv_iterations, self.per_bag_pinv_scale)
+        fork = _PinvFork(a2)                                                                   # beside attn3 v and the residual convolution
+        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
         right = Fh.attention16(ql, k, v, scale=sc, fp16=fp16)                                  # softmax(ql k^T) v   [b, h, m, d]
-        w = Fh.matmul4(z, right)                                                               # z (attn3 v)          [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None                   # [b, n', h d]
+        fork.join(z)
+        w = Fh.matmul4(z, right)                                                               # z (attn3 v)          [b, h, m, d]
         out = Fh.attention16(q, kl, w, scale=sc, fp16=fp16, merged=True, residual=res)         # softmax(q kl^T) w + res
         wo, bo = self.to_out[0].weight, self.to_out[0].bias
         out = Fh.linear(out, wo, bo, prec=gm)

@@ -19,8 +19,8 @@ def t(fn, n=50, reps=20):
         for _ in range(reps): g.replay()
         e1.record(s); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (n * reps) * 1e3
-for mode in (0, 3):
-    smml.lib().smml_gemm_set_mode(mode)
+for mode, small in ((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3, 2)):
+    smml.lib().smml_gemm_set_mode(mode); smml.lib().smml_gemm_set_small_tile(small)
     for (B, M, N, K) in ((32, 256, 256, 256), (32, 256, 256, 512), (8, 256, 256, 256), (64, 256, 256, 256), (32, 512, 512, 256)):
         a = torch.randn(1, B, M, K, device=dev); b = torch.randn(1, B, K, N, device=dev); r = torch.randn(1, B, M, N, device=dev)
         out = torch.empty(1, B, M, N, device=dev)
@@ -31,7 +31,7 @@ for mode in (0, 3):
             bt = b.transpose(-1, -2).contiguous()
             kw2 = dict(kw); kw2.update(sbk=1, sbn=K)
             nt = t(lambda: Fh._gemm(a, bt, out, **kw2))
-        print(f"mode {mode}: {B} x [{M} x {K}] @ [{K} x {N}]  plain {plain:6.1f} us  +residual {resid:6.1f} us  NT {nt:6.1f} us   ({2 * B * M * N * K / plain / 1e6:6.1f} TF plain)")
-smml.lib().smml_gemm_set_mode(0)
+        print(f"mode {mode} tile {(128, 64)[small - 1]}: {B} x [{M} x {K}] @ [{K} x {N}]  plain {plain:6.1f} us  +residual {resid:6.1f} us  NT {nt:6.1f} us   ({2 * B * M * N * K / plain / 1e6:6.1f} TF plain)")
+smml.lib().smml_gemm_set_mode(0); smml.lib().smml_gemm_set_small_tile(0)
 x = torch.randn(1 << 20, device=dev)
 print(f"elementwise add on 4 MB: {t(lambda: x.add_(1.0)):.1f} us per launch in a graph")
