@@ -188,6 +188,115 @@ __global__ __launch_bounds__(256) void resconv_bwd_weight_kernel(const float* __
   if (tid < KW) atomicAdd(&dw[h * KW + tid], red[tid]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip forms of the three residual-convolution kernels for the reference's 33 taps (residual_conv_kernel = 33,
+// NystromAttention.py:62-66).  One thread owns one float4 of d and a strip of RCS_T = 16 consecutive tokens; it walks the
+// 48 input rows its strip meets ONCE, and every row feeds all the outputs it belongs to from registers (fully unrolled:
+// 16 x 33 float4 FMAs) - 3 row loads per output instead of 33 through the cache.  The kernels are then bound by the one
+// read and one write of the tensor.  Lanes of a wave hold 16 consecutive float4 of a row (256 contiguous bytes for D = 64)
+// for several strips.
+//   MODE 0: out[b, t, h D + d]  = sum_k w[h, k]      v[b, h, t + k - 16, d]      (v head-major in, merged out)
+//   MODE 1: dv[b, h, t, d]      = sum_k w[h, 32 - k] dout[b, t + k - 16, h D + d] (merged in, head-major out)
+// ------------------------------------------------------------------------------------------------
+constexpr int RCS_T = 16, RCS_KW = 33, RCS_HALF = 16;
+template <int MODE>
+__global__ __launch_bounds__(256) void resconv_strip_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            float* __restrict__ out, int B, int Hh, int n, int D) {
+  __shared__ float ws[64 * RCS_KW];                        // all heads' taps (Hh <= 64), flipped for the data gradient
+  for (int i = threadIdx.x; i < Hh * RCS_KW; i += 256) {
+    const int h = i / RCS_KW, k = i - h * RCS_KW;
+    ws[i] = w[h * RCS_KW + (MODE ? RCS_KW - 1 - k : k)];
+  }
+  __syncthreads();
+  const int d4n = D >> 2, strips = (n + RCS_T - 1) / RCS_T;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Hh * strips * d4n) return;
+  const int d4 = (int)(idx % d4n);
+  const int st = (int)((idx / d4n) % strips);
+  const int h = (int)((idx / ((long long)d4n * strips)) % Hh);
+  const int b = (int)(idx / ((long long)d4n * strips * Hh));
+  const int t0 = st * RCS_T;
+  const long long hm = (((long long)b * Hh + h) * n) * D + d4 * 4, hs = D;                  // head-major base / row stride
+  const long long mm = ((long long)b * n) * ((long long)Hh * D) + h * D + d4 * 4, ms = (long long)Hh * D;   // merged
+  const float* ip = in + (MODE ? mm : hm);
+  const long long is = MODE ? ms : hs;
+  float wk[RCS_KW];
+#pragma unroll
+  for (int k = 0; k < RCS_KW; ++k) wk[k] = ws[h * RCS_KW + k];
+  float4 acc[RCS_T];
+#pragma unroll
+  for (int i = 0; i < RCS_T; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < RCS_T + RCS_KW - 1; ++j) {
+    const int tj = t0 - RCS_HALF + j;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tj >= 0 && tj < n) x = *reinterpret_cast<const float4*>(ip + (long long)tj * is);
+#pragma unroll
+    for (int i = 0; i < RCS_T; ++i) {
+      const int k = j - i;                                  // tap that row j carries into output i
+      if (k >= 0 && k < RCS_KW) {
+        acc[i].x = fmaf(wk[k], x.x, acc[i].x); acc[i].y = fmaf(wk[k], x.y, acc[i].y);
+        acc[i].z = fmaf(wk[k], x.z, acc[i].z); acc[i].w = fmaf(wk[k], x.w, acc[i].w);
+      }
+    }
+  }
+  float* op = out + (MODE ? hm : mm);
+  const long long os = MODE ? hs : ms;
+#pragma unroll
+  for (int i = 0; i < RCS_T; ++i)
+    if (t0 + i < n) *reinterpret_cast<float4*>(op + (long long)(t0 + i) * os) = acc[i];
+}
+
+// dw[h, k] += sum_{b, t, d} dout[b, t, h D + d] v[b, h, t + k - 16, d]: the same walk with the roles exchanged - the strip's 16
+// dout rows sit in registers, every v row is read once and meets the taps it realises.  A block is (b, h, 256 RCS_SPT tokens):
+// 16 float4 columns x 16 strips side by side, RCS_SPT strips one after the other per thread; the 33 sums are reduced over the
+// wave by shuffles, over the block in LDS, and leave as 33 atomics per block (n = 10 240: 20 blocks per (b, h)).
+constexpr int RCS_SPT = 2;
+__global__ __launch_bounds__(256) void resconv_strip_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ v,
+                                                                  float* __restrict__ dw, int B, int Hh, int n, int D) {
+  __shared__ float red[RCS_KW];
+  const int tid = threadIdx.x, d4n = D >> 2;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (tid < RCS_KW) red[tid] = 0.f;
+  __syncthreads();
+  const int per = 256 / d4n;                               // strips side by side in the block (d4n divides 256: D in {4, .., 64} powers of two)
+  const int d4 = tid % d4n, sl = tid / d4n;
+  const float* vb = v + (((long long)b * Hh + h) * n) * D + d4 * 4;
+  const float* db = dout + ((long long)b * n) * ((long long)Hh * D) + h * D + d4 * 4;
+  const long long ms = (long long)Hh * D;
+  float s[RCS_KW];
+#pragma unroll
+  for (int k = 0; k < RCS_KW; ++k) s[k] = 0.f;
+  for (int rep = 0; rep < RCS_SPT; ++rep) {
+    const int t0 = ((blockIdx.x * RCS_SPT + rep) * per + sl) * RCS_T;
+    if (t0 >= n) break;
+    float4 g[RCS_T];
+#pragma unroll
+    for (int i = 0; i < RCS_T; ++i)
+      g[i] = (t0 + i < n) ? *reinterpret_cast<const float4*>(db + (long long)(t0 + i) * ms) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < RCS_T + RCS_KW - 1; ++j) {
+      const int tj = t0 - RCS_HALF + j;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tj >= 0 && tj < n) x = *reinterpret_cast<const float4*>(vb + (long long)tj * D);
+#pragma unroll
+      for (int i = 0; i < RCS_T; ++i) {
+        const int k = j - i;
+        if (k >= 0 && k < RCS_KW) s[k] = fmaf(g[i].x, x.x, fmaf(g[i].y, x.y, fmaf(g[i].z, x.z, fmaf(g[i].w, x.w, s[k]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RCS_KW; ++k) {
+    float t = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((tid & 63) == 0) atomicAdd(&red[k], t);
+  }
+  __syncthreads();
+  if (tid < RCS_KW) atomicAdd(&dw[h * RCS_KW + tid], red[tid]);
+}
+
 // PPEG: y[b, y, x, c] = bias[c] + sum_{ky,kx} wm[c, ky, kx] * x[b, y+ky-3, x+kx-3, c]  (wm = merged 7x7 incl. identity)
 __global__ __launch_bounds__(256) void dw7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wm,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int H,
@@ -303,8 +412,14 @@ int smml_resconv_fwd_f32(const float* v, const float* w, float* out_merged, int 
   SMML_REQUIRE(v && w && out_merged && B > 0 && H > 0 && n > 0 && D > 0 && D % 4 == 0 && KW > 0 && KW % 2 == 1,
                "smml_resconv_fwd_f32: bad argument (D %% 4 == 0, odd kernel)");
   const long long total = (long long)B * H * n * (D / 4);
-  hipLaunchKernelGGL(resconv_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, w,
-                     out_merged, B, H, n, D, KW);
+  if (KW == RCS_KW && H <= 64) {                              // the reference's 33 taps: strip kernel
+    const long long threads = (long long)B * H * ((n + RCS_T - 1) / RCS_T) * (D / 4);
+    hipLaunchKernelGGL(resconv_strip_kernel<0>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, w,
+                       out_merged, B, H, n, D);
+  } else {
+    hipLaunchKernelGGL(resconv_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, w,
+                       out_merged, B, H, n, D, KW);
+  }
   SMML_LAUNCH_CHECK("smml_resconv_fwd_f32");
   return SMML_OK;
 }
@@ -316,6 +431,18 @@ int smml_resconv_bwd_f32(const float* dout_merged, const float* v, const float* 
                "smml_resconv_bwd_f32: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const long long total = (long long)B * H * n * (D / 4);
+  const bool strip = KW == RCS_KW && H <= 64 && (D == 64 || D == 32 || D == 16 || D == 8 || D == 4) && B <= 65535 && H <= 65535;
+  if (strip) {
+    const long long threads = (long long)B * H * ((n + RCS_T - 1) / RCS_T) * (D / 4);
+    hipLaunchKernelGGL(resconv_strip_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, dout_merged, w, dv, B,
+                       H, n, D);
+    SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/data");
+    const int tokens_per_block = RCS_SPT * (256 / (D / 4)) * RCS_T;
+    hipLaunchKernelGGL(resconv_strip_wgrad_kernel, dim3((n + tokens_per_block - 1) / tokens_per_block, H, B), dim3(256), 0, st,
+                       dout_merged, v, dw, B, H, n, D);
+    SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/weight");
+    return SMML_OK;
+  }
   hipLaunchKernelGGL(resconv_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout_merged, w, dv, B,
                      H, n, D, KW);
   SMML_LAUNCH_CHECK("smml_resconv_bwd_f32/data");
