@@ -104,6 +104,11 @@ def ptr(t: Optional[torch.Tensor]):
                            "this path has no CPU fallback")
     if not t.is_contiguous():
         raise RuntimeError("smml kernels need contiguous tensors")
+    if t.device.index != torch.cuda.current_device():
+        # the C entry points launch on the current HIP device and stream() hands them that device's stream: a tensor of another
+        # device would be dereferenced by a kernel running elsewhere (one process per GPU: torch.cuda.set_device(LOCAL_RANK))
+        raise RuntimeError(f"smml kernels launch on the current device (cuda:{torch.cuda.current_device()}) but got a tensor on "
+                           f"{t.device}; call torch.cuda.set_device first (one process per GPU)")
     return C.c_void_p(t.data_ptr())
 
 
