@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
+    ap.add_argument("--graph", action="store_true", help="one GPU only: capture the step in a hipGraph and time replays (the per-kernel "
+                    "HIP-event times of `roofline` then come from the eager warm-up steps)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,7 +184,8 @@ def main():
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
     mil = mil.to(dev).train()              # train mode: attention dropout 0.1 (DeformCrossTransMIL.py:49) is active
     model = pkg.BagDataParallel(mil) if world > 1 else mil
-    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True)
+    use_graph = bool(a.graph and world == 1)
+    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True, capturable=use_graph)
     bloss = pkg.BatchLoss(B, world)
     # synthetic bags, resident in HBM before timing; a different bag set per rank (whole bags per rank)
     path = pkg.synth.bag(B, N, in_dim, 42 + rank, "bench:bag").to(dev)
@@ -202,16 +205,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    Fh.TIMER.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    Fh.TIMER.enabled = False
+    if use_graph:
+        # eager steps first (they also create the dropout replay counter and give the per-kernel event times), then one capture;
+        # every replay draws new dropout masks through the device-resident seed offset (include/smml.h)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            Fh.TIMER.enabled = True
+            for _ in range(max(a.warmup, 3)):
+                step()
+            Fh.TIMER.enabled = False
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay()
+        fence()
+        dt = time.perf_counter() - t0
+    else:
+        for _ in range(a.warmup):
+            step()
+        fence()
+        Fh.TIMER.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        Fh.TIMER.enabled = False
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -227,7 +253,7 @@ def main():
             "config": {"workload": f"DeformCrossTransMIL training step (fwd + bwd + Adam), bag {N} x {in_dim} fp32, "
                                    f"token grid {S}x{S}, {J} sampled keys, path_dim 128, heads 8, CE + BatchLoss",
                        "bags_per_gpu": B, "global_batch": B * world, "instances": N, "feature_dim": in_dim,
-                       "parallelism": f"dp{world} (whole bags per rank, RCCL gradient all-reduce)"},
+                       "parallelism": f"dp{world} (whole bags per rank, RCCL gradient all-reduce)" + (", step replayed from one hipGraph" if use_graph else "")},
         }
         if "cpb_bwd" in kt:
             n, ms, pairs = kt["cpb_bwd"]

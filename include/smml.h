@@ -153,6 +153,13 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                              void* ev_start, void* ev_stop, void* stream);
+/* hipGraph support for attention dropout.  `dropout_seed` is a host value and is baked into a captured launch; to give every
+ * replay its own mask, point the calling thread at a device-resident 64-bit offset first: the forward / backward / mask
+ * launches issued by this thread afterwards add *device_offset to dropout_seed when they RUN (the pointer is never dereferenced
+ * on the host).  The forward and the backward of one call must see the same value, so hand each call its own copy of the counter.
+ * nullptr (the default) restores the plain host seed.  Thread-local. */
+void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset);
+
 /* attention dropout (nn.Dropout on the probabilities, DeformableAttention2D.py:309 / 1D :229): dropout_p in
  * [0, 1) and a 64-bit seed select a counter-based keep decision per (b, h, query, key); pass the same pair to
  * forward and backward.  The mask itself (0 / 1 floats [B, H, N, J]) is only materialised for tests: */

@@ -183,7 +183,15 @@ struct DropCfg {
   unsigned long long seed;
   unsigned thresh;      // keep iff hash >= thresh; 0 disables dropout
   float keep_scale;
+  const unsigned long long* seed_dev;   // optional device-resident offset added to `seed` when the kernel runs (a launch captured in
+                                        // a hipGraph bakes `seed` in; the offset lets every replay draw a new mask), or nullptr
 };
+// the seed a launch uses: one uniform load per wave
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg dc) {
+  if (dc.thresh && dc.seed_dev) dc.seed += *dc.seed_dev;
+  dc.seed_dev = nullptr;
+  return dc;
+}
 // counter-based keep decision: the 64-bit counter (element index + seed) is folded to 32 bits and run through a 32-bit
 // avalanche mixer (two 32-bit multiplies; "lowbias32", C. Wellons).  For fewer than 2^32 elements the fold is injective, so
 // no two elements of a launch share a mixer input.  A 64-bit splitmix here cost eight 32-bit multiplies per element and
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
     float* __restrict__ LSE, float* __restrict__ LT, unsigned short* __restrict__ MK, int N, int J, int H, int G, int NST,
-    float scale, DropCfg dc) {
+    float scale, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
 #if SMML_FWD_QK16
   __shared__ __attribute__((aligned(16))) _Float16 Kp[2][KT * FRLD];         // K tile, fp16 hi / lo planes, row image (A operand of S^T)
   __shared__ __attribute__((aligned(16))) _Float16 Vp[2][KT * FTLD];         // V tile, hi / lo planes, read transposed (A operand of O^T)
@@ -558,7 +567,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
     float* __restrict__ dLT, float* __restrict__ dQ, float* __restrict__ RHO, int N, int J, int H, int NST,
-    float scale, DropCfg dc) {
+    float scale, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
   __shared__ __attribute__((aligned(16))) __bf16 Vp[2][3][KT * VBLD];
   __shared__ __attribute__((aligned(16))) __bf16 Kp[2][3][KT * KBLD];
 
@@ -718,7 +728,8 @@ constexpr int DKV_KEYS = KT * WAVES;
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ LT, const float* __restrict__ dLT, float* __restrict__ dKp,
-    float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, int nparts, int Bn, DropCfg dc) {
+    float* __restrict__ dVp, int N, int J, int H, int NST, int nkg, int tiles_per_part, int nparts, int Bn, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
   __shared__ __attribute__((aligned(16))) __bf16 Qp[2][3][QT * QBLD];
   __shared__ __attribute__((aligned(16))) __bf16 dOp[2][3][QT * QBLD];
   __shared__ __attribute__((aligned(16))) float nls[2][QT];   // -lse (times log2 e on the fast path) of the tile's queries
@@ -1333,16 +1344,22 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   return w;
 }
 
+// Device-resident seed offset of the NEXT fused-attention launches issued by this host thread (smml_deform_attn_set_seed_offset):
+// read into the launch's DropCfg, never dereferenced on the host.
+static thread_local const unsigned long long* t_seed_offset = nullptr;
+
 static DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg dc;
   dc.seed = seed;
+  dc.seed_dev = t_seed_offset;
   dc.thresh = (p > 0.f) ? (unsigned)((double)p * 4294967296.0) : 0u;
   dc.keep_scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
   return dc;
 }
 
 // keep-mask a launch with (dropout_p, dropout_seed) uses, as 0 / 1 floats [B, H, N, J] (tests only)
-__global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long total, DropCfg dc) {
+__global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long total, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) mask[i] = (dc.thresh == 0 || drop_hash(dc.seed, i) >= dc.thresh) ? 1.f : 0.f;
 }
@@ -1357,6 +1374,8 @@ extern "C" {
 // row stride of the key-major score / mask tensors: whole 128-query workgroup tiles, so that the forward stores its rows
 // without per-lane bounds checks (columns >= N are padding nobody reads)
 int smml_deform_attn_nst(int N) { return (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
+
+void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset) { t_seed_offset = device_offset; }
 
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
                                       void* stream) {

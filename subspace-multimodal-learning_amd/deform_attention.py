@@ -61,15 +61,18 @@ class CPB(nn.Module):
         return (m[0][0].weight, m[0][0].bias, m[1][0].weight, m[1][0].bias, m[2].weight, m[2].bias)
 
 
-def _dropout_args(mod):
+def _dropout_args(mod, device=None):
     """nn.Dropout semantics on the attention probabilities: active in train() with p > 0; the 64-bit seed of the
-    in-kernel counter-based mask is drawn from torch's default (CPU) generator, so torch.manual_seed reproduces it."""
+    in-kernel counter-based mask is drawn from torch's default (CPU) generator, so torch.manual_seed reproduces it.
+    While the step is being captured in a hipGraph the host seed would be the same in every replay: the call then also gets a
+    device-resident offset that a captured counter bumps per call and per replay (functional.graph_seed_offset)."""
     p = float(mod.dropout.p)
     if not mod.training or p <= 0.0:
         return {"dropout_p": 0.0, "dropout_seed": 0}
     seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
     mod.last_dropout_seed = seed
-    return {"dropout_p": p, "dropout_seed": seed}
+    off = Fh.graph_seed_offset(device) if device is not None and torch.device(device).type == "cuda" else None
+    return {"dropout_p": p, "dropout_seed": seed, "dropout_seed_offset": off}
 
 
 _GRID_CACHE = {}
@@ -156,7 +159,7 @@ class DeformCrossAttention2D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
-                                **_dropout_args(self))
+                                **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 
@@ -221,7 +224,7 @@ class DeformCrossAttention1D(nn.Module):
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
-                                scale=self.scale, **_dropout_args(self))
+                                scale=self.scale, **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 

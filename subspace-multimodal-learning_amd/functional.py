@@ -393,7 +393,7 @@ def bilinear_corners(vs, Hh: int, Ww: int, posdim: int):
 # ------------------------------------------------------------------------------------------------
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed):
+    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None):
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
         B, N, HD = q.shape
@@ -412,12 +412,15 @@ class _DeformAttn(torch.autograd.Function):
             nst = L.smml_deform_attn_nst(N)
             logits = torch.empty(B, heads, J, nst, device=q.device, dtype=torch.float32)
             masks = torch.empty(B, heads, J, 2, nst, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
+        _set_seed_offset(L, seed_offset)
         capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                               capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                               capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
                                               heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
                                               *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
                    "deform_attn_fwd")
+        _set_seed_offset(L, None)
+        ctx.seed_offset = seed_offset           # a device int64 [1] owned by this call (hipGraph replays: deform_attention)
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed))
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         return out
@@ -437,6 +440,7 @@ class _DeformAttn(torch.autograd.Function):
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
+        _set_seed_offset(L, ctx.seed_offset)
         capi.check(L.smml_deform_attn_bwd_f32(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
             capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
@@ -445,14 +449,49 @@ class _DeformAttn(torch.autograd.Function):
             capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
             *TIMER.events("cpb_bwd", B * heads * N * J),
             capi.stream()), "deform_attn_bwd")
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None
+        _set_seed_offset(L, None)
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None
+
+
+def _set_seed_offset(L, t):
+    if t is None:
+        L.smml_deform_attn_set_seed_offset(None)
+    else:
+        if t.dtype != torch.int64 or t.numel() != 1:
+            raise RuntimeError("dropout_seed_offset must be a device int64 tensor with one element")
+        L.smml_deform_attn_set_seed_offset(capi.ptr(t))
+
+
+_REPLAY_COUNTER = {}         # device index -> int64 [1]: bumped once per dropout call inside a captured graph
+
+
+def graph_seed_offset(device, allocate_only: bool = False):
+    """The per-call seed offset of a dropout launch that is being captured in a hipGraph: a device-resident counter is bumped and
+    copied (both operations are part of the graph), so every replay - and every call within a replay - draws a new mask while the
+    forward and the backward of one call read the same value.  The counter itself must exist before the capture starts (it would
+    otherwise live in the graph's private pool and be re-zeroed by every replay): any eager dropout call on the device creates it."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ctr = _REPLAY_COUNTER.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ctr is None:
+        if capturing:
+            raise RuntimeError("run one eager training step before capturing it in a graph (the dropout replay counter is created "
+                               "by the first eager call)")
+        ctr = _REPLAY_COUNTER[key] = torch.zeros(1, device=dev, dtype=torch.int64)
+    if allocate_only or not capturing:
+        return None
+    ctr.add_(1)
+    return ctr.clone()
 
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
-                     dropout_p: float = 0.0, dropout_seed: int = 0):
+                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
-    dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed."""
-    return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed)
+    dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
+    (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset)."""
+    return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
+                             dropout_seed_offset)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device):

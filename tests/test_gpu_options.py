@@ -141,3 +141,56 @@ def test_wrap_pad_to_square(cuda):
     mil2 = _load(smml.DeformCrossTransMIL(args2), params, cuda)
     with pytest.raises(ValueError):
         mil2(path, omic)
+
+
+def test_dropout_mask_changes_between_graph_replays(cuda):
+    """A training-mode DeformCrossAttention2D captured in a hipGraph: the host seed is baked into the captured launches, the
+    device-resident offset (include/smml.h: smml_deform_attn_set_seed_offset; functional.graph_seed_offset) makes every replay draw
+    a new dropout mask, and forward / backward of one call agree on it (the gradient of a replay matches an eager call that is
+    given the replay's effective seed)."""
+    import torch
+    Fh = smml.functional
+    torch.manual_seed(3)
+    gen = torch.Generator().manual_seed(11)
+    B, N, J, H, G, PD = 1, 96, 40, 8, 8, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * G, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+             w3=rn(H // G, 32) * 0.3, b3=rn(H // G) * 0.1)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    dev = {n: x.to(cuda).requires_grad_(n == "q") for n, x in t.items()}
+    Fh.graph_seed_offset(cuda, allocate_only=True)                       # what the first eager dropout call of a model does
+    out_s = torch.zeros(B, N, 512, device=cuda); dq_s = torch.zeros(B, N, 512, device=cuda); off_s = torch.zeros(1, device=cuda, dtype=torch.int64)
+    seed = 12345
+
+    def call():
+        off = Fh.graph_seed_offset(cuda)
+        o = Fh.deform_attention(*(dev[n] for n in names), heads=H, groups=G, scale=0.125, dropout_p=0.25, dropout_seed=seed,
+                                dropout_seed_offset=off)
+        dev["q"].grad = None
+        o.sum().backward()
+        out_s.copy_(o.detach()); dq_s.copy_(dev["q"].grad); off_s.copy_(off)
+
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        # warm-up outside the capture (no offset in eager mode)
+        o = Fh.deform_attention(*(dev[n] for n in names), heads=H, groups=G, scale=0.125, dropout_p=0.25, dropout_seed=seed)
+        o.sum().backward()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            call()
+    torch.cuda.current_stream().wait_stream(s)
+    seen = []
+    for _ in range(3):
+        g.replay(); torch.cuda.synchronize()
+        off = int(off_s)
+        seen.append((off, out_s.clone(), dq_s.clone()))
+        # an eager call with the effective seed reproduces the replay (forward and backward agree on the mask)
+        dev["q"].grad = None
+        o = Fh.deform_attention(*(dev[n] for n in names), heads=H, groups=G, scale=0.125, dropout_p=0.25, dropout_seed=seed + off)
+        o.sum().backward()
+        assert torch.equal(o.detach(), out_s), "forward of the replay differs from the eager call with its effective seed"
+        assert_close("dq of a graph replay vs eager with the same effective seed", dq_s, dev["q"].grad, 1e-6)
+    assert seen[0][0] != seen[1][0] != seen[2][0]
+    assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1]), "replays must draw different masks"
