@@ -58,6 +58,10 @@
                               // is unchanged to three digits vs 3 terms (tests/diag_gterms.py: it is set by ReLU mask flips
                               // and by delta = rowsum(dO . O)), and the kernel is 10 % faster.  3: fp32-grade summands.
 #endif
+#ifndef SMML_BWD_TERMS
+#define SMML_BWD_TERMS 3      // bf16 terms per operand in the dq / dkv passes: 3 = fp32-grade (six products per block), 2 = 16-bit operands
+                              // (hi + mid, three products: measurement switch, profiles/r02_split_terms.txt)
+#endif
 #ifndef SMML_FWD_QK16
 #define SMML_FWD_QK16 1       // forward QK^T / PV on the 16-bit matrix pipe: every operand as fp16 hi + lo (RNE, 22 bits), three of the
                               // four cross products (hi hi, hi lo, lo hi; <= 2^-22 dropped) - 24 MFMAs of 32 cycles per 32-key tile
@@ -232,6 +236,17 @@ __device__ __forceinline__ float pow2_lift(float amax, float target, float lo, f
   if (!(amax > 0.f)) return 1.f;
   const float k = floorf(log2f(target / amax));
   return ldexpf(1.f, (int)fminf(fmaxf(k, lo), hi));      // an exact power of two (exp2f is the 1-ulp hardware approximation)
+}
+
+// one 32x32x16 block of a backward contraction from split operands
+__device__ __forceinline__ floatx16 bwd_prod(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, floatx16 d) {
+#if SMML_BWD_TERMS == 3
+  return mfma16b_x6(ah, am, al, bh, bm, bl, d);
+#else
+  d = mfma16b(am, bh, d);
+  d = mfma16b(ah, bm, d);
+  return mfma16b(ah, bh, d);
+#endif
 }
 
 struct CpbParams {
@@ -639,11 +654,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       split4_bf3(vreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&Vp[buf][0][key * VBLD + sd4]) = hh;
       *reinterpret_cast<uint2v*>(&Vp[buf][1][key * VBLD + sd4]) = mm;
-      *reinterpret_cast<uint2v*>(&Vp[buf][2][key * VBLD + sd4]) = ll;
+      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&Vp[buf][2][key * VBLD + sd4]) = ll;
       split4_bf3(kreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&Kp[buf][0][key * KBLD + sd4]) = hh;
       *reinterpret_cast<uint2v*>(&Kp[buf][1][key * KBLD + sd4]) = mm;
-      *reinterpret_cast<uint2v*>(&Kp[buf][2][key * KBLD + sd4]) = ll;
+      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&Kp[buf][2][key * KBLD + sd4]) = ll;
     }
     __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2, which every wave left before this barrier's
                             // predecessor: one barrier per tile is enough
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&Vp[buf][0][o]);
       const bf16x8 vm = *reinterpret_cast<const bf16x8*>(&Vp[buf][1][o]);
       const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&Vp[buf][2][o]);
-      dp = mfma16b_x6(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
+      dp = bwd_prod(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
     }
 
     float ds[16];
@@ -693,8 +708,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         const bf16x8 kh = lds_frag_tr(&Kp[buf][0][ro + 32 * db], &Kp[buf][0][ro + 32 * db + 8 * KBLD]);
         const bf16x8 km = lds_frag_tr(&Kp[buf][1][ro + 32 * db], &Kp[buf][1][ro + 32 * db + 8 * KBLD]);
         const bf16x8 kl = lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]);
-        if (db == 0) dq0 = mfma16b_x6(kh, km, kl, sh, sm, sl, dq0);
-        else dq1 = mfma16b_x6(kh, km, kl, sh, sm, sl, dq1);
+        if (db == 0) dq0 = bwd_prod(kh, km, kl, sh, sm, sl, dq0);
+        else dq1 = bwd_prod(kh, km, kl, sh, sm, sl, dq1);
       }
     }
   }
@@ -790,11 +805,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
       split4_bf3(qreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&Qp[buf][0][o]) = hh;
       *reinterpret_cast<uint2v*>(&Qp[buf][1][o]) = mm;
-      *reinterpret_cast<uint2v*>(&Qp[buf][2][o]) = ll;
+      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&Qp[buf][2][o]) = ll;
       split4_bf3(doreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&dOp[buf][0][o]) = hh;
       *reinterpret_cast<uint2v*>(&dOp[buf][1][o]) = mm;
-      *reinterpret_cast<uint2v*>(&dOp[buf][2][o]) = ll;
+      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&dOp[buf][2][o]) = ll;
     }
     if (tid < QT) nls[buf][tid] = prob_bias(lsereg);
     __syncthreads();        // one barrier per tile (double buffer, see pass 1)
@@ -839,8 +854,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
           const bf16x8 qh = lds_frag_tr(&Qp[buf][0][o], &Qp[buf][0][o + 8 * QBLD]);
           const bf16x8 qm = lds_frag_tr(&Qp[buf][1][o], &Qp[buf][1][o + 8 * QBLD]);
           const bf16x8 ql = lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]);
-          if (db == 0) { dv0 = mfma16b_x6(ah, am, al, ph, pm, pl, dv0); dk0 = mfma16b_x6(qh, qm, ql, sh, sm, sl, dk0); }
-          else { dv1 = mfma16b_x6(ah, am, al, ph, pm, pl, dv1); dk1 = mfma16b_x6(qh, qm, ql, sh, sm, sl, dk1); }
+          if (db == 0) { dv0 = bwd_prod(ah, am, al, ph, pm, pl, dv0); dk0 = bwd_prod(qh, qm, ql, sh, sm, sl, dk0); }
+          else { dv1 = bwd_prod(ah, am, al, ph, pm, pl, dv1); dk1 = bwd_prod(qh, qm, ql, sh, sm, sl, dk1); }
         }
       }
     }
