@@ -11,6 +11,8 @@ per GPU: DeformCrossTransMIL forward (fc1 -> fusion -> LayerNorm -> 2-D deformab
 continuous position bias over a 100 x 100 token grid / 625 sampled keys -> pooler -> heads), cross-entropy +
 BatchLoss (gathered over ranks), backward, gradient all-reduce (RCCL), Adam step.  Inputs are resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0.
+After the timed region, at N = 1 only: `roofline.traffic` from two child runs of this script under rocprofv3 --pmc (FETCH_SIZE,
+WRITE_SIZE; --no-traffic skips them), the Nystrom legs (extra key `nystrom`; --no-nystrom) and the CPU baseline (--no-cpu-baseline).
 """
 from __future__ import annotations
 
@@ -47,6 +49,44 @@ def measured_traffic(kernel, bags):
         return t["kernels"][kernel]["hbm_bytes_per_launch"] * bags / t["bags_per_launch"]
     except Exception:
         return None
+
+
+def live_traffic(kernel_substr, argv_tail, timeout=300):
+    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, collected NOW: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; the
+    children are started as subprocesses - nothing is exec'd from this GPU-initialised process).  gfx950 correction of the guide:
+    FETCH_SIZE counts 128-byte requests as 64 bytes (x 2 for wide coalesced reads); both counters are in KB.
+    -> (bytes per launch, note) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="smml_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), *argv_tail]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            acc = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, f"no {counter} rows for {kernel_substr}"
+            vals[counter] = sum(acc) / len(acc)
+        except Exception as e:        # a profiler hiccup must not cost the bench line
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0, (
+        f"live: two child runs of this script under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the "
+        f"kernel's dispatches; FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 (gfx950) + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB")
 
 
 def nystrom_flop(n, D=512, h=8, d=64, m=256, iters=6, k=33):
@@ -149,6 +189,7 @@ def main():
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
     ap.add_argument("--graph", action="store_true", help="one GPU only: capture the step in a hipGraph and time replays (the per-kernel "
                     "HIP-event times of `roofline` then come from the eager warm-up steps)")
     a = ap.parse_args()
@@ -263,18 +304,24 @@ def main():
             kname = "cpb_bwd_kernel<2>"
             # dominant kernel.  Every contraction issues on the 16-bit matrix pipe (split fp16 / bf16 products, fp32-grade
             # results), so the algorithmic flops are priced against THAT pipe's dense peak; what actually bounds the kernel is
-            # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~230 vector instructions per 12 MFMAs.
+            # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~265 vector instructions per 12 MFMAs.
+            traffic, tsrc = None, "not collected (--no-traffic, or N > 1)"
+            if world == 1 and not a.no_traffic:
+                traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
+                                                                "--no-traffic", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
+            if traffic is None and (S, in_dim) == (100, 512):
+                traffic = measured_traffic(kname, B)
+                tsrc = f"replayed from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, committed); live collection: {tsrc}"
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
-                               "traffic": measured_traffic(kname, B) if (S, in_dim) == (100, 512) else None,
-                               "traffic_source": f"replayed from profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command)",
+                               "traffic": traffic, "traffic_source": tsrc,
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                "issued_16bit": {"achieved": issued, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": issued / F16_MFMA_PEAK_TFLOPS},
                                "note": "achieved = algorithmic flops (4480 per (query, key) pair and head, SURVEY 8(d), recompute not counted) / "
                                        "HIP-event time of the kernel, against the dense 16-bit MFMA peak (the pipe its 12 MFMAs per (key, 32 "
                                        "queries) issue on); issued_16bit prices the MFMAs actually executed.  The kernel is vector-issue "
-                                       "bound: ~230 VALU instructions per 12 MFMAs, two waves per SIMD."}
+                                       "bound: ~265 VALU instructions per 12 MFMAs, two waves per SIMD."}
         if "deform_attn_fwd" in kt:
             n, ms, pairs = kt["deform_attn_fwd"]
             flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
@@ -283,7 +330,7 @@ def main():
                                    "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
                                    "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                    "note": f"2496 algorithmic flop per pair (position-bias MLP 2240 + QK^T / PV 256) against the dense 16-bit "
-                                           f"MFMA peak; {CPB_FWD_MFMAS} 16-bit MFMAs + ~145 vector instructions per (key, 32 queries)"}
+                                           f"MFMA peak; {CPB_FWD_MFMAS} + 24/32 16-bit MFMAs + ~170 vector instructions per (key, 32 queries)"}
         if world == 1 and not a.no_nystrom:
             # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`)
             out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),

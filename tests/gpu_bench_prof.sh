@@ -7,7 +7,7 @@ run() { local name=$1 t=$2; shift 2; echo "=== $name"; timeout -k 10 "$t" "$@" >
   if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "!!! $name died (rc $rc): stopping"; exit $rc; fi; return $rc; }
 run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" || exit 1
 run bench 900 python bench.py || exit 1
-A="--steps 3 --warmup 1 --no-cpu-baseline --no-nystrom"
+A="--steps 3 --warmup 1 --no-cpu-baseline --no-nystrom --no-traffic"
 run rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py $A || exit 1
 find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} sh -c 'echo "--- {}"; head -16 {} | cut -c1-200'
 run pmc1 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -- python bench.py $A || exit 1

@@ -9,7 +9,7 @@ for name in ${VARIANTS:-base s5 dfix s5dfix}; do
   cat gpurun_out/var_${name}_diag.log
   SMML_LIB=$PWD/$V/$name.so timeout -k 10 300 python tests/diag_gterms.py 3000 300 active ${ACTIVE_MODE:-small} > gpurun_out/var_${name}_diag_active.log 2>&1 || { echo "diag rc=$?"; exit 1; }
   cat gpurun_out/var_${name}_diag_active.log
-  SMML_LIB=$PWD/$V/$name.so timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/var_${name}_bench.log 2>&1 || { echo "bench rc=$?"; tail -5 gpurun_out/var_${name}_bench.log; exit 1; }
+  SMML_LIB=$PWD/$V/$name.so timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic > gpurun_out/var_${name}_bench.log 2>&1 || { echo "bench rc=$?"; tail -5 gpurun_out/var_${name}_bench.log; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/var_${name}_bench.log").read().strip().splitlines()[-1])
