@@ -5,7 +5,7 @@ import argparse
 import pytest
 import torch
 
-from helpers import Golden, params_for, rel_err, smml, synth
+from helpers import Golden, assert_close, params_for, rel_err, smml, synth
 from oracle.nystrom import nystrom_attention, pinv_newton_schulz, ppeg, trans_layer, trans_mil
 from test_gpu_parity import _assert_close, _calibrated, _load
 
@@ -204,3 +204,57 @@ def test_cmta_reference_bag_size_train_mode(cuda):
     (torch.nn.functional.cross_entropy(out[0], torch.randint(0, 4, (8,), device=cuda)) + l1).backward()
     for k, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.parametrize("B,H,n,D,KW", [(1, 8, 5, 64, 33), (2, 8, 17, 64, 33), (1, 3, 48, 32, 33), (2, 8, 1000, 64, 33), (1, 8, 531, 16, 33),
+                                        (2, 4, 70, 64, 9), (1, 2, 40, 24, 33)])
+def test_resconv_strip_kernels_vs_torch(cuda, B, H, n, D, KW):
+    """The 33-tap residual convolution (NystromAttention.py:62-66,144-145) on its own: the strip kernels (16 tokens per thread,
+    every row read once) at lengths below / across / far beyond a strip, head dims the weight-gradient walk supports (powers of
+    two) and one it does not (24: generic kernels), and a tap count that takes the generic path - against F.conv2d in fp64."""
+    gen = torch.Generator().manual_seed(B * 1000 + n)
+    v = torch.randn(B, H, n, D, generator=gen)
+    w = torch.randn(H, 1, KW, 1, generator=gen) * 0.2
+    wo = torch.randn(B, n, H * D, generator=gen)
+    vd, wd = v.to(cuda).requires_grad_(), w.to(cuda).requires_grad_()
+    out = Fh.resconv(vd, wd)                                            # [B, n, H*D]
+    (out * wo.to(cuda)).sum().backward()
+    v64, w64 = v.double().requires_grad_(), w.double().requires_grad_()
+    ref = torch.nn.functional.conv2d(v64, w64, padding=(KW // 2, 0), groups=H)        # [B, H, n, D]
+    ref = ref.permute(0, 2, 1, 3).reshape(B, n, H * D)
+    (ref * wo.double()).sum().backward()
+    tag = f"resconv B={B} H={H} n={n} D={D} KW={KW}"
+    assert_close(tag + " out", out, ref, 1e-5)
+    assert_close(tag + " dv", vd.grad, v64.grad, 1e-5)
+    assert_close(tag + " dw", wd.grad, w64.grad, 1e-5)
+
+
+def test_pinv_side_stream_is_bit_identical(cuda):
+    """NystromAttention runs its pseudo-inverse on a second stream (nystrom_attention._PinvFork): with and without the overlap the
+    block's output and every gradient are the same bits (the same kernels on the same data; only the stream differs)."""
+    import importlib
+    na = importlib.import_module(smml.__name__ + ".nystrom_attention")
+    torch.manual_seed(0)
+    mod = smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=64, pinv_iterations=6, residual=True).to(cuda)
+    x = torch.randn(2, 300, 512, generator=torch.Generator().manual_seed(4)).to(cuda)
+    res = {}
+    for flag in (True, False, True):
+        na.PINV_OVERLAP = flag
+        try:
+            xi = x.clone().requires_grad_()
+            mod.zero_grad(set_to_none=True)
+            out = mod(xi)
+            out.square().sum().backward()
+            torch.cuda.synchronize()
+            got = [out.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+        finally:
+            na.PINV_OVERLAP = True
+        if flag in res:
+            continue
+        res[flag] = got
+    # atomically accumulated weight gradients (split-K GEMMs, res_conv.weight) are not run-to-run identical: compare those to 1e-6
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        if i < 2:
+            assert torch.equal(a, b), f"tensor {i} differs between overlapped and serial execution"
+        else:
+            assert_close(f"param grad {i} overlapped vs serial", a, b, 1e-6)
