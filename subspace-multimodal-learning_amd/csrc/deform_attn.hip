@@ -928,10 +928,12 @@ template <int PD>
 __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const unsigned short* __restrict__ MK, const float* __restrict__ LT,
     const float* __restrict__ LSE, const float* __restrict__ RHO, const float* __restrict__ VS,
-    const float* __restrict__ GQ, CpbParams cp, float* __restrict__ slab, float* __restrict__ dVS, int N, int J, int H,
+    const float* __restrict__ GQ, CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H,
     int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: tab[2][2][16] | dvs[J*2, padded to 4] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
+  // layout: tab[2][2][16] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
+  // d vs: every wave writes the sums over its 32 queries, 16 keys at a time, to its own slab row [wg * WAVES + wave][J][2];
+  // dvs_reduce_kernel adds the rows of a (bag, group) in a fixed order (no atomics: run-to-run identical, no limit on J)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
@@ -940,11 +942,11 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   const int qi = qvalid ? (q0 + c) : (N - 1);
 
   float* tab = smem;
-  float* dvs = smem + CPB2_TAB;                             // [J][2]
-  float* wbase = dvs + ((2 * J + 3) & ~3);
+  float* wbase = smem + CPB2_TAB;
   float* xq = wbase + wave * CPB2_WAVE_LDS;                 // [2][32]
   float2* stg = reinterpret_cast<float2*>(xq + CPB_XQ);     // [16 keys][65]
-  for (int i = tid; i < 2 * J; i += 256) dvs[i] = 0.f;
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float2* dvs_row = reinterpret_cast<float2*>(dvs_slab) + (size_t)(wg * WAVES + wave) * J;
   if (tid < 32) {                                           // tid = 16 half + r
     const int ch = acc_row(tid & 15, tid >> 4);
     tab[(tid >> 4) * 32 + (tid & 15)] = cp.w1[ch * PD];
@@ -1218,61 +1220,86 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
         }
       }
       sx = xhalf_sum(sx); sy = xhalf_sum(sy);
-      if (hf == 0 && kk < nrow) {
-        const int key = (j & ~(CPB2_STG_KEYS - 1)) + kk;
-        atomicAdd(&dvs[2 * key], sx);
-        if (PD == 2) atomicAdd(&dvs[2 * key + 1], sy);
-      }
+      if (hf == 0 && kk < nrow) dvs_row[(j & ~(CPB2_STG_KEYS - 1)) + kk] = make_float2(sx, (PD == 2) ? sy : 0.f);
       asm volatile("" ::: "memory");
     }
   }
 
-  // ---- workgroup reduction of the per-lane partials -> slab[wg] ----
+  // ---- workgroup reduction of the per-lane partials -> slab[wg]: every wave fills its own copy of the slab in LDS with plain
+  //      stores (one writer per address; LDS operations of a wave execute in program order), the copies are added in a fixed
+  //      order - no float atomics, so the parameter gradients are run-to-run identical ----
   __syncthreads();
-  float* red = wbase + WAVES * CPB2_WAVE_LDS;               // [CPB_SLAB] accumulators in LDS
-  for (int i = tid; i < CPB_SLAB; i += 256) red[i] = 0.f;
-  __syncthreads();
+  float* red = wbase + WAVES * CPB2_WAVE_LDS + wave * CPB_SLAB;   // this wave's [CPB_SLAB]
+  for (int i = lane; i < CPB_SLAB; i += 64) red[i] = 0.f;
   {
-    const float s2s = s2[0] + s2[1];
-    atomicAdd(&red[1024 + 64 + 32 + c], w3c * s2s);                    // db2[c] = w3[c] sum mask . d bias
-    // dW3[out] = sum relu(D + b2) . d bias = sum_in W2[out][in] e[out][in] + b2[out] sum mask . d bias: nothing of it
-    // has to be accumulated per key (the first term is added row by row below)
-    atomicAdd(&red[1024 + 64 + 32 + 32 + c], b2c * s2s);
+    const float s2s = xhalf_sum(s2[0] + s2[1]);                       // both lane halves: sum mask . d bias of out = c
+    if (hf == 0) {
+      red[1024 + 64 + 32 + c] = w3c * s2s;                            // db2[c] = w3[c] sum mask . d bias
+      // dW3[out] = sum relu(D + b2) . d bias = sum_in W2[out][in] e[out][in] + b2[out] sum mask . d bias: nothing of it
+      // has to be accumulated per key (the first term is added row by row below)
+      red[1024 + 64 + 32 + 32 + c] = b2c * s2s;
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = acc_row(r, hf);
-    atomicAdd(&red[row * CH + c], 0.5f * e[r] * cp.w3[oi * CH + row]); // dW2[out = row][in = c]  (e holds 2 x the sum)
+    red[row * CH + c] = 0.5f * e[r] * cp.w3[oi * CH + row];           // dW2[out = row][in = c]  (e holds 2 x the sum)
     float v;
     v = 0.5f * e[r] * cp.w2[row * CH + c];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + row], v);
+    if (c == 0) red[1024 + 64 + 32 + 32 + row] += v;                   // after the store above (same wave: in order)
     v = ab1[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + 64 + row], v);
+    if (c == 0) red[1024 + 64 + row] = v;
     v = aw1x[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2], v);
+    if (c == 0) red[1024 + row * 2] = v;
     v = aw1y[r >> 1][r & 1];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (c == 0) atomicAdd(&red[1024 + row * 2 + 1], v);
+    if (c == 0) red[1024 + row * 2 + 1] = v;
   }
   {
     float v = wave_sum(ab3);
-    if (lane == 0) atomicAdd(&red[1024 + 64 + 32 + 32 + 32], v);
+    if (lane == 0) red[1024 + 64 + 32 + 32 + 32] = v;
   }
   __syncthreads();
-  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   float* sl = slab + (size_t)wg * CPB_SLAB;
-  for (int i = tid; i < CPB_SLAB; i += 256) sl[i] = red[i];
-  float* dVSb = dVS + (size_t)(b * G + g) * J * PD;
-  for (int i = tid; i < J * PD; i += 256) {
-    const int j = i / PD, comp = i - j * PD;
-    atomicAdd(&dVSb[i], dvs[2 * j + comp]);
+  const float* r0 = wbase + WAVES * CPB2_WAVE_LDS;
+  for (int i = tid; i < CPB_SLAB; i += 256)
+    sl[i] = (r0[i] + r0[CPB_SLAB + i]) + (r0[2 * CPB_SLAB + i] + r0[3 * CPB_SLAB + i]);
+}
+
+// dVS[(b, g)][j][0..PD) = sum over the heads of the group, the query tiles and the four waves of a workgroup of the slab rows, in
+// that fixed order: four lanes per output (one per wave slot) walk the o * qtiles workgroups, then combine.
+__global__ __launch_bounds__(256) void dvs_reduce_kernel(const float2* __restrict__ rows, float* __restrict__ dVS, int Bn, int G,
+                                                         int H, int qtiles, int J, int PD) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = (int)(t & 3);
+  const long long out = t >> 2;                       // (b * G + g) * J + j
+  const bool ok = out < (long long)Bn * G * J;
+  float2 s = make_float2(0.f, 0.f);
+  if (ok) {
+    const int j = (int)(out % J);
+    const int bg = (int)(out / J), b = bg / G, g = bg - b * G, o = H / G;
+    for (int oi = 0; oi < o; ++oi) {
+      const float2* p = rows + ((size_t)((b * H + g * o + oi) * qtiles) * WAVES + w) * J + j;
+#pragma unroll 8
+      for (int x = 0; x < qtiles; ++x) {
+        const float2 v = p[(size_t)x * WAVES * J];
+        s.x += v.x; s.y += v.y;
+      }
+    }
+  }
+  // lanes 4 k .. 4 k + 3 hold the four wave slots of one output: (w0 + w1) + (w2 + w3)
+  s.x += __shfl_xor(s.x, 1); s.y += __shfl_xor(s.y, 1);
+  s.x += __shfl_xor(s.x, 2); s.y += __shfl_xor(s.y, 2);
+  if (ok && w == 0) {
+    dVS[out * PD] = s.x;
+    if (PD == 2) dVS[out * PD + 1] = s.y;
   }
 }
 
@@ -1344,7 +1371,7 @@ static int dkv_parts(int B, int N, int J, int H) {
 // workspace layout (floats): [CPB slabs nwg * CPB_SLAB][stage-1 partials CHUNKS * CPB_SLAB * 2]
 //                            [dK slabs parts * B*J*H*64][dV slabs parts * B*J*H*64]
 struct BwdWorkspace {
-  size_t slab, partial, dkp, dvp, rho, total;   // float offsets / total floats
+  size_t slab, partial, dkp, dvp, rho, dvs, total;   // float offsets / total floats
 };
 static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   BwdWorkspace w;
@@ -1355,7 +1382,8 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   w.dkp = (w.partial + (size_t)CPB_RED_CHUNKS * CPB_SLAB * 2 + 3) & ~(size_t)3;
   w.dvp = w.dkp + kv;
   w.rho = w.dvp + kv;                      // [B, H, N] row sums of d scores (SMML_DELTA_FIX)
-  w.total = w.rho + (((size_t)B * H * N + 3) & ~(size_t)3);
+  w.dvs = w.rho + (((size_t)B * H * N + 3) & ~(size_t)3);     // [nwg * WAVES][J][2] d vs rows of the position-bias backward
+  w.total = w.dvs + nwg * WAVES * (size_t)J * 2;
   return w;
 }
 
@@ -1499,21 +1527,23 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   }
   // pass 3: position-bias MLP backward
   {
-    hipError_t e = hipMemsetAsync(dvs, 0, (size_t)B * G * J * posdim * sizeof(float), st);
-    if (e != hipSuccess) { smml_set_error("smml_deform_attn_bwd_f32: memset failed"); return SMML_ERR_HIP; }
     float* slab = (float*)workspace;
-    const size_t lds = ((size_t)CPB2_TAB + ((2 * J + 3) & ~3) + WAVES * CPB2_WAVE_LDS + CPB_SLAB) * sizeof(float);
-    SMML_REQUIRE(lds <= 80 * 1024, "smml_deform_attn_bwd_f32: J = %d too large for the LDS accumulator", J);
+    const size_t lds = ((size_t)CPB2_TAB + WAVES * CPB2_WAVE_LDS + WAVES * CPB_SLAB) * sizeof(float);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
       hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
-                         wsf + wsl.rho, vs, gq, cp, slab, dvs, N, J, H, G, nst);
+                         wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
-                         wsf + wsl.rho, vs, gq, cp, slab, dvs, N, J, H, G, nst);
+                         wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/cpb");
     const int nwg = qtiles * H * B;
+    {
+      const long long threads = (long long)B * G * J * 4;
+      hipLaunchKernelGGL(dvs_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                         reinterpret_cast<const float2*>(wsf + wsl.dvs), dvs, B, G, H, qtiles, J, posdim);
+    }
     const int nchunks = min(CPB_RED_CHUNKS, nwg), chunk = (nwg + nchunks - 1) / nchunks;
     hipLaunchKernelGGL(cpb_partial_kernel, dim3((CPB_SLAB + 63) / 64, nchunks), dim3(256), 0, st, slab, nwg, H / G, qtiles,
                        H, chunk, wsf + wsl.partial);

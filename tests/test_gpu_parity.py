@@ -586,6 +586,28 @@ def test_fused_core_random_shapes(cuda):
                 assert e <= tol, f"{tag} d{n}: l2 err {e:.3e} > {tol:.3e} (margin {margin:.1e})"
 
 
+def test_fused_core_gradients_are_run_to_run_identical(cuda):
+    """Every gradient of the fused attention core is reduced in a fixed order (per-workgroup / per-wave slabs, no float atomics):
+    two runs on the same inputs give the same bits - d vs included (it used to go through LDS + HBM atomics)."""
+    gen = torch.Generator().manual_seed(21)
+    B, N, J, heads, groups, PD = 2, 700, 150, 8, 4, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+             w3=rn(heads // groups, 32) * 0.3, b3=rn(heads // groups) * 0.1)
+    wo = rn(B, N, 512).to(cuda)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    runs = []
+    for _ in range(2):
+        dev = {n: x.to(cuda).requires_grad_(n != "gq") for n, x in t.items()}
+        out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=0.1, dropout_seed=5)
+        (out * wo).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({n: dev[n].grad.clone() for n in names if n != "gq"} | {"out": out.detach().clone()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), f"{n} differs between two runs"
+
+
 def test_saved_relu_masks_match_reference(cuda):
     """What the fused forward keeps of the position bias's hidden layer for its backward: one bit per unit
     (include/smml.h: relu_masks [B, H, J, 2, nst] uint16, hidden channel acc_row(r, half) of lane (query, half) at bit
