@@ -141,10 +141,11 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
                              unsigned short* relu_masks, int B, int N, int J, int H, int G, int posdim, float scale,
                              float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
-/* scratch the backward needs: position-bias gradient slabs and the query-sliced dK / dV partial sums; 16-byte aligned */
+/* scratch the backward needs: position-bias gradient slabs, the per-wave d vs rows and the query-sliced dK / dV partial sums;
+ * 16-byte aligned */
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
 /* dlogits_t: scratch of logits_t's size (receives d scores); dq / dk / dv / dw* / db* overwritten;
- * dvs overwritten (zeroed inside). */
+ * dvs overwritten.  Every output is reduced in a fixed order (no float atomics): run-to-run identical results. */
 int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, const float* out, const float* dout,
