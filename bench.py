@@ -51,7 +51,7 @@ def measured_traffic(kernel, bags):
         return None
 
 
-def live_traffic(kernel_substr, argv_tail, timeout=300):
+def live_traffic(kernel_substr, argv_tail, timeout=150):
     """HBM bytes per launch of the kernel whose name contains `kernel_substr`, collected NOW: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; the
     children are started as subprocesses - nothing is exec'd from this GPU-initialised process).  gfx950 correction of the guide:
@@ -61,6 +61,10 @@ def live_traffic(kernel_substr, argv_tail, timeout=300):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # already running under a profiler / tool library (its environment would be inherited by the children): do not nest
+    tooled = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER")) or k == "HSA_TOOLS_LIB"]
+    if tooled or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler (" + ", ".join(tooled[:3] or ["LD_PRELOAD"]) + "): PMC child runs skipped"
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="smml_pmc_", dir="/tmp")
