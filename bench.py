@@ -313,7 +313,7 @@ def main():
             if world == 1 and not a.no_traffic:
                 traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
                                                                 "--no-traffic", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
-            if traffic is None and (S, in_dim) == (100, 512):
+            if traffic is None and world == 1 and not a.no_traffic and (S, in_dim) == (100, 512):
                 traffic = measured_traffic(kname, B)
                 tsrc = f"replayed from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, committed); live collection: {tsrc}"
             out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS,
