@@ -167,6 +167,14 @@ void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset);
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p,
                                       unsigned long long dropout_seed, void* stream);
 
+/* decision export (parity tests only): the ReLU decisions [W1 p + b1 > 0] of the position bias's FIRST layer
+ * (DeformableAttention2D.py:129-131, 1D :69-71) bit for bit as the fused forward and the position-bias backward evaluate them,
+ * masks [(B G), J, 2, smml_deform_attn_nst(N)] uint16 in the bit order of relu_masks above.  Together with relu_masks (layer 2)
+ * and smml_bilinear_corners_f32 (the sampler's cells) this is every piecewise-linear decision of the module; tests impose
+ * them on the fp64 oracle so that gradient comparisons do not depend on rounding-level ties. */
+int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* w1, const float* b1, unsigned short* masks,
+                                 int B, int N, int J, int G, int posdim, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Nystrom landmark self-attention, HBM-bound pieces (the contractions of models/NystromAttention.py:86,
  * 122-140 and the pinv iteration :20-35 run through smml_gemm_f32 with alpha / beta epilogues).

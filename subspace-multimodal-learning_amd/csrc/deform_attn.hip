@@ -258,6 +258,32 @@ struct CpbParams {
   const float* b3;  // [o]
 };
 
+// Layer 1 of the position-bias MLP on the matrix pipe, query-major (lane = query, accumulator rows = hidden channels):
+// x[ch][q] = w1x[ch] p0[q] + w1y[ch] p1[q] + b1[ch] as ONE bf16 MFMA with weights and positions in three bf16 terms each.
+// The forward, the position-bias backward and the decision export (relu1_masks_kernel) all go through these two functions,
+// so the layer-1 ReLU decisions of the three are the same bits.
+__device__ __forceinline__ bf16x8 cpb_l1_weights_q(float wx, float wy, int hf) {
+  const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
+  const __bf16 xl = (__bf16)(xr - (float)xm);
+  const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
+  const __bf16 yl = (__bf16)(yr - (float)ym);
+  return hf == 0 ? (bf16x8){xh, yh, xh, yh, xh, yh, xl, yl} : (bf16x8){xm, ym, xm, ym, xm, ym, xl, yl};
+}
+struct PosTerms { unsigned hw, mw, lw; };       // {p0, p1} as three packed bf16 pairs (h + m + l = the fp32 values to 2^-24)
+__device__ __forceinline__ PosTerms cpb_split_pos(float p0, float p1) {
+  const float2v pv = {p0, p1};
+  const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
+  const float2v r1 = bf16_residual2(pv, hh);
+  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+  const float2v r2 = bf16_residual2(r1, mm);
+  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+  return PosTerms{__builtin_bit_cast(unsigned, hh), __builtin_bit_cast(unsigned, mm), __builtin_bit_cast(unsigned, ll)};
+}
+__device__ __forceinline__ floatx16 cpb_layer1_q(bf16x8 a1, const PosTerms& t, int hf, floatx16 b1acc) {
+  const uint4v bw = {t.hw, t.mw, t.lw, hf ? t.mw : t.hw};
+  return mfma16b(a1, __builtin_bit_cast(bf16x8, bw), b1acc);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -333,13 +359,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   bf16x8 a1;
   floatx16 b1acc;
   {
-    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f;
-    const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
-    const __bf16 xl = (__bf16)(xr - (float)xm);
-    const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
-    const __bf16 yl = (__bf16)(yr - (float)ym);
-    if (hf == 0) a1 = (bf16x8){xh, yh, xh, yh, xh, yh, xl, yl};
-    else a1 = (bf16x8){xm, ym, xm, ym, xm, ym, xl, yl};
+    a1 = cpb_l1_weights_q(cp.w1[c * PD], (PD == 2) ? cp.w1[c * PD + 1] : 0.f, hf);
 #pragma unroll
     for (int s = 0; s < 16; ++s) b1acc[s] = cp.b1[acc_row(s, hf)];
   }
@@ -435,18 +455,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
       // layer 1 on the matrix pipe, ReLU, fp16 hi / lo split, five MFMAs per K-block
-      floatx16 xacc;
-      {
-        const float2v pv = {p0, p1};
-        const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
-        const float2v r1 = bf16_residual2(pv, hh);
-        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-        const float2v r2 = bf16_residual2(r1, mm);
-        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-        const unsigned hw = __builtin_bit_cast(unsigned, hh), mw = __builtin_bit_cast(unsigned, mm);
-        const uint4v bw = {hw, mw, __builtin_bit_cast(unsigned, ll), hf ? mw : hw};
-        xacc = mfma16b(a1, __builtin_bit_cast(bf16x8, bw), b1acc);
-      }
+      const floatx16 xacc = cpb_layer1_q(a1, cpb_split_pos(p0, p1), hf, b1acc);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float hv[8];
@@ -978,8 +987,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
     const __bf16 bl_ = (__bf16)(br - (float)bm);
     const __bf16 z = (__bf16)0.f;
-    if (hf == 0) { a1q = (bf16x8){xh, yh, xh, yh, xh, yh, xl, yl}; a1t = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, bm}; }
-    else { a1q = (bf16x8){xm, ym, xm, ym, xm, ym, xl, yl}; a1t = (bf16x8){xm, ym, xm, ym, xl, yl, bl_, z}; }
+    a1q = cpb_l1_weights_q(wx, wy, hf);
+    if (hf == 0) a1t = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, bm};
+    else a1t = (bf16x8){xm, ym, xm, ym, xl, yl, bl_, z};
 #pragma unroll
     for (int s16 = 0; s16 < 16; ++s16) b1acc[s16] = cp.b1[acc_row(s16, hf)];
   }
@@ -1070,15 +1080,9 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     // ---- layer 1 on the matrix pipe, in both layouts ----
     floatx16 xacc, ht;
     {
-      const float2v pv = {p0, p1};
-      const bf16x2 hh = __builtin_convertvector(pv, bf16x2);
-      const float2v r1 = bf16_residual2(pv, hh);
-      const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-      const float2v r2 = bf16_residual2(r1, mm);
-      const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-      const unsigned hw = __builtin_bit_cast(unsigned, hh), mw = __builtin_bit_cast(unsigned, mm), lw = __builtin_bit_cast(unsigned, ll);
-      const uint4v qw = {hw, mw, lw, hf ? mw : hw};
-      xacc = mfma16b(a1q, __builtin_bit_cast(bf16x8, qw), b1acc);
+      const PosTerms pt = cpb_split_pos(p0, p1);
+      const unsigned hw = pt.hw, mw = pt.mw, lw = pt.lw;
+      xacc = cpb_layer1_q(a1q, pt, hf, b1acc);
       const uint4v tw = {hw, mw, hf ? hw : lw, hf ? 0x00003F80u : 0x3F803F80u};
       ht = mfma16b(__builtin_bit_cast(bf16x8, tw), a1t, (floatx16){0});
     }
@@ -1358,6 +1362,37 @@ __global__ void cpb_final_kernel(const float* __restrict__ part_in, int nchunks,
   }
 }
 
+// Decision export (tests only): the layer-1 ReLU decisions [x1 > 0] of the position-bias MLP exactly as the forward and the
+// backward evaluate them, in the bit layout of the saved layer-2 masks (hidden channel acc_row(r, half) at bit (13 + r) % 16):
+// masks [B * G, J, 2, NST] uint16.  Parity tests impose these decisions (and the saved layer-2 bits) on the fp64 oracle, so that
+// a gradient comparison no longer depends on which way a rounding-level tie of a pre-activation fell.
+template <int PD>
+__global__ __launch_bounds__(256) void relu1_masks_kernel(const float* __restrict__ VS, const float* __restrict__ GQ,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          unsigned short* __restrict__ MK, int N, int J, int G, int NST) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, g = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int qi = min(q0 + c, N - 1);
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+  const bf16x8 a1 = cpb_l1_weights_q(w1[c * PD], (PD == 2) ? w1[c * PD + 1] : 0.f, hf);
+  floatx16 b1acc;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) b1acc[s] = b1[acc_row(s, hf)];
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  unsigned short* MKb = MK + ((size_t)(b * G + g) * J * 2 + hf) * NST;
+  for (int j = 0; j < J; ++j) {
+    const float p0 = slog1p(gq0 - VSb[(size_t)j * PD]);
+    const float p1 = (PD == 2) ? slog1p(gq1 - VSb[(size_t)j * PD + 1]) : 0.f;
+    const floatx16 xacc = cpb_layer1_q(a1, cpb_split_pos(p0, p1), hf, b1acc);
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (xacc[r] > 0.f) ? (1u << ((13 + r) & 15)) : 0u;
+    MKb[(size_t)j * 2 * NST + q0 + c] = (unsigned short)m;      // rows are padded to whole workgroup tiles
+  }
+}
+
 // query slices of backward pass 2: enough workgroups to fill the chip a few times over, at most 16 slabs
 static int dkv_parts(int B, int N, int J, int H) {
   const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
@@ -1428,6 +1463,20 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
   hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total,
                      make_drop(dropout_p, dropout_seed));
   SMML_LAUNCH_CHECK("smml_deform_attn_dropout_mask_f32");
+  return SMML_OK;
+}
+
+int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* w1, const float* b1, unsigned short* masks, int B,
+                                 int N, int J, int G, int posdim, void* stream) {
+  SMML_REQUIRE(vs && gq && w1 && b1 && masks && B > 0 && N > 0 && J > 0 && G > 0 && (posdim == 1 || posdim == 2) && B <= 65535 &&
+                   G <= 65535, "smml_deform_attn_relu1_masks: bad argument");
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), G, B), block(256);
+  const int nst = smml_deform_attn_nst(N);
+  if (posdim == 2)
+    hipLaunchKernelGGL(relu1_masks_kernel<2>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
+  else
+    hipLaunchKernelGGL(relu1_masks_kernel<1>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
+  SMML_LAUNCH_CHECK("smml_deform_attn_relu1_masks");
   return SMML_OK;
 }
 
