@@ -37,13 +37,32 @@ def signed_log(d: torch.Tensor) -> torch.Tensor:
 GRAD_PROBE = None
 
 
-def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.") -> torch.Tensor:
+# Imposed decisions (parity tests).  The module is piecewise linear in three places - the two ReLU layers of the position-bias
+# MLP and the cell a bilinear sample falls into - and wherever a pre-activation / pixel coordinate lies within fp32 rounding of the
+# kink, two fp32 evaluations (the reference's and the kernels') may legitimately decide differently; the GRADIENT then jumps by a
+# finite amount.  To compare gradients without exempting such inputs, a test may queue one decision object per attention call
+# (consumed in call order by deform_cross_attention_2d / _1d): the oracle then evaluates relu(x) as x * mask with the masks the
+# kernels used and takes the sampler's cell from the kernels' floor() - values change by at most the rounding-level
+# pre-activation, gradients follow the imposed branch.  Interface (tests/helpers.py Decisions): .cells -> (x0, y0) int64
+# [(B g), J] or None; .relu_masks(i0, i1) -> (m1, m2) bool [(B g), i1 - i0, J, 32].
+DECISIONS = None
+
+
+def _next_decisions():
+    if DECISIONS:
+        return DECISIONS.pop(0)
+    return None
+
+
+def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.", masks=None) -> torch.Tensor:
     """The position-bias MLP  in -> 32 -> 32 -> heads//groups  (depth = 2).
 
     DeformableAttention2D.py:129-152 / DeformableAttention1D.py:69-98.
-    ``pos`` is [..., in] and already signed-log transformed."""
-    h = torch.relu(pos @ p[prefix + "mlp.0.0.weight"].t() + p[prefix + "mlp.0.0.bias"])
-    h = torch.relu(h @ p[prefix + "mlp.1.0.weight"].t() + p[prefix + "mlp.1.0.bias"])
+    ``pos`` is [..., in] and already signed-log transformed.  ``masks`` = (m1, m2): imposed ReLU decisions (see DECISIONS)."""
+    x1 = pos @ p[prefix + "mlp.0.0.weight"].t() + p[prefix + "mlp.0.0.bias"]
+    h = torch.relu(x1) if masks is None else x1 * masks[0].to(x1.dtype)
+    x2 = h @ p[prefix + "mlp.1.0.weight"].t() + p[prefix + "mlp.1.0.bias"]
+    h = torch.relu(x2) if masks is None else x2 * masks[1].to(x2.dtype)
     out = h @ p[prefix + "mlp.2.weight"].t() + p[prefix + "mlp.2.bias"]
     if GRAD_PROBE is not None and out.requires_grad:
         key = id(p[prefix + "mlp.2.bias"])
@@ -73,7 +92,7 @@ def grouped_pointwise(x: torch.Tensor, w: torch.Tensor, groups: int) -> torch.Te
     return torch.einsum("bngc,goc->bngo", xg, wg).reshape(B, n, cout)
 
 
-def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int):
+def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int, cells=None):
     """Integer path of F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False)
     as called at DeformableAttention2D.py:268-271: pixel coordinates, the four corner indices,
     their in-bounds masks and bilinear weights.
@@ -93,6 +112,11 @@ def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int):
                 d = min(d, float((iy - torch.round(iy)).abs().min()))
             GRAD_PROBE["boundary"] = min(GRAD_PROBE.get("boundary", 1.0), d)
     x0f, y0f = torch.floor(ix), torch.floor(iy)
+    if cells is not None:            # imposed cells (see DECISIONS): the bilinear formula of that cell, extended past its edge by <= rounding
+        x0f, y0f = cells[0].to(ix.dtype), cells[1].to(iy.dtype)
+        with torch.no_grad():
+            for c, f in ((ix, x0f), (iy, y0f)):
+                assert float((c - f).min()) > -1e-3 and float((c - f).max()) < 1 + 1e-3, "imposed cell is not the sample's (or its neighbour within rounding)"
     x0, y0 = x0f.to(torch.int64), y0f.to(torch.int64)
     x1, y1 = x0 + 1, y0 + 1
     wx1, wy1 = ix - x0f, iy - y0f
@@ -108,10 +132,10 @@ def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int):
     return ix, iy, corners
 
 
-def bilinear_gather(feats: torch.Tensor, vx: torch.Tensor, vy: torch.Tensor) -> torch.Tensor:
+def bilinear_gather(feats: torch.Tensor, vx: torch.Tensor, vy: torch.Tensor, cells=None) -> torch.Tensor:
     """feats [Bg, H, W, c] token-major, vx/vy [Bg, J] normalised sample positions -> [Bg, J, c]."""
     Bg, H, W, c = feats.shape
-    _, _, corners = sample_positions(vx, vy, W, H)
+    _, _, corners = sample_positions(vx, vy, W, H, cells)
     flat = feats.reshape(Bg, H * W, c)
     out = torch.zeros(Bg, vx.shape[1], c, dtype=feats.dtype, device=feats.device)
     for (cx, cy, wgt, m) in corners:
@@ -207,7 +231,8 @@ def deform_cross_attention_2d(
 
     # bilinear sampling of the grouped path stream at the *full* map size (:268-274)
     feats = x2t.reshape(B, Hh, Ww, G, cg).permute(0, 3, 1, 2, 4).reshape(B * G, Hh, Ww, cg)
-    kv = bilinear_gather(feats, vsx, vsy)                                   # [(B g), J, cg]
+    dec = _next_decisions()
+    kv = bilinear_gather(feats, vsx, vsy, dec.cells if dec is not None else None)   # [(B g), J, cg]
     kv = kv.reshape(B, G, J, cg).permute(0, 2, 1, 3).reshape(B, J, C)       # b j (g c)
 
     k = grouped_pointwise(kv, p["to_k.weight"], G if group_key_values else 1)   # :279
@@ -225,7 +250,7 @@ def deform_cross_attention_2d(
 
     def bias_fn(i0, i1):
         pos = gq[i0:i1].view(1, i1 - i0, 1, 2) - vs.view(B * G, 1, J, 2)
-        b = cpb_mlp(signed_log(pos), p)                                     # [(B g), i, J, o]
+        b = cpb_mlp(signed_log(pos), p, masks=dec.relu_masks(i0, i1) if dec is not None else None)   # [(B g), i, J, o]
         return b.reshape(B, G, i1 - i0, J, o).permute(0, 1, 4, 2, 3).reshape(B, heads, i1 - i0, J)
 
     attn_out = _attend(q, k, v, bias_fn, heads, scale, q_chunk, attn_keep, 1.0 / (1.0 - dropout_p))   # [B, N, inner]
@@ -290,7 +315,8 @@ def deform_cross_attention_1d(
     feats = x2t.reshape(B, n, G, cg).permute(0, 2, 1, 3).reshape(B * G, n, 1, cg)   # H = n, W = 1
     if true_1d_sampling:          # corrected semantics (NOT the reference): H = 1, W = n - vs runs along the tokens
         feats = feats.reshape(B * G, 1, n, cg)
-    kv = bilinear_gather(feats, vs, torch.zeros_like(vs))                           # [(B g), t, cg]
+    dec = _next_decisions()
+    kv = bilinear_gather(feats, vs, torch.zeros_like(vs), dec.cells if dec is not None else None)   # [(B g), t, cg]
     kv = kv.reshape(B, G, t, cg).permute(0, 2, 1, 3).reshape(B, t, C)
 
     k = grouped_pointwise(kv, p["to_k.weight"], G if group_key_values else 1)
@@ -303,7 +329,7 @@ def deform_cross_attention_1d(
         pos = seq[i0:i1].view(1, i1 - i0, 1, 1) - vs.view(B * G, 1, t, 1)
         if cpb_log_distance:
             pos = signed_log(pos)
-        b = cpb_mlp(pos, p)                                                         # [(B g), i, t, o]
+        b = cpb_mlp(pos, p, masks=dec.relu_masks(i0, i1) if dec is not None else None)   # [(B g), i, t, o]
         return b.reshape(B, G, i1 - i0, t, o).permute(0, 1, 4, 2, 3).reshape(B, heads, i1 - i0, t)
 
     attn_out = _attend(q, k, v, bias_fn, heads, scale, q_chunk)

@@ -55,6 +55,23 @@ class KernelTimer:
 
 TIMER = KernelTimer()
 
+# Decision tap (parity tests only; None in production).  When a test sets this to a list, every bilinear-sampling launch and every
+# fused-attention forward appends what is needed to recover the piecewise-linear decisions the kernels took - the sampler's
+# cells, the layer-1 and layer-2 ReLU masks of the position-bias MLP - so that tests can impose the SAME decisions on the fp64
+# oracle (tests/helpers.py Decisions).  Nothing here changes what the kernels compute.
+DECISION_TAP = None
+
+
+def relu1_masks(vs, gq, w1, b1, *, B: int, N: int, J: int, groups: int):
+    """Layer-1 ReLU decisions of the position-bias MLP as the kernels evaluate them: int16 [(B G), J, 2, nst] in the bit order of the
+    saved layer-2 masks (include/smml.h smml_deform_attn_relu1_masks).  Tests only."""
+    L = capi.lib()
+    nst = L.smml_deform_attn_nst(N)
+    out = torch.empty(B * groups, J, 2, nst, device=vs.device, dtype=torch.int16)
+    capi.check(L.smml_deform_attn_relu1_masks(capi.fptr(_c(vs)), capi.fptr(_c(gq)), capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.ptr(out),
+                                              B, N, J, groups, vs.shape[-1], capi.stream()), "relu1_masks")
+    return out
+
 
 class _ZeroPool:
     """Small zero-initialised fp32 tensors (weight / bias gradients that kernels accumulate into with atomics) carved out
@@ -356,6 +373,8 @@ class _Sample(torch.autograd.Function):
                                                            Cc // groups, J, posdim, capi.stream()), "sample_fwd")
         ctx.cfg = (groups, posdim)
         ctx.save_for_backward(x, vs)
+        if DECISION_TAP is not None:
+            DECISION_TAP.append({"kind": "sample", "vs": vs.detach(), "Hh": Hh, "Ww": Ww, "posdim": posdim})
         return kv
 
     @staticmethod
@@ -423,6 +442,9 @@ class _DeformAttn(torch.autograd.Function):
         ctx.seed_offset = seed_offset           # a device int64 [1] owned by this call (hipGraph replays: deform_attention)
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed))
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
+        if DECISION_TAP is not None:
+            DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(), "masks2": masks,
+                                 "B": B, "N": N, "J": J, "heads": heads, "groups": groups})
         return out
 
     @staticmethod

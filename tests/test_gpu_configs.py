@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import helpers
-from helpers import assert_calibrated, assert_close, params_for, rel_err, smml, synth
+import oracle.deform as odeform
+from helpers import assert_calibrated, assert_close, decision_tap, params_for, rel_err, smml, synth
 from oracle.losses import batch_loss, orthogonal_loss
 from oracle.mil import deform_pathomic_net
 from oracle.nystrom import nystrom_attention
@@ -107,18 +108,24 @@ def test_cfg4_full_fusion_10000x512(cuda, B, S):
         return (torch.nn.functional.cross_entropy(lg[2], label.to(lg[2].device)) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
                 + 0.1 * ol(vt, vi, vi, vt).sum()), l_t, l_i
 
+    # HIP first: the piecewise-linear decisions of its two attention calls (sampler cells, ReLU masks of the position bias) are
+    # imposed on both oracle runs, so every gradient is held to the plain rule - no boundary / flip exemption (helpers.py)
+    with decision_tap() as tap:
+        feats, vt, vi, lg, _, _, _ = net(x_path=x_path.to(cuda), x_omic=None, x_omic_tumor=x_t.to(cuda), x_omic_immune=x_i.to(cuda))
+    bl, ol = smml.BatchLoss(B, 1), smml.OrthogonalLoss()
+    loss, l_t, l_i = total(feats, vt, vi, lg, bl, ol)
+    loss.backward()
+    assert len(tap.decisions()) == 2                       # tumor branch, immune branch (model.py:494,497) - the oracle's order too
     run = {}
     with cpb_probe() as probe:
         for dt in (torch.float32, torch.float64):
             p = {k: (v.clone().to(dt).requires_grad_() if v.dtype.is_floating_point else v) for k, v in params.items()}
-            feats, vt, vi, lg = deform_pathomic_net(x_path.to(dt), x_t.to(dt), x_i.to(dt), p, grid_hw=(S, S), q_chunk=1024)
-            loss, l_t, l_i = total(feats, vt, vi, lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
-            loss.backward()
-            run[dt] = (feats.detach(), lg[2].detach(), lg[4].detach(), lg[6].detach(), l_t.detach(), l_i.detach(), loss.detach(), p)
-    feats, vt, vi, lg, _, _, _ = net(x_path=x_path.to(cuda), x_omic=None, x_omic_tumor=x_t.to(cuda), x_omic_immune=x_i.to(cuda))
-    bl, ol = smml.BatchLoss(B, 1), smml.OrthogonalLoss()
-    loss, l_t, l_i = total(feats, vt, vi, lg, bl, ol)
-    loss.backward()
+            odeform.DECISIONS = tap.decisions()
+            o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dt), x_t.to(dt), x_i.to(dt), p, grid_hw=(S, S), q_chunk=1024)
+            assert not odeform.DECISIONS
+            o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
+            o_loss.backward()
+            run[dt] = (o_feats.detach(), o_lg[2].detach(), o_lg[4].detach(), o_lg[6].detach(), o_lt.detach(), o_li.detach(), o_loss.detach(), p)
     r32, r64 = run[torch.float32], run[torch.float64]
     for name, got, i in (("features", feats, 0), ("haz", lg[2], 1), ("vgrid_t", lg[4], 2), ("vgrid_i", lg[6], 3),
                          ("batchloss_t", l_t, 4), ("batchloss_i", l_i, 5), ("loss", loss, 6)):

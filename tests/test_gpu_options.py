@@ -6,7 +6,8 @@ import argparse
 import pytest
 import torch
 
-from helpers import assert_calibrated, assert_close, params_for, smml, synth
+import oracle.deform as odeform
+from helpers import assert_calibrated, assert_close, decision_tap, params_for, smml, synth
 from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d, sample_positions
 from oracle.nystrom import nystrom_attention
 from test_gpu_parity import _compare_param_grads, _load, cpb_probe
@@ -24,17 +25,19 @@ def test_consistent_grid_norm_2d(cuda):
     mod = _load(mod, params, cuda)
     x1 = synth.normal((B, C, N), 31, tag + ":x1"); x2 = synth.normal((B, C, N), 31, tag + ":x2")
     wo = synth.normal((B, C, N), 31, tag + ":wo")
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o, vg = mod(ad, bd, return_vgrid=True)
+    (o * wo.to(cuda)).sum().backward()
     run = {}
     with cpb_probe() as probe:
         for dt in (torch.float32, torch.float64):
             pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
             a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
-            o, vg = deform_cross_attention_2d(a, b, pr, grid_hw=(Hh, Ww), consistent_grid_norm=True)
-            (o * wo.to(dt)).sum().backward()
-            run[dt] = (o, vg, a.grad, b.grad, pr)
-    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
-    o, vg = mod(ad, bd, return_vgrid=True)
-    (o * wo.to(cuda)).sum().backward()
+            odeform.DECISIONS = tap.decisions()
+            o_r, vg_r = deform_cross_attention_2d(a, b, pr, grid_hw=(Hh, Ww), consistent_grid_norm=True)
+            (o_r * wo.to(dt)).sum().backward()
+            run[dt] = (o_r, vg_r, a.grad, b.grad, pr)
     r32, r64 = run[torch.float32], run[torch.float64]
     for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
         assert_calibrated("cgn " + name, got, r32[i], r64[i])
@@ -57,17 +60,19 @@ def test_true_1d_sampling(cuda):
     mod = _load(mod, params, cuda)
     x1 = synth.normal((B, C, n), 33, tag + ":x1"); x2 = synth.normal((B, C, n), 33, tag + ":x2")
     wo = synth.normal((B, C, n), 33, tag + ":wo")
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o, vg = mod(ad, bd, return_vgrid=True)
+    (o * wo.to(cuda)).sum().backward()
     run = {}
     with cpb_probe() as probe:
         for dt in (torch.float32, torch.float64):
             pr = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
             a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
-            o, vg = deform_cross_attention_1d(a, b, pr, offset_scale=2.0, true_1d_sampling=True)
-            (o * wo.to(dt)).sum().backward()
-            run[dt] = (o, vg, a.grad, b.grad, pr)
-    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
-    o, vg = mod(ad, bd, return_vgrid=True)
-    (o * wo.to(cuda)).sum().backward()
+            odeform.DECISIONS = tap.decisions()
+            o_r, vg_r = deform_cross_attention_1d(a, b, pr, offset_scale=2.0, true_1d_sampling=True)
+            (o_r * wo.to(dt)).sum().backward()
+            run[dt] = (o_r, vg_r, a.grad, b.grad, pr)
     r32, r64 = run[torch.float32], run[torch.float64]
     for name, got, i in (("out", o, 0), ("vgrid", vg, 1), ("dx1", ad.grad, 2), ("dx2", bd.grad, 3)):
         assert_calibrated("t1d " + name, got, r32[i], r64[i])

@@ -275,3 +275,62 @@ def test_gradient_modulation_block():
         assert [bool(x) for x in info["branch"]] == list(z[f"case{seed}/changed_rows"])
         seen.update(info["branch"])
     assert seen == {0, 1, 2}
+
+
+def test_imposed_decisions_reproduce_the_plain_oracle():
+    """oracle.deform.DECISIONS (the hook the GPU parity tests use to impose the kernels' ReLU masks and sampler cells): with the
+    oracle's OWN decisions imposed, values and gradients must equal the plain run bit for bit - 2-D and 1-D module."""
+    import oracle.deform as od
+
+    class Own:
+        """decisions computed from the oracle's own fp32 evaluation (same interface as tests/helpers.py Decisions)"""
+        def __init__(self, vs, gq, p, W, H):
+            vx, vy = (vs[..., 0], vs[..., 1]) if vs.shape[-1] == 2 else (vs[..., 0], torch.zeros_like(vs[..., 0]))
+            ix, iy, _ = sample_positions(vx, vy, W, H)
+            self.cells = (torch.floor(ix).long(), torch.floor(iy).long())
+            pos = od.signed_log(gq[None, :, None, :] - vs[:, None, :, :])
+            x1 = pos @ p["rel_pos_bias.mlp.0.0.weight"].t() + p["rel_pos_bias.mlp.0.0.bias"]
+            x2 = torch.relu(x1) @ p["rel_pos_bias.mlp.1.0.weight"].t() + p["rel_pos_bias.mlp.1.0.bias"]
+            self.m1, self.m2 = x1 > 0, x2 > 0
+
+        def relu_masks(self, i0, i1):
+            return self.m1[:, i0:i1], self.m2[:, i0:i1]
+
+    for dim in (2, 1):
+        B, C = 2, 128
+        if dim == 2:
+            Hh, Ww = 12, 16
+            N = Hh * Ww
+            mod = smml.DeformCrossAttention2D(dim=C, grid_hw=(Hh, Ww))
+            fn = lambda a, b, p: deform_cross_attention_2d(a, b, p, grid_hw=(Hh, Ww), q_chunk=50, return_aux=True)
+        else:
+            N = 61
+            mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+            fn = lambda a, b, p: deform_cross_attention_1d(a, b, p, offset_scale=2.0, q_chunk=50, return_aux=True)
+        params = params_for(mod, 5, f"imposed{dim}")
+        x1 = synth.normal((B, C, N), 5, f"imposed{dim}:x1"); x2 = synth.normal((B, C, N), 5, f"imposed{dim}:x2")
+        wo = synth.normal((B, C, N), 5, f"imposed{dim}:wo")
+        res = []
+        dec = None
+        for imposed in (False, True):
+            p = {k: v.clone().requires_grad_() for k, v in params.items()}
+            a, b = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+            od.DECISIONS = [dec] if imposed else None
+            out, vg, aux = fn(a, b, p)
+            assert not od.DECISIONS
+            (out * wo).sum().backward()
+            res.append([out.detach(), vg.detach(), a.grad, b.grad] + [p[k].grad for k in sorted(p) if p[k].grad is not None])
+            if not imposed:
+                with torch.no_grad():
+                    if dim == 2:
+                        vs = torch.stack((aux["vsx"], aux["vsy"]), dim=-1)
+                        qx = 2.0 * torch.arange(Ww, dtype=torch.float32) / max(Hh - 1, 1) - 1.0
+                        qy = 2.0 * torch.arange(Hh, dtype=torch.float32) / max(Ww - 1, 1) - 1.0
+                        gq = torch.stack((qx.view(1, Ww).expand(Hh, Ww), qy.view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(N, 2)
+                        dec = Own(vs, gq, params, Ww, Hh)
+                    else:
+                        gq = (2.0 * torch.arange(N, dtype=torch.float32) / max(N - 1, 1) - 1.0).view(N, 1)
+                        dec = Own(aux["vs"].unsqueeze(-1), gq, params, 1, N)
+        assert len(res[0]) == len(res[1]) > 10
+        for i, (u, v) in enumerate(zip(*res)):
+            assert torch.equal(u, v), f"{dim}-D module, tensor {i}: imposing the oracle's own decisions changed the result"
