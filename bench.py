@@ -65,6 +65,7 @@ def live_traffic(kernel_substr, argv_tail, timeout=150):
     tooled = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER")) or k == "HSA_TOOLS_LIB"]
     if tooled or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process runs under a profiler (" + ", ".join(tooled[:3] or ["LD_PRELOAD"]) + "): PMC child runs skipped"
+    import signal
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="smml_pmc_", dir="/tmp")
@@ -72,9 +73,22 @@ def live_traffic(kernel_substr, argv_tail, timeout=150):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), *argv_tail]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            # own session = own process group: on a timeout the WHOLE group (the rocprofv3 wrapper and the profiled python it
+            # started) is killed and reaped before this process times anything else on the GPU
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = child.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+                return None, f"CHILD_TIMEOUT: rocprofv3 --pmc {counter} pass exceeded {timeout} s and its process group was killed"
+            if rc < 0:
+                return None, f"CHILD_SIGNAL: rocprofv3 --pmc {counter} pass died by signal {-rc}"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
             acc = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -289,6 +303,18 @@ def main():
     dt = float(tmax.item())
 
     kt = Fh.TIMER.collect()
+    dp_info = None
+    if world > 1:
+        # self-check of a multi-GPU run: the world size the collective backend reports, every rank's device, and the data-parallel
+        # wrapper's counters of the LAST step (buckets launched while backward was still running, buckets skipped as grad-less,
+        # host time spent inside the gradient hooks)
+        st = dict(getattr(model, "stats", {}))
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "device_index": local, "buckets": st.get("buckets"),
+                "launched_in_backward": st.get("launched_in_backward"), "skipped": st.get("skipped"),
+                "hook_host_ms_per_step": st.get("hook_host_ms")}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dp_info = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ranks": gathered}
     if rank == 0:
         out = {
             "metric": "bags/sec fwd+bwd, DeformCrossTransMIL N=10k x 512",
@@ -310,9 +336,16 @@ def main():
             # results), so the algorithmic flops are priced against THAT pipe's dense peak; what actually bounds the kernel is
             # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~265 vector instructions per 12 MFMAs.
             traffic, tsrc = None, "not collected (--no-traffic, or N > 1)"
+            if world == 1 and not a.no_nystrom:
+                # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
+                # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
+                out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
+                                  nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
             if world == 1 and not a.no_traffic:
                 traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
                                                                 "--no-traffic", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
+            if tsrc.startswith(("CHILD_TIMEOUT", "CHILD_SIGNAL")):
+                out["pmc_child_failed"] = tsrc           # a hung / crashed profiler child is surfaced, not folded into a fallback
             if traffic is None and world == 1 and not a.no_traffic and (S, in_dim) == (100, 512):
                 traffic = measured_traffic(kname, B)
                 tsrc = f"replayed from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, committed); live collection: {tsrc}"
@@ -335,10 +368,11 @@ def main():
                                    "launches": n, "avg_ms": ms, "flop_per_launch": flop,
                                    "note": f"2496 algorithmic flop per pair (position-bias MLP 2240 + QK^T / PV 256) against the dense 16-bit "
                                            f"MFMA peak; {CPB_FWD_MFMAS} + 24/32 16-bit MFMAs + ~170 vector instructions per (key, 32 queries)"}
-        if world == 1 and not a.no_nystrom:
-            # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`)
+        if world == 1 and not a.no_nystrom and "nystrom" not in out:
             out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
                               nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
+        if world > 1:
+            out["data_parallel"] = dp_info               # what the collective backend saw + per-rank overlap counters: a SCALE run checks itself
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, in_dim, S)
         print(json.dumps(out))

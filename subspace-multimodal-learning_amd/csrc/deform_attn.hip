@@ -190,9 +190,18 @@ struct DropCfg {
   const unsigned long long* seed_dev;   // optional device-resident offset added to `seed` when the kernel runs (a launch captured in
                                         // a hipGraph bakes `seed` in; the offset lets every replay draw a new mask), or nullptr
 };
-// the seed a launch uses: one uniform load per wave
+// 64-bit finaliser (splitmix64, Steele / Lea / Flood): every input bit reaches every output bit
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// the seed a launch uses: one uniform load and two finalisers per wave.  The replay offset must NOT simply be added to the seed:
+// drop_hash mixes idx + seed, so an offset that grows by k per replay would make the mask of replay r the mask of replay 0
+// shifted by k r elements along the key axis.  The offset is hashed into a fresh 64-bit key instead.
 __device__ __forceinline__ DropCfg drop_resolve(DropCfg dc) {
-  if (dc.thresh && dc.seed_dev) dc.seed += *dc.seed_dev;
+  if (dc.thresh && dc.seed_dev) dc.seed = mix64(dc.seed ^ mix64(*dc.seed_dev));
   dc.seed_dev = nullptr;
   return dc;
 }

@@ -104,6 +104,7 @@ int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float
   SMML_REQUIRE(B > 0 && B <= 1024 && C > 0 && C <= GM_MAX_C && hs > 0, "smml_grad_modulate_f32: need 0 < B <= 1024, 0 < C <= %d, hs > 0",
                GM_MAX_C);
   const size_t lds = ((size_t)2 * B * C + 2 * B + 2) * sizeof(float);
+  SMML_REQUIRE(lds <= 64 * 1024, "smml_grad_modulate_f32: B x C = %d x %d needs %zu bytes of LDS (limit 64 KiB: B (C + 1) <= 8191)", B, C, lds);
   hipLaunchKernelGGL(grad_modulate_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, feat_t, feat_i, weight, bias, label,
                      weight_grad, info, B, C, hs);
   SMML_LAUNCH_CHECK("smml_grad_modulate_f32");

@@ -20,6 +20,7 @@ latency-bound: the default bucket is 512 KiB - 4 to 9 buckets, enough for the fi
 position-bias backward (the longest kernel of the step) of the other branch still runs."""
 from __future__ import annotations
 
+import time
 from typing import List
 
 import torch
@@ -40,6 +41,7 @@ class _Bucket:
         self.views = None
         self.used = None                      # per parameter: receives a gradient (known after the first step)
         self.pending = 0
+        self.complete = False
         self.ready = [False] * len(params)
         self.work = None
         self.skip = False
@@ -72,7 +74,9 @@ class BagDataParallel(nn.Module):
         self._armed = False
         self._known = False                   # the grad-less set has been recorded
         self._avg_op = None
-        self.stats = {"buckets": len(self._buckets), "launched_in_backward": 0, "skipped": 0, "steps": 0}
+        self.stats = {"buckets": len(self._buckets), "launched_in_backward": 0, "skipped": 0, "steps": 0, "hook_host_ms": 0.0,
+                      "used_mismatch": 0}
+        self._hook_s = 0.0                    # host time spent inside the gradient hooks of the current backward
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -91,14 +95,24 @@ class BagDataParallel(nn.Module):
     def _arm(self):
         if not self._armed:
             self._armed = True
+            self._hook_s = 0.0
+            self._next = 0
             self.stats["launched_in_backward"] = 0
             for b in self._buckets:
                 b.ready = [False] * len(b.params)
                 b.work = None
+                b.complete = False
                 b.pending = len(b.params) if b.used is None else sum(b.used)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _on_grad(self, p: nn.Parameter):
+        t0 = time.perf_counter()
+        try:
+            self._on_grad_timed(p)
+        finally:
+            self._hook_s += time.perf_counter() - t0
+
+    def _on_grad_timed(self, p: nn.Parameter):
         self._arm()
         bi, pi = self._where[p]
         b = self._buckets[bi]
@@ -109,8 +123,20 @@ class BagDataParallel(nn.Module):
             b.ready[pi] = True
             b.pending -= 1
             if b.pending == 0:
-                self._launch(b)
-                self.stats["launched_in_backward"] += 1
+                b.complete = True
+                # collectives must be issued in the SAME order on every rank: buckets are launched strictly in index order
+                # (= the order their gradients become ready in the normal case); a complete bucket behind an incomplete one
+                # waits for it - at the latest until the end-of-backward flush, which also walks the buckets in index order
+                while self._next < len(self._buckets):
+                    nb = self._buckets[self._next]
+                    if nb.skip:
+                        self._next += 1
+                    elif nb.complete and nb.work is None:
+                        self._launch(nb)
+                        self.stats["launched_in_backward"] += 1
+                        self._next += 1
+                    else:
+                        break
 
     def _reduce_op(self, t: torch.Tensor):
         """(op, pre-scale): ReduceOp.AVG where the backend has it (RCCL), else SUM of pre-scaled values."""
@@ -130,10 +156,12 @@ class BagDataParallel(nn.Module):
         todo = [(v, g) for v, g in live if g.data_ptr() != v.data_ptr()]
         # slots without a gradient this step contribute zeros.  Slots of the static grad-less set were zeroed when the bucket
         # was created and are never written; any other missing slot (first step, or a used parameter that got nothing this
-        # time) still holds the previous step's average and is cleared here
-        for v, p, r, u in zip(b.views, b.params, b.ready, b.used if b.used is not None else [True] * len(b.params)):
-            if u and not (r and p.grad is not None):
-                v.zero_()
+        # time) still holds the previous step's average and is cleared here.  Steady state (set known, every used slot ready):
+        # nothing to clear, no per-slot work on the backward thread
+        if b.used is None or len(live) != sum(b.used):
+            for v, p, r, u in zip(b.views, b.params, b.ready, b.used if b.used is not None else [True] * len(b.params)):
+                if u and not (r and p.grad is not None):
+                    v.zero_()
         if todo:
             torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
         op, scale = self._reduce_op(b.flat)
@@ -154,10 +182,29 @@ class BagDataParallel(nn.Module):
                 if r and p.grad is not None:
                     p.grad = v
         if not self._known:
+            used = [bool(r and p.grad is not None) for b in self._buckets for p, r in zip(b.params, b.ready)]
+            if self.world > 1:
+                # the grad-less set decides how many all-reduces a step issues: it must be the same on every rank, or the job
+                # hangs in the collective with no diagnostic.  Ranks exchange their sets once (MAX = union, MIN =
+                # intersection); where they differ the union is taken - every rank then launches the same buckets, a rank
+                # whose parameter got no gradient contributes zeros - and the mismatch is counted for the caller to see
+                dev = self._buckets[0].params[0].device
+                m = torch.tensor([used, [not u for u in used]], dtype=torch.int32, device=dev)
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+                union, any_unused = m[0].bool().tolist(), m[1].bool().tolist()
+                self.stats["used_mismatch"] = sum(1 for u, n in zip(union, any_unused) if u and n)
+                used = union
+            i = 0
             for b in self._buckets:
-                b.used = [bool(r and p.grad is not None) for p, r in zip(b.params, b.ready)]
+                b.used = used[i:i + len(b.params)]
+                i += len(b.params)
                 b.skip = not any(b.used)
+                if b.views is not None:               # slots of the (now static) grad-less set stay zero from here on
+                    for v, u in zip(b.views, b.used):
+                        if not u:
+                            v.zero_()
             self._known = True
             self.stats["skipped"] = sum(1 for b in self._buckets if b.skip)
         self.stats["steps"] += 1
+        self.stats["hook_host_ms"] = 1e3 * self._hook_s
         self._armed = False

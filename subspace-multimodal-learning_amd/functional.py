@@ -516,11 +516,16 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
                              dropout_seed_offset)
 
 
-def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device):
-    """The keep mask (0 / 1) [B, H, N, J] a launch with this (p, seed) applies; tests only."""
+def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):
+    """The keep mask (0 / 1) [B, H, N, J] a launch with this (p, seed[, device-resident replay offset]) applies; tests only."""
     mask = torch.empty(B, H, N, J, device=device, dtype=torch.float32)
-    capi.check(capi.lib().smml_deform_attn_dropout_mask_f32(capi.fptr(mask), B, N, J, H, float(dropout_p), int(dropout_seed),
-                                                            capi.stream()), "dropout_mask")
+    L = capi.lib()
+    _set_seed_offset(L, seed_offset)
+    try:
+        capi.check(L.smml_deform_attn_dropout_mask_f32(capi.fptr(mask), B, N, J, H, float(dropout_p), int(dropout_seed),
+                                                       capi.stream()), "dropout_mask")
+    finally:
+        _set_seed_offset(L, None)
     return mask
 
 

@@ -79,7 +79,10 @@ class BilinearFusion(nn.Module):
             o2 = self.linear_o2[2](self._lin(self.linear_o2, vec2, Fh.ACT_RELU))
         one = torch.ones(o1.shape[0], 1, device=o1.device, dtype=o1.dtype)      # reference: torch.cuda.FloatTensor(...).fill_(1)
         o1, o2 = torch.cat((o1, one), 1), torch.cat((o2, one), 1)
-        o12 = torch.bmm(o1.unsqueeze(2), o2.unsqueeze(1)).flatten(start_dim=1)
+        # Kronecker product [B, d1 + 1] x [B, d2 + 1] -> [B, (d1 + 1)(d2 + 1)] (fusion.py:58): a batched K = 1 product through the
+        # package's own GEMM (forward and both gradients in smml_gemm_f32) - no library GEMM on the path
+        Bn = o1.shape[0]
+        o12 = Fh.matmul4(o1.reshape(1, Bn, -1, 1), o2.reshape(1, Bn, 1, -1)).reshape(Bn, -1)
         out = self.post_fusion_dropout(o12)
         out = self.encoder1[3](self.encoder1[2](self.encoder1[1](self._lin(self.encoder1, out))))
         if self.skip:

@@ -5,12 +5,12 @@
                                              loop, no host synchronisation.  Task types diag2021 / grade / subtype; the
                                              survival branch needs sksurv's C-index on the host (:121-134) and is not built.
   PinnedBagStager     train_test.py:53       `x_path.cuda()` of a pageable [B, 2500, 1024] fp32 batch (82 MB per step) replaced
-                                             by double-buffered pinned host buffers and asynchronous copies on a side stream:
-                                             batch k + 1 crosses PCIe while batch k computes.
+                                             by three pinned staging slots and asynchronous copies on a side stream: the host
+                                             copy and the PCIe transfer of batch k + 2 run while batch k computes.
 
 Semantics kept from the reference: the modulation is RANK-LOCAL - every rank derives ratio_t from its own samples and edits
 its own copy of the (already all-reduced) classifier gradient, so replicas may apply different edits.
-`gradient_modulate(..., group=...)` offers the corrected variant (scores summed over ranks first) as an explicit option."""
+`allreduce_scores_then_modulate(...)` offers the corrected variant (scores over the gathered batch) as an explicit option."""
 from __future__ import annotations
 
 from typing import Iterable, Iterator, Optional, Sequence
@@ -51,11 +51,16 @@ def gradient_modulate(classifier: torch.nn.Module, feat_t: torch.Tensor, feat_i:
 
 class PinnedBagStager:
     """Iterates over host batches (tuples of CPU tensors, the bag first) and yields them resident on `device`.
-    Two pinned staging buffers per tuple slot and a copy stream: while the consumer computes on batch k, batch k + 1 is copied
-    into pinned memory by the host and crosses PCIe asynchronously.  The yielded tensors stay valid until the consumer asks for
-    the batch after the next one (double buffering) and are ordered against the consumer's current stream with events - no
-    torch.cuda.synchronize() anywhere.  `bag_dtype` optionally narrows the bag (slot 0) on the host before the copy
+    THREE staging slots (pinned host buffers + device buffers per tuple position) and a copy stream.  When the consumer asks for
+    batch k + 1 (its kernels on batch k are enqueued and running), the host copies batch k + 2 into pinned memory and enqueues its
+    DMA - into the slot batch k - 1 used, so nothing here waits for batch k's kernels on the host: the pageable -> pinned copy
+    (82 MB for the reference batch) and the PCIe transfer both run beside batch k's compute.  Ordering is by events only: the
+    copy stream waits (on the device) for the consumer work enqueued so far before it overwrites a slot, the consumer's stream
+    waits for a slot's DMA before the slot is yielded; no torch.cuda.synchronize().
+    Validity: the tensors of batch k stay intact while the consumer works on batches k and k + 1; they are overwritten once
+    batch k + 2 has been requested.  `bag_dtype` optionally narrows the bag (slot 0) on the host before the copy
     (torch.bfloat16 halves the PCIe bytes; the path widens it again on the device)."""
+    SLOTS = 3
 
     def __init__(self, batches: Iterable[Sequence[torch.Tensor]], device, bag_dtype: Optional[torch.dtype] = None):
         self.device = torch.device(device)
@@ -64,14 +69,17 @@ class PinnedBagStager:
         self.batches = batches
         self.bag_dtype = bag_dtype
         self.copy_stream = torch.cuda.Stream(self.device)
-        self._pinned = [None, None]
-        self._dev = [None, None]
-        self._ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self._consumed = [None, None]
+        self._pinned = [None] * self.SLOTS
+        self._dev = [None] * self.SLOTS
+        self._ready = [None] * self.SLOTS              # recorded on the copy stream after a slot's DMA
+        self.host_wait_s = 0.0                         # time the host spent waiting for a slot's previous DMA (diagnostic; ~0)
 
     def _stage(self, slot: int, batch: Sequence[torch.Tensor]):
-        if self._consumed[slot] is not None:
-            self._consumed[slot].synchronize()          # the consumer's kernels that read this slot's device buffers have finished
+        import time
+        if self._ready[slot] is not None:              # the previous DMA out of this slot's pinned buffers (three batches ago): long done
+            t0 = time.perf_counter()
+            self._ready[slot].synchronize()
+            self.host_wait_s += time.perf_counter() - t0
         src = list(batch)
         if self.bag_dtype is not None:
             src[0] = src[0].to(self.bag_dtype)
@@ -79,36 +87,42 @@ class PinnedBagStager:
             self._pinned[slot] = [torch.empty(s.shape, dtype=s.dtype, pin_memory=True) for s in src]
             self._dev[slot] = [torch.empty(s.shape, dtype=s.dtype, device=self.device) for s in src]
         for p, s in zip(self._pinned[slot], src):
-            p.copy_(s)                                  # pageable -> pinned, on the host
+            p.copy_(s)                                  # pageable -> pinned, on the host, beside the consumer's running kernels
+        # device side: everything the consumer has enqueued so far (it may still read this slot's previous tenant) precedes the DMA
+        seen = torch.cuda.Event()
+        seen.record(torch.cuda.current_stream(self.device))
+        self.copy_stream.wait_event(seen)
         with torch.cuda.stream(self.copy_stream):
             for d, p in zip(self._dev[slot], self._pinned[slot]):
                 d.copy_(p, non_blocking=True)
-            self._ready[slot].record(self.copy_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._ready[slot] = ev
 
     def __iter__(self) -> Iterator[Sequence[torch.Tensor]]:
         it = iter(self.batches)
-        slot = 0
         try:
-            self._stage(slot, next(it))
+            self._stage(0, next(it))
         except StopIteration:
             return
+        k = 0                                           # batch index of the slot about to be yielded
+        staged = 1                                      # batches staged so far
+        exhausted = False
         while True:
-            cur = slot
-            nxt = None
-            try:
-                nxt = next(it)
-            except StopIteration:
-                pass
-            if nxt is not None:
-                self._stage(cur ^ 1, nxt)               # overlaps with the consumer's work on `cur`
+            # keep two batches ahead of the consumer: by the time batch k is yielded, k + 1 (and k + 2 once the pipeline is full)
+            # have been staged; each _stage call runs while the consumer's kernels on earlier batches are in flight
+            while not exhausted and staged < k + 2:
+                try:
+                    self._stage(staged % self.SLOTS, next(it))
+                    staged += 1
+                except StopIteration:
+                    exhausted = True
+            cur = k % self.SLOTS
             torch.cuda.current_stream(self.device).wait_event(self._ready[cur])
             yield tuple(self._dev[cur])
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._consumed[cur] = ev
-            if nxt is None:
+            k += 1
+            if k >= staged:
                 return
-            slot = cur ^ 1
 
 
 def allreduce_scores_then_modulate(classifier, feat_t, feat_i, label, group=None):

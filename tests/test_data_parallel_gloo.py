@@ -115,6 +115,64 @@ def test_world_size_2_gloo():
     assert torch.equal(res[0]["ga0"], res[1]["ga0"])
 
 
+class _Branchy(nn.Module):
+    """`extra` receives a gradient only where `use_extra` is set - ranks that disagree in the first step"""
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(1)
+        self.a = nn.Linear(6, 5)
+        self.extra = nn.Linear(5, 5)
+        self.b = nn.Linear(5, 2)
+        self.use_extra = False
+
+    def forward(self, x):
+        h = torch.tanh(self.a(x))
+        if self.use_extra:
+            h = h + self.extra(h)
+        return self.b(h)
+
+
+def _worker_mismatch(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _Branchy()
+    net.use_extra = (rank == 1)                # a data-dependent branch taken on one rank only
+    dp = smml.BagDataParallel(net, bucket_bytes=32)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(3 + rank))
+    grads = []
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        dp(x).pow(2).sum().backward()
+        grads.append(net.extra.weight.grad.clone() if net.extra.weight.grad is not None else None)
+    q.put((rank, {"mismatch": dp.stats["used_mismatch"], "skipped": dp.stats["skipped"], "hook_ms": dp.stats["hook_host_ms"],
+                  "extra": [g.numpy() if g is not None else None for g in grads],
+                  "a": net.a.weight.grad.numpy()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_the_gradless_set_do_not_hang():
+    """the grad-less set is learned per rank from the first backward; if the ranks disagree (a data-dependent branch,
+    a warm-up on one rank) they would issue different numbers of all-reduces and hang.  The sets are exchanged once: the union is
+    used everywhere (the rank without a gradient contributes zeros), the mismatch is counted in stats."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["mismatch"] == res[1]["mismatch"] == 2          # extra.weight, extra.bias
+    assert (res[0]["a"] == res[1]["a"]).all()
+    # rank 1's gradient of `extra` is halved (the mean with rank 0's zeros) and identical in every step
+    e1 = res[1]["extra"]
+    assert e1[0] is not None and (e1[0] == e1[1]).all() and (e1[1] == e1[2]).all()
+    assert res[0]["hook_ms"] >= 0.0
+
+
 def test_default_buckets_split_the_mil_model():
     """DeformCrossTransMIL has 1.96 MB of parameters: the default bucket size must give several buckets (one 2 MiB bucket
     could only ever be reduced after backward had finished)."""

@@ -193,9 +193,39 @@ def test_dropout_mask_changes_between_graph_replays(cuda):
         seen.append((off, out_s.clone(), dq_s.clone()))
         # an eager call with the effective seed reproduces the replay (forward and backward agree on the mask)
         dev["q"].grad = None
-        o = Fh.deform_attention(*(dev[n] for n in names), heads=H, groups=G, scale=0.125, dropout_p=0.25, dropout_seed=seed + off)
+        o = Fh.deform_attention(*(dev[n] for n in names), heads=H, groups=G, scale=0.125, dropout_p=0.25,
+                                dropout_seed=_mix64(seed ^ _mix64(off)))
         o.sum().backward()
         assert torch.equal(o.detach(), out_s), "forward of the replay differs from the eager call with its effective seed"
         assert_close("dq of a graph replay vs eager with the same effective seed", dq_s, dev["q"].grad, 1e-6)
     assert seen[0][0] != seen[1][0] != seen[2][0]
     assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1]), "replays must draw different masks"
+
+
+def _mix64(z):
+    """splitmix64 finaliser, as csrc/deform_attn.hip mix64"""
+    M = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def test_dropout_masks_of_graph_replays_are_uncorrelated(cuda):
+    """with the replay offset ADDED to the seed the mask of replay r was the mask of replay 0 shifted by (calls per step)
+    x r elements along the key axis.  The offset is now hashed into the key: masks of different offsets must agree with each
+    other - at every small index shift - no more often than independent masks do (p^2 + (1 - p)^2), and keep the right density."""
+    Fh = smml.functional
+    B, N, J, H, p, seed = 1, 300, 80, 8, 0.5, 777
+    masks = []
+    for off in (0, 1, 2, 5):
+        m = Fh.deform_attention_dropout_mask(B, N, J, H, p, seed, cuda, seed_offset=torch.tensor([off], device=cuda, dtype=torch.int64))
+        assert abs(float(m.mean()) - (1 - p)) < 0.01
+        masks.append(m.flatten().bool())
+    n = masks[0].numel()
+    for a in range(len(masks)):
+        for b in range(a + 1, len(masks)):
+            for shift in range(-12, 13):
+                lo, hi = max(0, shift), min(n, n + shift)
+                agree = float((masks[a][lo - shift:hi - shift] == masks[b][lo:hi]).float().mean())
+                assert abs(agree - 0.5) < 0.01, f"offsets {a},{b} shift {shift}: masks agree on {agree:.3f} of the elements"

@@ -87,7 +87,21 @@ def test_pinned_bag_stager(cuda):
         assert torch.equal(lab.cpu(), batches[k][2])
         ptrs.add(bag.data_ptr())
         y = (bag * 2).sum()          # consumer work on the current stream
-    assert k == 4 and len(ptrs) == 2 and torch.isfinite(y)
+    assert k == 4 and len(ptrs) == 3 and torch.isfinite(y)       # three staging slots, reused
+    # a consumer may keep the previous batch across one iteration (with two slots it was overwritten under it) - checked
+    # with long-running consumer kernels in flight so that a missing device-side ordering would show
+    big = [(torch.full((4, 2000, 512), float(i)), torch.tensor([i])) for i in range(6)]
+    st = smml.PinnedBagStager(big, cuda)
+    prev = None
+    acc = torch.zeros((), device=cuda)
+    w = torch.randn(2048, 2048, device=cuda)
+    for k, (bag, lab) in enumerate(st):
+        for _ in range(20):
+            w = torch.tanh(w @ w * 1e-3)                # keeps the consumer's stream busy while the next batches are staged
+        if prev is not None:
+            acc = acc + (prev[0].mean() - float(k - 1)).abs() + (bag.mean() - float(k)).abs()      # the previous batch is still intact
+        prev = (bag, lab)
+    assert k == 5 and float(acc) == 0.0 and st.host_wait_s < 0.5
     st16 = smml.PinnedBagStager(batches[:2], cuda, bag_dtype=torch.bfloat16)
     for k, (bag, om, lab) in enumerate(st16):
         assert bag.dtype == torch.bfloat16 and torch.equal(bag.cpu(), batches[k][0].to(torch.bfloat16))
