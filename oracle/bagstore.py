@@ -3,9 +3,11 @@
 Restates data/dataset.py:151-175 (IvYGAP_Dataset.read_img; the TCGA copy at :383-407 is identical): a bag of num_patches
 rows is brought to max_num = args.fixdim rows - shorter bags are repeated floor(max_num / num_patches) times and topped up
 with their first max_num % num_patches rows, longer bags keep row int(np.around(i * (num_patches / max_num))).
-The reference embeds the rule in its image-reading loop (it needs the patch files), so it cannot be executed here: this
-restatement keeps its statements' arithmetic (list concatenation, Python float division, np.around) - parity unpinned for
-this row, by construction only."""
+The reference embeds the rule in its image-reading loop (it needs the patch files to run as it stands).  PINNED: tests/golden/
+make_golden.py (case_fixdim) executes the statements of read_img themselves - source taken from the imported class, file access
+(np.load / io.imread / os.listdir) replaced by stand-ins that return row numbers - and stores the resulting index vectors for 33
+(bag length, fixdim) pairs in tests/golden/fixdim_indices.npz; tests/test_bag_store.py checks this restatement, the package's
+vectorised form and the device kernel against them, bit for bit."""
 from __future__ import annotations
 
 import numpy as np

@@ -474,6 +474,53 @@ def case_gradmod(check):
     print("wrote gradmod_b8.npz")
 
 
+FIXDIM_CASES = [(n, f) for f in (50, 2500, 10000) for n in (1, 7, 49, 50, 51, 811, 2499, 2500, 2501, 3000, 12345)]
+
+
+def case_fixdim(check):
+    """The fixed-instance-count rule (f3) is embedded in the image-reading loop of the reference's datasets
+    (data/dataset.py:142-175, IvYGAP_Dataset.read_img) and needs the patch files to run as it stands.  Here the METHOD'S OWN
+    STATEMENTS are executed: its source is taken from the imported class at generation time (inspect), cut at the end of the
+    index-selection block (:175, before the image reshapes), and run with stand-ins for the file system only - `np.load` returns a
+    synthetic read_details table whose row i is (i, 0), `io.imread` returns the row number encoded in the requested file name,
+    `os.listdir` returns nothing.  `patch_all` is then the list of source rows the reference would have read, in order."""
+    import inspect, textwrap
+    for name in ("skimage.io", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = sys.modules["h5py"].__class__(name)
+    sys.modules["skimage"].io = sys.modules["skimage.io"]; sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].Compose = object
+    import data.dataset as ds
+    from oracle.bagstore import fixdim_indices
+    src = inspect.getsource(ds.IvYGAP_Dataset.read_img).split("\n")
+    end = next(i for i, ln in enumerate(src) if "patch_all = np.asarray(patch_all)" in ln)
+    body = textwrap.dedent("\n".join(src[1:end]))                 # the statements between `def read_img(self, index):` and :175
+    assert "np.around(i * (num_patches / max_num))" in body and "max_num % num_patches" in body
+
+    class _Np:                                                    # numpy with np.load replaced (the only file access through np)
+        def __init__(self, table): self._t = table
+        def __getattr__(self, k): return getattr(np, k)
+        def load(self, *a, **k): return [self._t]
+
+    payload = {}
+    for n, fixdim in FIXDIM_CASES:
+        table = np.stack((np.arange(n), np.zeros(n, dtype=np.int64)), axis=1)
+        io = argparse.Namespace(imread=lambda path: int(os.path.basename(path).split("_")[0]))
+        self_ = argparse.Namespace(dataDir="/nowhere/", LIST=np.array([["0", "bag"]]), args=argparse.Namespace(dataDir="/nowhere/", fixdim=fixdim))
+        ns = dict(np=_Np(table), io=io, os=argparse.Namespace(listdir=lambda p: [], path=os.path), self=self_, index=0)
+        exec(body, ns)
+        idx = np.asarray(ns["patch_all"], dtype=np.int64)
+        assert idx.shape == (fixdim,), (n, fixdim, idx.shape)
+        payload[f"n{n}_f{fixdim}"] = idx.astype(np.int32)
+        if check:
+            mine = fixdim_indices(n, fixdim)
+            print(f"  oracle vs reference  fixdim n={n:<6d} fixdim={fixdim:<6d} equal={bool(np.array_equal(mine, idx))}")
+            assert np.array_equal(mine, idx)
+    np.savez_compressed(os.path.join(HERE, "fixdim_indices.npz"), **payload)
+    print("wrote fixdim_indices.npz", os.path.getsize(os.path.join(HERE, "fixdim_indices.npz")) // 1024, "KiB")
+
+
 def rel_err(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -492,7 +539,7 @@ if __name__ == "__main__":
     install_stubs()
     cases = {"deform2d": case_deform2d, "deform1d": case_deform1d, "nystrom": case_nystrom,
              "translayer": case_translayer, "pathomic": case_pathomic, "losses": case_losses,
-             "coattn": case_coattn_fusion, "cmta": case_cmta, "gradmod": case_gradmod}
+             "coattn": case_coattn_fusion, "cmta": case_cmta, "gradmod": case_gradmod, "fixdim": case_fixdim}
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):
             continue
