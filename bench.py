@@ -33,7 +33,7 @@ PKG = "subspace-multimodal-learning_amd"
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix) = FP32 vector, dense
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA - the pipe every contraction of the dominant kernels issues on
 CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 1 + 1 + 2 + 4 + 4
-CPB_FWD_MFMAS = 9                   # deform_attn_fwd_kernel: 1 (layer 1) + 8 (layer 2, four-term split) 16-bit MFMAs per (key, 32 queries)
+CPB_FWD_MFMAS = 7                   # deform_attn_fwd_kernel: 1 (layer 1) + 6 (layer 2, three-term split) 16-bit MFMAs per (key, 32 queries)
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
 TRAFFIC_FILE = "r02_hbm_traffic.json"

@@ -60,9 +60,9 @@ def cpb_mlp(pos: torch.Tensor, p: Params, prefix: str = "rel_pos_bias.", masks=N
     DeformableAttention2D.py:129-152 / DeformableAttention1D.py:69-98.
     ``pos`` is [..., in] and already signed-log transformed.  ``masks`` = (m1, m2): imposed ReLU decisions (see DECISIONS)."""
     x1 = pos @ p[prefix + "mlp.0.0.weight"].t() + p[prefix + "mlp.0.0.bias"]
-    h = torch.relu(x1) if masks is None else x1 * masks[0].to(x1.dtype)
+    h = torch.relu(x1) if masks is None else x1 * masks[0].to(device=x1.device, dtype=x1.dtype)
     x2 = h @ p[prefix + "mlp.1.0.weight"].t() + p[prefix + "mlp.1.0.bias"]
-    h = torch.relu(x2) if masks is None else x2 * masks[1].to(x2.dtype)
+    h = torch.relu(x2) if masks is None else x2 * masks[1].to(device=x2.device, dtype=x2.dtype)
     out = h @ p[prefix + "mlp.2.weight"].t() + p[prefix + "mlp.2.bias"]
     if GRAD_PROBE is not None and out.requires_grad:
         key = id(p[prefix + "mlp.2.bias"])
@@ -113,7 +113,7 @@ def sample_positions(vx: torch.Tensor, vy: torch.Tensor, W: int, H: int, cells=N
             GRAD_PROBE["boundary"] = min(GRAD_PROBE.get("boundary", 1.0), d)
     x0f, y0f = torch.floor(ix), torch.floor(iy)
     if cells is not None:            # imposed cells (see DECISIONS): the bilinear formula of that cell, extended past its edge by <= rounding
-        x0f, y0f = cells[0].to(ix.dtype), cells[1].to(iy.dtype)
+        x0f, y0f = cells[0].to(device=ix.device, dtype=ix.dtype), cells[1].to(device=iy.device, dtype=iy.dtype)
         with torch.no_grad():
             for c, f in ((ix, x0f), (iy, y0f)):
                 assert float((c - f).min()) > -1e-3 and float((c - f).max()) < 1 + 1e-3, "imposed cell is not the sample's (or its neighbour within rounding)"

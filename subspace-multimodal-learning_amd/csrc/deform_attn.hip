@@ -30,13 +30,15 @@
 #define SMML_FWD_WPS 2      // waves per SIMD the forward kernel is register-budgeted for
 #endif
 #ifndef SMML_SPLIT_TERMS
-#define SMML_SPLIT_TERMS 4    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer of the forward:
+#define SMML_SPLIT_TERMS 3    // products kept of W h = (wh + wm + wl)(hh + hl) in the 32x32 layer of the forward:
                               //   3 = wh hh + wh hl + wm hh (<= 2^-21 |w||h| dropped), 4 adds wm hl (W2 and h both to 22 bits: <= 2^-23
-                              //   dropped), 5 adds wl hh (W2 to 33 bits).  The layer's VALUE does not care, but its SIGN is the ReLU mask
-                              //   the backward consumes: with 3 terms the saved masks flip 4-5 x as often as torch's fp32 evaluation flips
-                              //   its own and the position-bias weight gradients came out 4-5 x noisier than torch fp32 against an fp64
-                              //   evaluation (tests/diag_gterms.py, profiles/r02_split_terms.txt: dW1 1.1e-3 vs torch 2.0e-4); with 4
-                              //   terms 2.2e-4, with 5 terms 2.07e-4.  4 costs two MFMAs per key over 3 (+0.5 ms per 8-bag step), 5 four.
+                              //   dropped), 5 adds wl hh (W2 to 33 bits).  The layer's VALUE is fp32-grade with 3; its SIGN is the ReLU mask the
+                              //   backward consumes, and with 3 terms a few more rounding-level ties (|pre-activation| ~ 1e-7) fall the other
+                              //   way than in an fp64 evaluation (profiles/r02_split_terms.txt: 8-9 of 2.3e8 decisions for every variant,
+                              //   torch fp32: 6).  Round 2 shipped 4 terms because its gradient-level gate compared gradients ACROSS such
+                              //   flips (one flipped unit moves dW1 by ~4e-4 of its norm); round 3's parity tests impose the kernels' own
+                              //   decisions on the oracle (tests/helpers.py), under which 3 and 4 terms give the same errors
+                              //   (gpurun_out/parity_report_{default,s3}.tsv) - and 3 is two MFMAs per key cheaper (-0.5 ms per 8-bag step).
 #endif
 #ifndef SMML_DELTA_FIX
 #define SMML_DELTA_FIX 0      // 1: re-centre the rows of d bias in the position-bias backward (d bias_k - P_k sum_k d bias_k).

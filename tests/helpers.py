@@ -9,6 +9,9 @@ Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exa
     oracle against an fp64 evaluation of the same quantity = its `noise`) gets max(1e-4, NOISE_FACTOR x noise) with
     NOISE_FACTOR = 2, never more than NOISE_CAP - except where the reference's own noise already exceeds the cap / 2
     (then 2 x noise, flagged `ill` in the report: the fixture itself cannot be reproduced closer by any fp32 program);
+  * the full-size model test (config 4, 100 x 100) measures the noise on TWO fp32 back ends - the oracle on the host CPU and the same
+    oracle code on the GPU's ATen kernels - and takes the larger: for its cancellation-heavy gradients torch-on-GPU fp32 sits up to
+    10 x further from fp64 than torch-on-CPU fp32 (profiles/r03_fp32_backends.txt), and the reference is a GPU training code;
   * where an fp64 truth is available the HIP result is ALSO held to the reference's own accuracy in the l2 norm:
     l2(hip - fp64) <= max(1e-4, L2_FACTOR x l2(fp32 - fp64)) with L2_FACTOR = 1.5 - the kernels may not be noisier than
     1.5 x torch's fp32 evaluation (VERDICT r01 item 1);
@@ -76,20 +79,27 @@ def assert_close(name, got, ref, tol=TOL):
     assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
 
 
-def assert_calibrated(name, got, ref32, ref64, floor=TOL):
+def assert_calibrated(name, got, ref32, ref64, floor=TOL, ref32_alt=None):
     """HIP result against the fp64 oracle: max-norm within max(floor, 2 x noise) (capped, see module docstring) and l2-norm
-    within max(floor, 1.5 x the fp32 oracle's own l2 distance to fp64)."""
+    within max(floor, 1.5 x the fp32 oracle's own l2 distance to fp64).  `ref32_alt`: a second fp32 evaluation of the oracle on
+    another back end (the GPU's ATen kernels); the noise is then the larger of the two distances to fp64 - two fp32 back ends of
+    the SAME op sequence sit up to 10 x differently far from fp64 on cancellation-heavy gradients (profiles/r03_fp32_backends.txt:
+    the host's blocked summations are unusually accurate; the reference itself trains on a GPU)."""
     if float(ref64.detach().abs().max()) < 1e-12:        # identically zero in exact arithmetic (e.g. one sampled key: d scores = 0)
         gm = float(got.detach().abs().max())
         record(name, gm, None, 1e-3, "zero")
         assert gm < 1e-3, f"{name}: expected ~0 (rounding of cancelling terms), got {gm:.3e}"
         return
     noise = rel_err(ref32, ref64)
+    if ref32_alt is not None:
+        noise = max(noise, rel_err(ref32_alt, ref64))
     tol = bound_for(noise, floor)
     e = rel_err(got, ref64)
     record(name, e, noise, tol, "max" if noise <= NOISE_CAP / NOISE_FACTOR else "max,ill")
     assert e <= tol, f"{name}: rel err vs fp64 oracle {e:.3e} > {tol:.3e} (fp32 oracle's own: {noise:.3e})"
     n2 = l2_err(ref32, ref64)
+    if ref32_alt is not None:
+        n2 = max(n2, l2_err(ref32_alt, ref64))
     tol2 = max(floor, L2_FACTOR * n2)
     e2 = l2_err(got, ref64)
     record(name, e2, n2, tol2, "l2")
