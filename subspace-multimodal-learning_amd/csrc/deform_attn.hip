@@ -61,8 +61,12 @@
                               // and by delta = rowsum(dO . O)), and the kernel is 10 % faster.  3: fp32-grade summands.
 #endif
 #ifndef SMML_BWD_TERMS
-#define SMML_BWD_TERMS 3      // bf16 terms per operand in the dq / dkv passes: 3 = fp32-grade (six products per block), 2 = 16-bit operands
-                              // (hi + mid, three products: measurement switch, profiles/r02_split_terms.txt)
+#define SMML_BWD_TERMS 3      // bf16 terms per operand in the dq pass: 3 = fp32-grade (six products per block), 2 = 16-bit operands (hi + mid,
+                              // three products: measurement switch - d scores then carry 2^-17 errors, which the position-bias gradients
+                              // (dW3) and the single-key case (dS = 0 exactly) do not pass the parity gate with, profiles/r02_split_terms.txt)
+#endif
+#ifndef SMML_DKV_TERMS
+#define SMML_DKV_TERMS SMML_BWD_TERMS   // the same for the dkv pass (dK, dV only: nothing downstream recomputes from them)
 #endif
 #ifndef SMML_FWD_QK16
 #define SMML_FWD_QK16 1       // forward QK^T / PV on the 16-bit matrix pipe: every operand as fp16 hi + lo (RNE, 22 bits), three of the
@@ -249,15 +253,13 @@ __device__ __forceinline__ float pow2_lift(float amax, float target, float lo, f
   return ldexpf(1.f, (int)fminf(fmaxf(k, lo), hi));      // an exact power of two (exp2f is the 1-ulp hardware approximation)
 }
 
-// one 32x32x16 block of a backward contraction from split operands
+// one 32x32x16 block of a backward contraction from split operands (TERMS bf16 terms per operand: 3 = six products, 2 = three)
+template <int TERMS>
 __device__ __forceinline__ floatx16 bwd_prod(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, floatx16 d) {
-#if SMML_BWD_TERMS == 3
-  return mfma16b_x6(ah, am, al, bh, bm, bl, d);
-#else
+  if (TERMS == 3) return mfma16b_x6(ah, am, al, bh, bm, bl, d);
   d = mfma16b(am, bh, d);
   d = mfma16b(ah, bm, d);
   return mfma16b(ah, bh, d);
-#endif
 }
 
 struct CpbParams {
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&Vp[buf][0][o]);
       const bf16x8 vm = *reinterpret_cast<const bf16x8*>(&Vp[buf][1][o]);
       const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&Vp[buf][2][o]);
-      dp = bwd_prod(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
+      dp = bwd_prod<SMML_BWD_TERMS>(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
     }
 
     float ds[16];
@@ -728,8 +730,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         const bf16x8 kh = lds_frag_tr(&Kp[buf][0][ro + 32 * db], &Kp[buf][0][ro + 32 * db + 8 * KBLD]);
         const bf16x8 km = lds_frag_tr(&Kp[buf][1][ro + 32 * db], &Kp[buf][1][ro + 32 * db + 8 * KBLD]);
         const bf16x8 kl = lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]);
-        if (db == 0) dq0 = bwd_prod(kh, km, kl, sh, sm, sl, dq0);
-        else dq1 = bwd_prod(kh, km, kl, sh, sm, sl, dq1);
+        if (db == 0) dq0 = bwd_prod<SMML_BWD_TERMS>(kh, km, kl, sh, sm, sl, dq0);
+        else dq1 = bwd_prod<SMML_BWD_TERMS>(kh, km, kl, sh, sm, sl, dq1);
       }
     }
   }
@@ -825,11 +827,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
       split4_bf3(qreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&Qp[buf][0][o]) = hh;
       *reinterpret_cast<uint2v*>(&Qp[buf][1][o]) = mm;
-      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&Qp[buf][2][o]) = ll;
+      if (SMML_DKV_TERMS == 3) *reinterpret_cast<uint2v*>(&Qp[buf][2][o]) = ll;
       split4_bf3(doreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&dOp[buf][0][o]) = hh;
       *reinterpret_cast<uint2v*>(&dOp[buf][1][o]) = mm;
-      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&dOp[buf][2][o]) = ll;
+      if (SMML_DKV_TERMS == 3) *reinterpret_cast<uint2v*>(&dOp[buf][2][o]) = ll;
     }
     if (tid < QT) nls[buf][tid] = prob_bias(lsereg);
     __syncthreads();        // one barrier per tile (double buffer, see pass 1)
@@ -874,8 +876,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
           const bf16x8 qh = lds_frag_tr(&Qp[buf][0][o], &Qp[buf][0][o + 8 * QBLD]);
           const bf16x8 qm = lds_frag_tr(&Qp[buf][1][o], &Qp[buf][1][o + 8 * QBLD]);
           const bf16x8 ql = lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]);
-          if (db == 0) { dv0 = bwd_prod(ah, am, al, ph, pm, pl, dv0); dk0 = bwd_prod(qh, qm, ql, sh, sm, sl, dk0); }
-          else { dv1 = bwd_prod(ah, am, al, ph, pm, pl, dv1); dk1 = bwd_prod(qh, qm, ql, sh, sm, sl, dk1); }
+          if (db == 0) { dv0 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv0); dk0 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk0); }
+          else { dv1 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv1); dk1 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk1); }
         }
       }
     }
