@@ -235,6 +235,10 @@ size_t smml_attn16_fwd_workspace_bytes(int BH, int Lq, int Lk);   /* 0 unless th
 int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, void* workspace,
                         size_t workspace_bytes, int BH, int Lq, int Lk, int D, float scale, int use_fp16, int heads_merged,
                         int accumulate, void* stream);
+/* forward kernel choice for Lk <= 256 (measurement / test hook): 0 (default) = always the online-softmax kernel, 1 = the two-pass
+ * kernel with all keys resident in LDS wherever its 256-query workgroups fill the chip, 2 = wherever Lk <= 256.  The two-pass kernel
+ * halves the vector instructions per MFMA but the launch is HBM-bound with fp32 storage (csrc/attn16.hip). */
+void smml_attn16_set_fewkeys(int mode);
 size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk);
 int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* residual, const float* dout,
                         const float* lse2, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, int BH, int Lq,

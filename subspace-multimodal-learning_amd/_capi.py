@@ -30,6 +30,7 @@ SIGNATURES = {
     "smml_gemm_set_small_tile": (None, [_i]),
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
+    "smml_attn16_set_fewkeys": (None, [_i]),
     "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_bwd_f32": (_i, [_f] * 10 + [_f, _sz, _i, _i, _i, _i, _fl, _i, _i, _f]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),

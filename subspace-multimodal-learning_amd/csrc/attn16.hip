@@ -17,6 +17,8 @@
 // they stand (converted pairwise to 16 bit; the k order of that fragment is acc_row(8 s + j, half), which the transposed
 // LDS reads of V^T reproduce).  head dim 64; 32 queries per wave, 4 waves per workgroup, 32-key tiles, double-buffered
 // LDS with the next tile's global loads in flight during the MFMAs.
+#include <algorithm>
+#include <cstdlib>
 #include "smml_common.h"
 
 namespace {
@@ -208,6 +210,153 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
       *reinterpret_cast<float4*>(op + 32 + d) = b;
     }
     if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward for FEW KEYS (Lk <= 256: the [n', m] side of the Nystrom block, m = 256 landmarks): two-pass softmax, no online rescale.
+// All keys' K and V are staged ONCE per workgroup (bf16 / fp16 images, 86 KB: one 8-wave workgroup per CU = two waves per SIMD);
+// a wave keeps the whole score row block S^T [256 keys x 32 queries] in registers (8 accumulators), takes the exact row maximum,
+// exponentiates once and feeds P^T straight into O^T = V^T P^T.  Against the online form this drops, per 32-key tile, the running
+// maximum bookkeeping, the exp of the correction factor and the rescale of the 32 output registers: ~9 vector instructions per
+// MFMA instead of ~24 (profiles/r02_nystrom16_pmc.txt).       grid (ceil(Lq / 256 / blocks per workgroup), BH), 512 threads, dynamic LDS: the staging is paid once per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_MAX = 256;                       // keys
+constexpr int SK_WAVES = 8;                       // waves per workgroup (32 queries each)
+constexpr size_t SK_LDS = (size_t)SK_MAX * (RLD + TLD) * 2;   // bytes: K row image + V transposed-read image
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn16_fwd_fewkeys_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                    const float* __restrict__ V, float* __restrict__ O,
+                                                                    float* __restrict__ LSE2, int Lq, int Lk, float qscale,
+                                                                    OLayout ol, int accumulate, int blocks_per_wg) {
+  typedef typename Pipe<T>::x8 x8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+  T* Kr = reinterpret_cast<T*>(sk_smem);                       // [256][RLD]
+  T* Vt = Kr + SK_MAX * RLD;                                   // [256][TLD]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.y;
+  const int nblk = (Lq + AQ * SK_WAVES - 1) / (AQ * SK_WAVES);
+  const int blk0 = blockIdx.x * blocks_per_wg, blk1 = min(nblk, blk0 + blocks_per_wg);    // this workgroup's 256-query blocks
+  const float* Kb = K + (size_t)bh * Lk * AD;
+  const float* Vb = V + (size_t)bh * Lk * AD;
+  const float* Qb = Q + (size_t)bh * Lq * AD;
+  // the first block's query rows are requested before the keys (they are consumed right after the staging barrier)
+  float4 qraw[8];
+  auto load_q = [&](int blk) {
+    const int qi = min(blk * (AQ * SK_WAVES) + wave * AQ + c, Lq - 1);
+    const float* qrow = Qb + (size_t)qi * AD + 8 * hf;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      qraw[2 * st] = *reinterpret_cast<const float4*>(qrow + 16 * st);
+      qraw[2 * st + 1] = *reinterpret_cast<const float4*>(qrow + 16 * st + 4);
+    }
+  };
+  load_q(blk0);
+  // stage every key once per workgroup: thread -> key (tid >> 4) + 32 i, 4 consecutive d (rows past Lk are zero); the staging
+  // is paid once for blocks_per_wg query blocks
+  {
+    // all sixteen loads are issued before the first use (clamped addresses, rows past Lk zeroed afterwards: a branch around each
+    // load would make hipcc wait for every one of them in turn)
+    const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+    float4 kreg[SK_MAX / 32], vreg[SK_MAX / 32];
+#pragma unroll
+    for (int i = 0; i < SK_MAX / 32; ++i) {
+      const int key = min(skey + 32 * i, Lk - 1);
+      kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * AD + sd4);
+      vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * AD + sd4);
+    }
+#pragma unroll
+    for (int i = 0; i < SK_MAX / 32; ++i) {
+      const int key = skey + 32 * i;
+      const float z = (key < Lk) ? 1.f : 0.f;
+      *reinterpret_cast<uint2v*>(&Kr[key * RLD + sd4]) = pack4<T>(make_float4(kreg[i].x * z, kreg[i].y * z, kreg[i].z * z, kreg[i].w * z));
+      *reinterpret_cast<uint2v*>(&Vt[key * TLD + sd4]) = pack4<T>(make_float4(vreg[i].x * z, vreg[i].y * z, vreg[i].z * z, vreg[i].w * z));
+    }
+  }
+  __syncthreads();
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int nt = (Lk + AK - 1) / AK;                  // <= 8 tiles of 32 keys
+  for (int blk = blk0; blk < blk1; ++blk) {
+    const int q0 = blk * (AQ * SK_WAVES) + wave * AQ;
+    const bool qvalid = (q0 + c) < Lq;
+    const int qi = qvalid ? (q0 + c) : (Lq - 1);
+    x8 qf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const float4 a = qraw[2 * st], b = qraw[2 * st + 1];
+      const float x[8] = {a.x * qscale, a.y * qscale, a.z * qscale, a.w * qscale, b.x * qscale, b.y * qscale, b.z * qscale, b.w * qscale};
+      qf[st] = pack8<T>(x);
+    }
+    if (blk + 1 < blk1) load_q(blk + 1);              // next block's rows arrive during this block's MFMAs
+    // pass 1: S^T = K (qscale Q)^T for every tile, row maximum
+    floatx16 s[SK_MAX / AK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < SK_MAX / AK; ++t) {
+      s[t] = floatx16{0};
+      if (t < nt) {                                     // uniform
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          s[t] = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Kr[(32 * t + c) * RLD + 16 * st + 8 * hf]), qf[st], s[t]);
+        if (32 * t + 32 > Lk) {                         // ragged last tile (uniform)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (32 * t + acc_row(r, hf) >= Lk) s[t][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[t][r]);
+      }
+    }
+    m = xhalf_max(m);
+    // pass 2: P^T = 2^(S^T - m), row sum, O^T += V^T P^T
+    floatx16 o0 = {0}, o1 = {0};
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < SK_MAX / AK; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m); l += s[t][r]; }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float p8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p8[j] = s[t][8 * kb + j];
+          const x8 pb = pack8<T>(p8);
+          const int ro = (32 * t + 16 * kb + 4 * hf + trq) * TLD + trc;
+          o0 = Pipe<T>::mfma(frag_tr<T>(&Vt[ro], &Vt[ro + 8 * TLD]), pb, o0);
+          o1 = Pipe<T>::mfma(frag_tr<T>(&Vt[ro + 32], &Vt[ro + 32 + 8 * TLD]), pb, o1);
+        }
+      }
+    }
+    l = xhalf_sum(l);
+    const float inv = 1.f / l;
+    {
+      // the residual (out already holds the depthwise convolution of v) is fetched as ONE batch of loads: with the load inside the
+      // store loop hipcc waits for each (four dependent L2 round trips per block)
+      float* op = O + obase(ol, bh) + (size_t)qi * ol.rs;
+      float4 ra[4], rb[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
+      if (accumulate) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          ra[rg] = *reinterpret_cast<const float4*>(op + 8 * rg + 4 * hf);
+          rb[rg] = *reinterpret_cast<const float4*>(op + 32 + 8 * rg + 4 * hf);
+        }
+      }
+      if (qvalid) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int d = 8 * rg + 4 * hf;
+          *reinterpret_cast<float4*>(op + d) = make_float4(fmaf(o0[4 * rg], inv, ra[rg].x), fmaf(o0[4 * rg + 1], inv, ra[rg].y),
+                                                           fmaf(o0[4 * rg + 2], inv, ra[rg].z), fmaf(o0[4 * rg + 3], inv, ra[rg].w));
+          *reinterpret_cast<float4*>(op + 32 + d) = make_float4(fmaf(o1[4 * rg], inv, rb[rg].x), fmaf(o1[4 * rg + 1], inv, rb[rg].y),
+                                                                fmaf(o1[4 * rg + 2], inv, rb[rg].z), fmaf(o1[4 * rg + 3], inv, rb[rg].w));
+        }
+        if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m + __builtin_amdgcn_logf(l);
+      }
+    }
   }
 }
 
@@ -521,7 +670,16 @@ static int attn16_parts(int BH, int Lq, int Lk) {
 
 }  // namespace
 
+// forward with <= 256 keys: -1 = read SMML_ATTN16_FEWKEYS (default 0), 0 = the online-softmax kernel, 1 = the two-pass kernel where its
+// grid fills the chip, 2 = wherever Lk <= 256 (tests).  OFF by default - measured at 4 x 8 heads x 10 240 queries x 256 keys
+// (profiles/r03_nystrom16_notes.md): the two-pass kernel issues 13 vector instructions per MFMA instead of 24, and is SLOWER (69 vs 54
+// us): with fp32 storage this launch moves 252 MB (q in, residual in, out out) - 4.7 TB/s at 54 us - i.e. the [n', m] side of the Nystrom
+// block is HBM-bound, not issue-bound, and one 8-wave workgroup per CU (86 KB of LDS) keeps fewer bytes in flight than two 4-wave ones.
+static int g_fewkeys = -1;
+
 extern "C" {
+
+void smml_attn16_set_fewkeys(int mode) { g_fewkeys = mode; }
 
 // scratch of smml_attn16_fwd_f32: the partial outputs + log-sum-exps of a key-split launch (0 when the launch is not split)
 size_t smml_attn16_fwd_workspace_bytes(int BH, int Lq, int Lk) {
@@ -571,8 +729,27 @@ int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* o
     lpart = opart + (size_t)ns * BH * Lq * AD;
   }
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, ns), block(256);
   const float qscale = scale * LOG2E_F;
+  // few keys, many queries (the [n', m] side of the Nystrom block): the two-pass kernel with all keys resident in LDS
+  if (g_fewkeys < 0) { const char* e = getenv("SMML_ATTN16_FEWKEYS"); g_fewkeys = e ? atoi(e) : 0; }
+  const bool fills = (long)BH * ((Lq + AQ * SK_WAVES - 1) / (AQ * SK_WAVES)) >= 128;      // enough 256-query workgroups for the chip
+  if (ns == 1 && Lk <= SK_MAX && (g_fewkeys == 2 || (g_fewkeys == 1 && fills))) {
+    // one workgroup stages the keys once and walks blocks_per_wg 256-query blocks: ~1.5 workgroups per CU in all
+    const int nblk = (Lq + AQ * SK_WAVES - 1) / (AQ * SK_WAVES);
+    const int bpw = (int)std::max(1L, std::min<long>(nblk, ((long)nblk * BH) / 384));
+    dim3 gridf((nblk + bpw - 1) / bpw, BH), blockf(64 * SK_WAVES);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_fewkeys_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_fewkeys_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS);
+      attr_set = true;
+    }
+    if (use_fp16) hipLaunchKernelGGL(attn16_fwd_fewkeys_kernel<_Float16>, gridf, blockf, SK_LDS, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, bpw);
+    else hipLaunchKernelGGL(attn16_fwd_fewkeys_kernel<__bf16>, gridf, blockf, SK_LDS, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, bpw);
+    SMML_LAUNCH_CHECK("smml_attn16_fwd_f32/fewkeys");
+    return SMML_OK;
+  }
+  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, ns), block(256);
   if (use_fp16) hipLaunchKernelGGL(attn16_fwd_kernel<_Float16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
   else hipLaunchKernelGGL(attn16_fwd_kernel<__bf16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
   SMML_LAUNCH_CHECK("smml_attn16_fwd_f32");

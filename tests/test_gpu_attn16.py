@@ -52,6 +52,36 @@ def test_attention16_vs_fp64(cuda, fp16, B, H, Lq, Lk):
         assert l2_err(a.grad, b.grad) <= tol / 2
 
 
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("B,H,Lq,Lk,merged", [(1, 2, 1, 1, False), (2, 3, 300, 70, False), (1, 8, 1000, 256, True), (2, 4, 257, 33, True),
+                                             (1, 2, 513, 255, False)])
+def test_attention16_fewkeys_forward(cuda, fp16, B, H, Lq, Lk, merged):
+    """The two-pass forward for <= 256 keys (all keys resident in LDS, exact row maximum, no online rescale - the [n', m] side of the
+    Nystrom block), forced on whatever the grid size: against fp64 AND against the online-softmax kernel on the same inputs (the
+    two must agree to the operand rounding; the saved log-sum-exp too, since the shared backward consumes it); ragged last key tile,
+    a single key, more than one 256-query workgroup, heads-merged output accumulated onto a residual."""
+    gen = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q = torch.randn(B, H, Lq, 64, generator=gen); k = torch.randn(B, H, Lk, 64, generator=gen); v = torch.randn(B, H, Lk, 64, generator=gen)
+    res = torch.randn(B, Lq, H * 64, generator=gen) if merged else None
+    o64 = _ref_attention(q.double(), k.double(), v.double(), 0.125, res.double() if merged else None, merged=merged)
+    L = smml.lib()
+    outs = {}
+    for mode in (0, 2):
+        L.smml_attn16_set_fewkeys(mode)
+        try:
+            dev = [t.clone().to(cuda).requires_grad_() for t in (q, k, v)]
+            o = Fh.attention16(*dev, scale=0.125, fp16=fp16, merged=merged, residual=res.to(cuda) if merged else None)
+            o.sum().backward()
+            outs[mode] = (o.detach(), [t.grad for t in dev])
+        finally:
+            L.smml_attn16_set_fewkeys(-1)
+    tol = TOL[fp16]
+    assert_close(f"fewkeys out vs fp64 {Lq}x{Lk}", outs[2][0], o64, tol)
+    assert_close(f"fewkeys out vs online kernel {Lq}x{Lk}", outs[2][0], outs[0][0], tol / 4)
+    for a, b, n in zip(outs[2][1], outs[0][1], "qkv"):           # same backward kernels, fed with each forward's output / lse
+        assert float((a - b).abs().max()) <= (tol / 4) * max(float(b.abs().max()), 1e-3), f"d{n} differs between the two forwards"
+
+
 def test_attention16_merged_layout_and_residual(cuda):
     gen = torch.Generator().manual_seed(5)
     B, H, Lq, Lk = 2, 8, 200, 96
