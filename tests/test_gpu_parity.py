@@ -767,3 +767,14 @@ def test_sampler_gradient_on_cell_boundaries(cuda):
     _assert_close("boundary kv", kv, ref, 1e-5)
     _assert_close("boundary dx", xd.grad, xr.grad, 1e-5)
     _assert_close("boundary dvs", vd.grad, vr.grad, 1e-5)
+
+
+def test_colsum_shapes(cuda):
+    """Column sums (bias gradients, landmark / pooler means): the 16-byte-load kernel (C % 4 == 0, 256 % (C / 4) == 0) and the scalar
+    one, row counts that are not multiples of the row chunks, several batches, a scale."""
+    gen = torch.Generator().manual_seed(8)
+    for (nb, R, C) in [(1, 80000, 128), (3, 1000, 512), (2, 77, 128), (1, 5, 4), (2, 300, 36), (1, 10240, 64), (4, 4097, 256), (2, 33, 1024)]:
+        x = torch.randn(nb, R, C, generator=gen)
+        got = Fh.colsum(x.to(cuda), 0.25)
+        ref = x.double().sum(dim=1) * 0.25
+        _assert_close(f"colsum {nb}x{R}x{C}", got, ref, 2e-6 * max(1.0, (R / 100) ** 0.5))
