@@ -129,10 +129,11 @@ int smml_bilinear_corners_f32(const float* vs, int* cx, int* cy, unsigned char* 
  * Replaces DeformableAttention2D.py:120-157,284-312 and DeformableAttention1D.py:60-102,205-232.
  *   q [B, N, H*64] (unscaled)  k, v [B, J, H*64]  vs [(B G), J, posdim]  gq [N, posdim]
  *   w1 [32, posdim] b1 [32] w2 [32, 32] b2 [32] w3 [H/G, 32] b3 [H/G]
- *   out [B, N, H*64]  lse [B, H, N]  logits_t [B, H, J, smml_deform_attn_nst(N)] and
- *   relu_masks [B, H, J, 2, smml_deform_attn_nst(N)] uint16 (both nullable together: only needed for
- *   backward; relu_masks holds the ReLU decisions of the position bias's second layer, 32 bits per
- *   (query, key, head), in the bit order the backward kernel consumes - opaque to the caller).  H/G <= 2.
+ *   out [B, N, H*64]  lse [B, H, N]  logits_t [B, H, nst / 32, J, 32] and relu_masks [B, H, nst / 32, J, 2, 32] uint16 with
+ *   nst = smml_deform_attn_nst(N) (both nullable together: only needed for backward).  Score-shaped tensors are stored per 32-query
+ *   tile - the unit one wave owns - so that every pass streams contiguous memory; relu_masks holds the ReLU decisions of the
+ *   position bias's second layer, 32 bits per (query, key, head), in the bit order the backward kernel consumes.  Both are
+ *   opaque to the caller (scratch it allocates and hands back to the backward).  H/G <= 2.
  * ev_start / ev_stop (nullable, handles of smml_event_create) are recorded on `stream` around the fused
  * forward kernel, resp. around the position-bias backward kernel (the dominant kernel of the step). */
 int smml_deform_attn_nst(int N);
@@ -144,7 +145,7 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
 /* scratch the backward needs: position-bias gradient slabs, the per-wave d vs rows and the query-sliced dK / dV partial sums;
  * 16-byte aligned */
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
-/* dlogits_t: scratch of logits_t's size (receives d scores); dq / dk / dv / dw* / db* overwritten;
+/* dlogits_t: scratch of logits_t's size and layout (receives d scores); dq / dk / dv / dw* / db* overwritten;
  * dvs overwritten.  Every output is reduced in a fixed order (no float atomics): run-to-run identical results. */
 int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                              const float* w1, const float* b1, const float* w2, const float* b2,

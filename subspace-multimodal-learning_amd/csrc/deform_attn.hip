@@ -227,6 +227,20 @@ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned 
 __device__ __forceinline__ float drop_factor(const DropCfg& dc, unsigned long long idx) {
   return (drop_hash(dc.seed, idx) >= dc.thresh) ? dc.keep_scale : 0.f;
 }
+// In training with dropout the forward stashes each element's keep decision in the LOWEST MANTISSA BIT of the score it saves for the
+// backward (logits_t): both backward passes read those scores anyway and get the decision for free - the hash (two 32-bit multiplies
+// + 64-bit index arithmetic per element) was a third of the dq / dkv passes' vector work.  The score moves by at most one ulp; the
+// direction comes from its second-lowest bit, so the move is zero-mean whatever the decision, and the forward's own softmax uses the
+// stashed value: forward and backward see the same probabilities.
+__device__ __forceinline__ float stash_keep(float x, bool keep) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const unsigned flip = (u ^ (keep ? 1u : 0u)) & 1u;                    // lowest bit differs from the decision
+  const int dir = (u & 0x7FFFFFFEu) ? (int)(u & 2u) - 1 : 1;            // +1 / -1: independent of the decision (never below +-0)
+  return __builtin_bit_cast(float, u + (unsigned)(flip ? dir : 0));
+}
+__device__ __forceinline__ float stashed_factor(float x, float keep_scale) {
+  return (__builtin_bit_cast(unsigned, x) & 1u) ? keep_scale : 0.f;
+}
 
 // max over the 64 lanes (prologue use only)
 __device__ __forceinline__ float wave_max_all(float v) {
@@ -403,10 +417,13 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
-  float* LTb = LT ? LT + ((size_t)(b * H + h) * J) * NST : nullptr;
+  // score-shaped tensors (logits_t, dlogits_t, relu_masks) are stored per 32-query tile: [B, H, NST / 32, J, 32] - a wave streams its
+  // own contiguous [J][32] block in the forward, the dq pass and the position-bias backward, and the dkv pass reads 32 keys x 128 B
+  // = one contiguous 4 KB run per query tile (a key-major [J][NST] row layout made every one of these a 40-KB-strided gather)
+  float* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;              // this wave's [J][32] block
   // layer-2 ReLU masks for the backward (training only): 16 bits per lane and key, element r (hidden channel
   // acc_row(r, hf)) at bit (13 + r) % 16 - the position from which the backward rotates it straight into an fp16 operand
-  unsigned short* MKb = MK ? MK + ((size_t)(b * H + h) * J * 2 + hf) * NST : nullptr;
+  unsigned short* MKb = MK ? MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32 : nullptr;   // [J][2][32] block, this lane half
   float big;                                                  // 2^100 in an SGPR (v_mul_f32 ... clamp takes no literal)
   asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
 
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
           mb3 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb3);
         }
       }
-      if (SAVE) MKb[(size_t)(j0 + jj) * 2 * NST + q0 + c] = (unsigned short)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded rows: no bounds check
+      if (SAVE) MKb[(size_t)(j0 + jj) * 64 + c] = (unsigned short)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded tiles: no bounds check
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);   // both halves store the same sum: no exec masking in the loop
     }
@@ -508,11 +525,26 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       s[r] = sv;
       tmax = fmaxf(tmax, sv);
     }
+    unsigned keepbits = 0xFFFFu;              // dropout decisions of this lane's 16 keys (bit r)
+    if (dc.thresh) {
+      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
+      keepbits = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keepbits |= (drop_hash(dc.seed, base + acc_row(r, hf)) >= dc.thresh) ? (1u << r) : 0u;
+    }
     if (SAVE) {                               // rows are padded to whole workgroup tiles: lanes past N write padding
+      if (dc.thresh) {
+        tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc_row(r, hf) < nk) s[r] = stash_keep(s[r], (keepbits >> r) & 1u);      // finite scores only
+          tmax = fmaxf(tmax, s[r]);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = acc_row(r, hf);
-        if (key < nk) LTb[(size_t)(j0 + key) * NST + q0 + c] = s[r];
+        if (key < nk) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
       }
     }
     tmax = xhalf_max(tmax);
@@ -526,9 +558,8 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
       s[r] = p;
     }
     if (dc.thresh) {                              // dropped / rescaled probabilities feed P.V only
-      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] *= drop_factor(dc, base + acc_row(r, hf));
+      for (int r = 0; r < 16; ++r) s[r] *= ((keepbits >> r) & 1u) ? dc.keep_scale : 0.f;
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -615,7 +646,6 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const int HD = H * DH;
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
-  const int qcol = qvalid ? (q0 + c) : 0;            // column of this lane in the key-major score rows
 
   // dO of this lane's query as the B operand of dP^T = V . dO^T: K-block kb holds d = 16 kb + 8 hf + j
   bf16x8 doh[4], dom[4], dol[4];
@@ -638,8 +668,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   float rho = 0.f;       // sum over keys of this query's d scores: 0 in exact arithmetic, ~1e-7 |dO||O| with delta = rowsum(dO . O)
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
-  const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
-  float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+  const float* LTb = LT + ((size_t)(b * H + h) * NST + q0) * J;          // this wave's [J][32] blocks (layout: forward kernel)
+  float* dLTb = dLT + ((size_t)(b * H + h) * NST + q0) * J;
 
   // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
   const int skey = tid >> 4, sd4 = (tid & 15) * 4;
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = min(j0 + acc_row(r, hf), J - 1);     // clamped: always in bounds, masked at use
-      l[r] = LTb[(size_t)key * NST + qcol];
+      l[r] = LTb[(size_t)key * 32 + c];
     }
   };
   fetch(0, kreg, vreg, lt);
@@ -708,9 +738,9 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       if (key < nk && qvalid) {
         const float p = prob_of(ltc[r], nl);
         float dpr = dp[r];
-        if (dc.thresh) dpr *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qi) * J) + j0 + key);
+        if (dc.thresh) dpr *= stashed_factor(ltc[r], dc.keep_scale);          // the forward's decision rides in the score's lowest bit
         v = p * (dpr - delta);
-        dLTb[(size_t)(j0 + key) * NST + q0 + c] = v;
+        dLTb[(size_t)(j0 + key) * 32 + c] = v;
       }
       ds[r] = v;
       rho += v;
@@ -784,8 +814,8 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
   const int nk = min(KT, J - j0);                       // <= 0: this wave has no keys (it still stages tiles)
   const bool kvalid = c < nk;
   const int key = min(j0 + c, J - 1);
-  const float* LTk = LT + ((size_t)(b * H + h) * J + key) * NST;
-  const float* dLTk = dLT + ((size_t)(b * H + h) * J + key) * NST;
+  const float* LTk = LT + (size_t)(b * H + h) * NST * J + (size_t)key * 32;      // + query tile * J * 32 + query within the tile
+  const float* dLTk = dLT + (size_t)(b * H + h) * NST * J + (size_t)key * 32;
   const float* LSEb = LSE + (size_t)(b * H + h) * N;
 
   const int nqt = (N + QT - 1) / QT;
@@ -809,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const int qq = q0 + 8 * rg + 4 * hf;                // 4 consecutive queries; score rows are padded to NST
+      const size_t qq = (size_t)q0 * J + 8 * rg + 4 * hf;   // tile q0 / 32 -> (q0 / 32) J 32 floats; 4 consecutive queries of the tile
       ltr[rg] = *reinterpret_cast<const float4*>(LTk + qq);
       dlr[rg] = *reinterpret_cast<const float4*>(dLTk + qq);
     }
@@ -852,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
         const int qq = q0 + acc_row(r, hf);
         const bool ok = kvalid && qq < N;
         float pv = ok ? prob_of(lv[r], ls[r]) : 0.f;
-        if (dc.thresh && ok) pv *= drop_factor(dc, (((unsigned long long)(b * H + h) * N + qq) * J) + key);
+        if (dc.thresh && ok) pv *= stashed_factor(lv[r], dc.keep_scale);
         p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
         ds[r] = ok ? dsv[r] : 0.f;
       }
@@ -1048,24 +1078,22 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
   float2v s2 = {0.f, 0.f};             // sum mask . d bias of out = c (db2; dW3 follows from it and e at the end)
 
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
-  const float* dLTb = dLT + ((size_t)(b * H + h) * J) * NST;
+  const float* dLTb = dLT + ((size_t)(b * H + h) * NST + q0) * J;        // this wave's [J][32] block (layout: forward kernel)
   __syncthreads();
-  const int qcol = qvalid ? (q0 + c) : 0;               // lanes past the bag end read column 0 (always in bounds) and are zeroed;
-                                                       // q0 itself can lie beyond the padded row (waves of the last workgroup)
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
-  float db_n = dLTb[qcol];
+  float db_n = dLTb[c];                                 // lanes past the bag end read padding of their own tile and are zeroed
 #if SMML_DELTA_FIX
   // The d scores of a fused softmax backward use delta = rowsum(dO . O), which leaves sum_k dS_k = rho != 0 at the 1e-7
   // level per query (in exact arithmetic delta = sum_k P_k dP_k and the row sums vanish).  The sums below multiply d bias
   // by near-constant factors, which amplifies exactly that component, so the row is re-centred here: d bias_k - P_k rho.
-  const float* LTb = LT + ((size_t)(b * H + h) * J) * NST;
+  const float* LTb = LT + ((size_t)(b * H + h) * NST + q0) * J;
   const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
   const float nrho = -RHO[(size_t)(b * H + h) * N + qi];
-  float lt_n = LTb[qcol];
+  float lt_n = LTb[c];
 #endif
-  const unsigned short* MKb = MK + ((size_t)(b * H + h) * J * 2 + hf) * NST;
-  unsigned m16_n = MKb[qcol];
+  const unsigned short* MKb = MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
+  unsigned m16_n = MKb[c];
 
   for (int j = 0; j < J; ++j) {
 #if SMML_DELTA_FIX
@@ -1078,10 +1106,10 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       const int jn = min(j + 1, J - 1);                     // branch-free prefetch of the next key's operands
       vx_n = VSb[(size_t)jn * PD];
       if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
-      db_n = dLTb[(size_t)jn * NST + qcol];
-      m16_n = MKb[(size_t)jn * 2 * NST + qcol];
+      db_n = dLTb[(size_t)jn * 32 + c];
+      m16_n = MKb[(size_t)jn * 64 + c];
 #if SMML_DELTA_FIX
-      lt_n = LTb[(size_t)jn * NST + qcol];
+      lt_n = LTb[(size_t)jn * 32 + c];
 #endif
     }
     float* xb = xq + (j & 1) * 32;

@@ -62,6 +62,13 @@ TIMER = KernelTimer()
 DECISION_TAP = None
 
 
+def relu_masks_rows(masks):
+    """The saved layer-2 ReLU masks [B, H, nst / 32, J, 2, 32] (per-tile storage of the kernels) as [B, H, J, 2, nst] rows - the layout
+    smml_deform_attn_relu1_masks writes and the tests decode.  Tests only."""
+    B, H, NT, J, _, _ = masks.shape
+    return masks.permute(0, 1, 3, 4, 2, 5).reshape(B, H, J, 2, NT * 32)
+
+
 def relu1_masks(vs, gq, w1, b1, *, B: int, N: int, J: int, groups: int):
     """Layer-1 ReLU decisions of the position-bias MLP as the kernels evaluate them: int16 [(B G), J, 2, nst] in the bit order of the
     saved layer-2 masks (include/smml.h smml_deform_attn_relu1_masks).  Tests only."""
@@ -429,8 +436,9 @@ class _DeformAttn(torch.autograd.Function):
         logits = masks = None
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
-            logits = torch.empty(B, heads, J, nst, device=q.device, dtype=torch.float32)
-            masks = torch.empty(B, heads, J, 2, nst, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
+            # score-shaped tensors are stored per 32-query tile (include/smml.h): [B, H, nst / 32, J, 32] (+ the lane-half axis of the masks)
+            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32)
+            masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
         _set_seed_offset(L, seed_offset)
         capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                               capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),

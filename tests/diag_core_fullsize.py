@@ -25,7 +25,7 @@ smml.functional.DECISION_TAP = None
 (out * wo.to(cuda)).sum().backward()
 a = tapped[0]
 m1b = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G)
-m2b = a["masks2"][:, ::H // G].reshape(B * G, J, 2, -1)
+m2b = Fh.relu_masks_rows(a["masks2"])[:, ::H // G].reshape(B * G, J, 2, -1)
 refs = {}
 CH = 1000
 for dt in (torch.float32, torch.float64):

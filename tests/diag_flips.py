@@ -22,8 +22,8 @@ d = {n: x.to(cuda).contiguous() for n, x in t.items()}
 L = capi.lib()
 nst = L.smml_deform_attn_nst(N)
 out = torch.empty(B, N, 512, device=cuda); lse = torch.empty(B, H, N, device=cuda)
-logits = torch.empty(B, H, J, nst, device=cuda)
-masks = torch.zeros(B, H, J, 2, nst, device=cuda, dtype=torch.int16)
+logits = torch.empty(B, H, nst // 32, J, 32, device=cuda)
+masks = torch.zeros(B, H, nst // 32, J, 2, 32, device=cuda, dtype=torch.int16)
 capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
                                       capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
                                       0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")

@@ -183,7 +183,7 @@ class Decisions:
         self.N = N
         self.m1 = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G).cpu()          # int16 [(B G), J, 2, nst]
         o = H // G                                                    # the heads of a group share layers 1 and 2: take the first
-        self.m2 = a["masks2"][:, ::o].reshape(B * G, J, 2, -1).cpu()                                        # int16 [(B G), J, 2, nst]
+        self.m2 = Fh.relu_masks_rows(a["masks2"])[:, ::o].reshape(B * G, J, 2, -1).cpu()                    # int16 [(B G), J, 2, nst]
 
     @staticmethod
     def decode(bits, i0, i1, device="cpu"):

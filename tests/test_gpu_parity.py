@@ -546,7 +546,7 @@ def test_fused_core_random_shapes(cuda):
         # the ReLU decisions the kernels took (layer 1 exported, layer 2 as saved for the backward), imposed on both torch evaluations
         a = tapped[0]
         m1 = helpers.Decisions.decode(Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=groups), 0, N, cuda)
-        m2 = helpers.Decisions.decode(a["masks2"][:, ::heads // groups].reshape(B * groups, J, 2, -1), 0, N, cuda)
+        m2 = helpers.Decisions.decode(Fh.relu_masks_rows(a["masks2"])[:, ::heads // groups].reshape(B * groups, J, 2, -1), 0, N, cuda)
         refs = {}
         for dt in (torch.float32, torch.float64):
             r = {n: x.to(cuda, dt).requires_grad_() for n, x in t.items()}
@@ -617,8 +617,8 @@ def test_saved_relu_masks_match_reference(cuda):
     assert nst % 128 == 0 and nst >= N
     out = torch.empty(B, N, 512, device=cuda)
     lse = torch.empty(B, H, N, device=cuda)
-    logits = torch.empty(B, H, J, nst, device=cuda)
-    masks = torch.zeros(B, H, J, 2, nst, device=cuda, dtype=torch.int16)
+    logits = torch.empty(B, H, nst // 32, J, 32, device=cuda)                                   # per-tile storage (include/smml.h)
+    masks = torch.zeros(B, H, nst // 32, J, 2, 32, device=cuda, dtype=torch.int16)
     capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
                                           capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
                                           0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")
@@ -627,7 +627,7 @@ def test_saved_relu_masks_match_reference(cuda):
     pos = r["gq"][None, :, None, :] - r["vs"].view(B * G, 1, J, PD)
     x2 = torch.relu((torch.sign(pos) * torch.log(pos.abs() + 1)) @ r["w1"].T + r["b1"]) @ r["w2"].T + r["b2"]   # [(B G), N, J, 32]
     x2 = x2.view(B, G, N, J, 32)
-    bits = masks.to(torch.int32) & 0xFFFF                                                   # [B, H, J, 2, nst]
+    bits = Fh.relu_masks_rows(masks).to(torch.int32) & 0xFFFF                                # [B, H, J, 2, nst]
     o = H // G
     checked = wrong = 0
     for half in range(2):
@@ -660,8 +660,8 @@ def test_saved_relu_masks_statistics_at_scale(cuda):
     nst = L.smml_deform_attn_nst(N)
     out = torch.empty(B, N, 512, device=cuda)
     lse = torch.empty(B, H, N, device=cuda)
-    logits = torch.empty(B, H, J, nst, device=cuda)
-    masks = torch.zeros(B, H, J, 2, nst, device=cuda, dtype=torch.int16)
+    logits = torch.empty(B, H, nst // 32, J, 32, device=cuda)                                   # per-tile storage (include/smml.h)
+    masks = torch.zeros(B, H, nst // 32, J, 2, 32, device=cuda, dtype=torch.int16)
     capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
                                           capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
                                           0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")
@@ -673,7 +673,7 @@ def test_saved_relu_masks_statistics_at_scale(cuda):
         return (torch.relu((torch.sign(pos) * torch.log(pos.abs() + 1)) @ r["w1"].T + r["b1"]) @ r["w2"].T + r["b2"]).view(B, G, N, J, 32)
     x64 = pre(torch.float64)
     n32 = int(((pre(torch.float32) > 0) != (x64 > 0)).sum())
-    bits = masks.to(torch.int32) & 0xFFFF
+    bits = Fh.relu_masks_rows(masks).to(torch.int32) & 0xFFFF
     flipped = []
     for half in range(2):
         for reg in range(16):
