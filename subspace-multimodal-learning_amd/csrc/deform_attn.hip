@@ -66,7 +66,11 @@
                               // (dW3) and the single-key case (dS = 0 exactly) do not pass the parity gate with, profiles/r02_split_terms.txt)
 #endif
 #ifndef SMML_DKV_TERMS
-#define SMML_DKV_TERMS SMML_BWD_TERMS   // the same for the dkv pass (dK, dV only: nothing downstream recomputes from them)
+#define SMML_DKV_TERMS 2      // the dkv pass: hi + mid bf16 terms (16 operand bits, three products).  dK and dV are plain sums of products -
+                              // nothing downstream recomputes from them, unlike the d scores of the dq pass - and land 6e-6 from fp64
+                              // (l2; fp32 operands: 5e-7), inside the 1e-4 gate of every parity test; once the dropout hashes were out
+                              // of the pass (r03) the third term's 24 MFMAs per tile were its longest pole: -0.33 ms per 8-bag step, A/B
+                              // on one box.  3 = fp32-grade operands.
 #endif
 #ifndef SMML_FWD_QK16
 #define SMML_FWD_QK16 1       // forward QK^T / PV on the 16-bit matrix pipe: every operand as fp16 hi + lo (RNE, 22 bits), three of the
@@ -731,19 +735,32 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     }
 
     float ds[16];
+    if (nk == KT && q0 + QT <= N) {                        // interior tile (uniform): no bounds branches around the stores
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = acc_row(r, hf);
-      float v = 0.f;
-      if (key < nk && qvalid) {
+      for (int r = 0; r < 16; ++r) {
         const float p = prob_of(ltc[r], nl);
         float dpr = dp[r];
         if (dc.thresh) dpr *= stashed_factor(ltc[r], dc.keep_scale);          // the forward's decision rides in the score's lowest bit
-        v = p * (dpr - delta);
-        dLTb[(size_t)(j0 + key) * 32 + c] = v;
+        const float v = p * (dpr - delta);
+        dLTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = v;
+        ds[r] = v;
+        rho += v;
       }
-      ds[r] = v;
-      rho += v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = acc_row(r, hf);
+        float v = 0.f;
+        if (key < nk && qvalid) {
+          const float p = prob_of(ltc[r], nl);
+          float dpr = dp[r];
+          if (dc.thresh) dpr *= stashed_factor(ltc[r], dc.keep_scale);
+          v = p * (dpr - delta);
+          dLTb[(size_t)(j0 + key) * 32 + c] = v;
+        }
+        ds[r] = v;
+        rho += v;
+      }
     }
     // dQ^T[d, query] += K^T . dS^T: accumulator register 8 kb + j of dS^T is element j of K-block kb (keys 16 kb + 4 hf + 0..3
     // and 16 kb + 8 + 4 hf + 0..3), the K^T fragment is gathered for the same keys by two transposed reads
@@ -877,14 +894,23 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     if (nk > 0) {                                          // wave-uniform
       // P[query, key] and dS[query, key] with the query on the accumulator-row axis
       float p[16], ds[16];
+      if (nk == KT && q0 + QT <= N) {                      // interior tile (uniform): no bounds selects
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qq = q0 + acc_row(r, hf);
-        const bool ok = kvalid && qq < N;
-        float pv = ok ? prob_of(lv[r], ls[r]) : 0.f;
-        if (dc.thresh && ok) pv *= stashed_factor(lv[r], dc.keep_scale);
-        p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
-        ds[r] = ok ? dsv[r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          float pv = prob_of(lv[r], ls[r]);
+          if (dc.thresh) pv *= stashed_factor(lv[r], dc.keep_scale);
+          p[r] = pv; ds[r] = dsv[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = q0 + acc_row(r, hf);
+          const bool ok = kvalid && qq < N;
+          float pv = ok ? prob_of(lv[r], ls[r]) : 0.f;
+          if (dc.thresh && ok) pv *= stashed_factor(lv[r], dc.keep_scale);
+          p[r] = pv;                                       // dV takes the dropped probabilities, dK the dS written by pass 1
+          ds[r] = ok ? dsv[r] : 0.f;
+        }
       }
       // dV^T[d, key] += dO^T . P ;  dK^T[d, key] += Q^T . dS.  Register 8 kb + j of p / ds is element j of K-block kb (queries
       // 16 kb + 4 hf + 0..3 and 16 kb + 8 + 4 hf + 0..3); the A fragments are gathered for the same queries
