@@ -65,6 +65,10 @@
                               // three products: measurement switch - d scores then carry 2^-17 errors, which the position-bias gradients
                               // (dW3) and the single-key case (dS = 0 exactly) do not pass the parity gate with, profiles/r02_split_terms.txt)
 #endif
+#ifndef SMML_DQ_OUT_TERMS
+#define SMML_DQ_OUT_TERMS 2   // the dQ = dS K product of the dq pass (a plain output, like dK / dV): two terms; the d scores themselves
+                              // (dP = V dO^T, SMML_BWD_TERMS) keep three
+#endif
 #ifndef SMML_DKV_TERMS
 #define SMML_DKV_TERMS 2      // the dkv pass: hi + mid bf16 terms (16 operand bits, three products).  dK and dV are plain sums of products -
                               // nothing downstream recomputes from them, unlike the d scores of the dq pass - and land 6e-6 from fp64
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       split4_bf3(kreg[i], hh, mm, ll);
       *reinterpret_cast<uint2v*>(&Kp[buf][0][key * KBLD + sd4]) = hh;
       *reinterpret_cast<uint2v*>(&Kp[buf][1][key * KBLD + sd4]) = mm;
-      if (SMML_BWD_TERMS == 3) *reinterpret_cast<uint2v*>(&Kp[buf][2][key * KBLD + sd4]) = ll;
+      if (SMML_DQ_OUT_TERMS == 3) *reinterpret_cast<uint2v*>(&Kp[buf][2][key * KBLD + sd4]) = ll;
     }
     __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2, which every wave left before this barrier's
                             // predecessor: one barrier per tile is enough
@@ -776,9 +780,9 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       for (int db = 0; db < 2; ++db) {
         const bf16x8 kh = lds_frag_tr(&Kp[buf][0][ro + 32 * db], &Kp[buf][0][ro + 32 * db + 8 * KBLD]);
         const bf16x8 km = lds_frag_tr(&Kp[buf][1][ro + 32 * db], &Kp[buf][1][ro + 32 * db + 8 * KBLD]);
-        const bf16x8 kl = lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]);
-        if (db == 0) dq0 = bwd_prod<SMML_BWD_TERMS>(kh, km, kl, sh, sm, sl, dq0);
-        else dq1 = bwd_prod<SMML_BWD_TERMS>(kh, km, kl, sh, sm, sl, dq1);
+        const bf16x8 kl = (SMML_DQ_OUT_TERMS == 3) ? lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]) : km;
+        if (db == 0) dq0 = bwd_prod<SMML_DQ_OUT_TERMS>(kh, km, kl, sh, sm, sl, dq0);
+        else dq1 = bwd_prod<SMML_DQ_OUT_TERMS>(kh, km, kl, sh, sm, sl, dq1);
       }
     }
   }
@@ -928,10 +932,10 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
           const int o = ro + 32 * db;
           const bf16x8 ah = lds_frag_tr(&dOp[buf][0][o], &dOp[buf][0][o + 8 * QBLD]);
           const bf16x8 am = lds_frag_tr(&dOp[buf][1][o], &dOp[buf][1][o + 8 * QBLD]);
-          const bf16x8 al = lds_frag_tr(&dOp[buf][2][o], &dOp[buf][2][o + 8 * QBLD]);
+          const bf16x8 al = (SMML_DKV_TERMS == 3) ? lds_frag_tr(&dOp[buf][2][o], &dOp[buf][2][o + 8 * QBLD]) : am;
           const bf16x8 qh = lds_frag_tr(&Qp[buf][0][o], &Qp[buf][0][o + 8 * QBLD]);
           const bf16x8 qm = lds_frag_tr(&Qp[buf][1][o], &Qp[buf][1][o + 8 * QBLD]);
-          const bf16x8 ql = lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]);
+          const bf16x8 ql = (SMML_DKV_TERMS == 3) ? lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]) : qm;
           if (db == 0) { dv0 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv0); dk0 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk0); }
           else { dv1 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv1); dk1 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk1); }
         }
