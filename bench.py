@@ -36,7 +36,7 @@ CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (
 CPB_FWD_MFMAS = 7                   # deform_attn_fwd_kernel: 1 (layer 1) + 6 (layer 2, three-term split) 16-bit MFMAs per (key, 32 queries)
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
-TRAFFIC_FILE = "r02_hbm_traffic.json"
+TRAFFIC_FILE = "r03_hbm_traffic.json"
 
 
 def measured_traffic(kernel, bags):

@@ -33,6 +33,8 @@ def counters(path):
             k = short(r["Kernel_Name"])
             if k:
                 out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    out[k]["_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return out
 
 
@@ -61,13 +63,16 @@ if f1 and f2:
     c1, c2 = counters(f1), counters(f2)
     lines = [f"# PMC notes ({tag}): `python bench.py --steps 3 --warmup 1`, B = {bags} bags of 10 000 x 512, means per dispatch", "",
              "SQ_* cycle counters are in quad-cycles summed over waves (MI355X_MICROARCH.md); instruction counters are wave-instructions.", "",
-             "| kernel | VALU insts | MFMA insts | VALU / MFMA | LDS insts | LDS bank-conflict / LDS active | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY (shares of WAVE_CYCLES) | MFMA busy cycles |",
-             "|---|---|---|---|---|---|---|---|---|---|"]
+             "| kernel | VALU insts | MFMA insts | VALU / MFMA | LDS insts | LDS bank-conflict / LDS active | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY (shares of WAVE_CYCLES) | MFMA busy cycles | MFMA busy / SIMD cycles | co-exec / MFMA busy | clock GHz |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for k in ("cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel"):
         a, b = c1[k], c2[k]
         wc = mean(a["SQ_WAVE_CYCLES"])
         valu, mf = mean(a["SQ_INSTS_VALU"]), mean(b["SQ_INSTS_MFMA"])
         lines.append(f"| {k} | {valu:.3e} | {mf:.3e} | {valu / mf:.1f} | {mean(b['SQ_INSTS_LDS']):.3e} | {mean(b['SQ_LDS_BANK_CONFLICT']) / max(mean(b['SQ_LDS_IDX_ACTIVE']), 1):.3f} | "
-                     f"{mean(a['SQ_WAIT_ANY']) / wc:.2f} | {mean(a['SQ_WAIT_INST_ANY']) / wc:.2f} | {mean(a['SQ_ACTIVE_INST_ANY']) / wc:.2f} | {mean(a['SQ_VALU_MFMA_BUSY_CYCLES']):.3e} |")
+                     f"{mean(a['SQ_WAIT_ANY']) / wc:.2f} | {mean(a['SQ_WAIT_INST_ANY']) / wc:.2f} | {mean(a['SQ_ACTIVE_INST_ANY']) / wc:.2f} | {mean(a['SQ_VALU_MFMA_BUSY_CYCLES']):.3e} | "
+                     f"{mean(a['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024 / (mean(a['GRBM_GUI_ACTIVE']) / 8):.3f} | "
+                     f"{(mean(a['SQ_VALU_MFMA_COEXEC_CYCLES']) / mean(a['SQ_VALU_MFMA_BUSY_CYCLES'])) if a['SQ_VALU_MFMA_COEXEC_CYCLES'] else float('nan'):.3f} | "
+                     f"{mean(a['GRBM_GUI_ACTIVE']) / 8 / (mean(a['_ns']) if a['_ns'] else float('nan')):.2f} |")
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc_notes.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
