@@ -173,7 +173,6 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
     the launch stream, algorithmic flops per SURVEY.md 8(d)."""
     torch.manual_seed(7)
     mod = pkg.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256).to(dev).eval()
-    pkg.functional.NYSTROM_PIPE = "f32"
     x = (torch.randn(B, n, 512, device=dev) * 0.5).to(dtype).requires_grad_()
 
     def step():
@@ -190,7 +189,7 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
     ms = e0.elapsed_time(e1) / steps
     total, qkav = nystrom_flop(n)
     tf = 3 * total * B / (ms * 1e-3) / 1e12
-    pipe = getattr(pkg.functional, "NYSTROM_PIPE", "f32")            # which matrix pipe the contractions issue on
+    pipe = mod.matrix_pipe(dtype)                                    # which matrix pipe the contractions issue on
     peak = F16_MFMA_PEAK_TFLOPS if pipe != "f32" else F32_MFMA_PEAK_TFLOPS
     return {"workload": f"NystromAttention fwd+bwd, {B} x {n} x 512 {str(dtype).replace('torch.', '')}, 256 landmarks", "ms_per_step": ms, "bags_per_s": B / (ms * 1e-3),
             "algorithmic_TFLOPs": tf, "pipe": pipe, "peak_TFLOPs": peak, "frac": tf / peak,

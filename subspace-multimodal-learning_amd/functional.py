@@ -776,9 +776,6 @@ def attention16(q, k, v, *, scale: float, fp16: bool = False, merged: bool = Fal
     return _Attention16.apply(q, k, v, residual, scale, fp16, merged)
 
 
-NYSTROM_PIPE = "f32"          # set by the Nystrom block's 16-bit compute mode (bench.py reads it to pick the roofline peak)
-
-
 class _SoftmaxRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

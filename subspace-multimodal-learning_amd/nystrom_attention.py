@@ -156,14 +156,23 @@ class NystromAttention(nn.Module):
             padding = residual_conv_kernel // 2
             self.res_conv = nn.Conv2d(heads, heads, (kernel_size, 1), padding=(padding, 0), groups=heads, bias=False)
 
+    def matrix_pipe(self, dtype, return_attn=False) -> str:
+        """Which matrix pipe forward() issues its contractions on for a bag of `dtype`: "f32" (exact path), "bf16" or "f16" (the
+        16-bit compute mode: head dim 64, no attention matrix requested).  A pure function of the module's configuration - callers
+        that price a measurement (bench.py) ask here rather than reading state a forward left behind."""
+        mode = self.compute_dtype or {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(dtype, "fp32")
+        if mode == "fp32" or self.dim_head != 64 or return_attn:
+            return "f32"
+        return "f16" if mode == "fp16" else "bf16"
+
     def forward(self, x, mask=None, return_attn=False):
         if mask is not None:
             raise NotImplementedError("the mask argument is not built on the HIP path (no caller in the reference uses it)")
         b, n, dim = x.shape
         h, m, d = self.heads, self.num_landmarks, self.dim_head
-        mode = self.compute_dtype or {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(x.dtype, "fp32")
-        if mode != "fp32" and d == 64 and not return_attn:
-            return self._forward16(x, mode == "fp16")
+        pipe = self.matrix_pipe(x.dtype, return_attn)
+        if pipe != "f32":
+            return self._forward16(x, pipe == "f16")
         pad = (m - n % m) % m
         if pad:
             x = F.pad(x, (0, 0, pad, 0), value=0)              # zero rows in FRONT (:82)
@@ -198,7 +207,6 @@ class NystromAttention(nn.Module):
         """16-bit compute mode (module docstring): same op order as forward() up to the re-association of the output product."""
         b, n, dim = x.shape
         h, m, d = self.heads, self.num_landmarks, self.dim_head
-        Fh.NYSTROM_PIPE = "f16" if fp16 else "bf16"
         pad = (m - n % m) % m
         x = x.float()
         if pad:

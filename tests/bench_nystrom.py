@@ -38,4 +38,4 @@ for _ in range(a.steps): run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 fl = 3 * nystrom_fwd_flop(a.n) * a.bags
 print(json.dumps({"workload": f"NystromAttention fwd+bwd, {a.bags} x {a.n} x 512 {a.dtype}, 256 landmarks", "ms_per_step": dt * 1e3,
-                  "bags_per_s": a.bags / dt, "algorithmic_TFLOPs": fl / dt / 1e12, "pipe": smml.functional.NYSTROM_PIPE, "graph": bool(a.graph)}))
+                  "bags_per_s": a.bags / dt, "algorithmic_TFLOPs": fl / dt / 1e12, "pipe": mod.matrix_pipe(x.dtype), "graph": bool(a.graph)}))

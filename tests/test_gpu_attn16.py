@@ -118,7 +118,7 @@ def test_nystrom_16bit_mode_vs_oracle(cuda, mode, B, n):
     out = mod(xd)
     (out * wo.to(cuda)).sum().backward()
     tol = TOL[mode == "fp16"]
-    assert Fh.NYSTROM_PIPE == ("f16" if mode == "fp16" else "bf16")
+    assert mod.matrix_pipe(xd.dtype) == ("f16" if mode == "fp16" else "bf16")
     assert_close(tag + " out", out, o64, tol)
     assert_close(tag + " dx", xd.grad, xr.grad, tol)
     for k, p in mod.named_parameters():
@@ -136,7 +136,7 @@ def test_nystrom_16bit_mode_follows_the_bag_dtype(cuda):
     with torch.no_grad():
         ref = mod(x)
         o16 = mod(x.to(torch.bfloat16))
-        assert o16.dtype == torch.float32 and Fh.NYSTROM_PIPE == "bf16"
+        assert o16.dtype == torch.float32 and mod.matrix_pipe(torch.bfloat16) == "bf16" and mod.matrix_pipe(x.dtype) == "f32"
         assert rel_err(o16, ref) < 3e-2 and not torch.equal(o16, ref)
         mod.compute_dtype = "fp32"
         assert torch.equal(mod(x.to(torch.bfloat16)), mod(x.to(torch.bfloat16).float()))
