@@ -64,6 +64,16 @@ int smml_gemm_get_mode(void);
  * workgroups per CU, e.g. the batched 256^3 products of the Nystrom pseudo-inverse), 1 never, 2 wherever it applies. */
 void smml_gemm_set_small_tile(int v);
 
+/* bf16-STORAGE GEMM (16-bit matrix pipe, fp32 accumulation): A and B are bf16 in memory, C is bf16 (out_bf16 = 1) or fp32.
+ *   trans = 0   C[M, N] = A[M, K] B[N, K]^T   (row strides lda / ldb >= K, in elements; K % 8 == 0)
+ *   trans = 1   C[M, N] = A[K, M]^T B[K, N]   (row strides lda >= M, ldb >= N; M % 8 == 0, N % 8 == 0)
+ * bias (fp32 [N] or NULL) is added once.  splitk > 1 (fp32 output only): the K range is cut into slices whose partial products are
+ * ADDED to C atomically - the caller zeroes C.  Operands 16-byte aligned, lda / ldb multiples of 8.
+ * The projections of the Nystrom block's bf16 compute mode (models/NystromAttention.py:88 to_qkv, :147 to_out) and their backward
+ * products with bf16 bags (BASELINE configs 2 / 4): activations stay bf16 end to end. */
+int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
+                  long long ldc, int trans, int out_bf16, int splitk, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.
  * Replaces nn.LayerNorm at models/DeformCrossTransMIL.py:44,71,75,90,144 and mil.py:175,187. */
@@ -187,6 +197,15 @@ int smml_softmax_bwd_f32(const float* y, const float* dy, float* dx, long long r
 int smml_tile_rows_f32(const float* src, float* dst, long long nb, int R, int C, float scale, void* stream);
 /* depthwise residual convolution along the tokens (:72,144-145): v [B, H, n, D], w [H, KW] ->
  * out_merged [B, n, H*D] (heads merged, the layout the output projection consumes). */
+/* Newton-Schulz pseudo-inverse iteration (models/NystromAttention.py:28-33; dup cmta_utils.py:152-157), `iters` times, on NB problems of
+ * m x m (row-major, contiguous): z <- 1/4 z (13 I - x z (15 I - x z (7 I - x z))).  One host call issues the whole chain of batched
+ * products (4 per iteration forward, 8 + one update backward) on `stream`.
+ * fwd: saved [iters][4][NB, m, m] receives (z_k, x z, a, b) of every iteration for the backward (slot [0][0] stays unwritten: z_0 is z0);
+ *      z_out [NB, m, m] = the result.   bwd: dx, dz0 [NB, m, m] overwritten; scratch = 7 x NB x m x m floats. */
+int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, void* stream);
+int smml_newton_schulz_bwd(const float* x, const float* z0, const float* saved, const float* dz_in, float* dx, float* dz0,
+                           float* scratch, int NB, int m, int iters, void* stream);
+
 int smml_resconv_fwd_f32(const float* v, const float* w, float* out_merged, int B, int H, int n, int D, int KW,
                          void* stream);
 /* dv [B, H, n, D] overwritten, dw [H, KW] accumulated into */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "smml_gemm_set_mode": (None, [_i]),
     "smml_gemm_get_mode": (_i, []),
     "smml_gemm_set_small_tile": (None, [_i]),
+    "smml_gemm_b16": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _i, _i, _i, _f]),
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
     "smml_attn16_set_fewkeys": (None, [_i]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "smml_softmax_fwd_f32": (_i, [_f, _f, _ll, _i, _f]),
     "smml_softmax_bwd_f32": (_i, [_f, _f, _f, _ll, _i, _f]),
     "smml_tile_rows_f32": (_i, [_f, _f, _ll, _i, _i, _fl, _f]),
+    "smml_newton_schulz_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f]),
+    "smml_newton_schulz_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_resconv_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_resconv_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_dwconv7_fwd_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),

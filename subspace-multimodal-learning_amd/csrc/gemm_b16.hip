@@ -1,0 +1,222 @@
+// bf16-storage GEMM on the 16-bit matrix pipe of gfx950 (v_mfma_f32_32x32x16_bf16): both operands are bf16 IN MEMORY, products accumulate
+// in fp32, the result is written as bf16 or fp32.  This is the projection GEMM of the Nystrom block's bf16 compute mode
+// (models/NystromAttention.py:88 to_qkv, :147 to_out, and their backward): with bf16 bags (BASELINE configs 2 / 4) the activations never
+// exist in fp32, so the GEMM moves half the bytes of the fp32-storage kernels in gemm.hip and spends no vector instructions on
+// conversions (the single-term mode of gemm_bf3_kernel converts every operand element when its tile is staged: ~100 vector instructions
+// per 8 MFMAs, which is what held it at ~370 TFLOP/s).
+//
+//   trans = 0 ("NT")   C[M, N] = A[M, K] . B[N, K]^T      both operands k-contiguous          (y = x W^T;  dx = dy (W^T)^T with W^T materialised)
+//   trans = 1 ("TN")   C[M, N] = A[K, M]^T . B[K, N]      both operands row-contiguous, K outer (dW = dy^T x), split-K over gridDim.z
+//
+// Tile 128 x 128 x 64, 2 x 2 waves of 64 x 64 (2 x 2 accumulators of 32 x 32), global loads of 16 bytes staged through registers one
+// K-tile ahead (written to LDS after the barrier that ends the previous tile's reads), LDS images as in gemm.hip:
+//   k-contiguous operand   [row][64 k + 8]    144-byte rows: a lane's 8 k-values of an MFMA are one conflict-free ds_read_b128
+//   row-contiguous operand [k][128 rows + 32] 320-byte rows as they come from memory; fragments by ds_read_b64_tr_b16
+// Workgroup ids are remapped so that each XCD walks a contiguous range of tiles (column tiles fastest): the column tiles of one row panel
+// share the panel through one L2 instead of eight.
+#include "smml_common.h"
+
+namespace {
+
+constexpr int GM = 128, GN = 128, GK = 64;
+constexpr int KC_LD = GK + 8;          // halves per row, k-contiguous image
+constexpr int RC_LD = GM + 32;         // halves per k-row, row-contiguous image (GM == GN)
+constexpr int KC_PLANE = GM * KC_LD;   // 9216 halves = 18 KB
+constexpr int RC_PLANE = GK * RC_LD;   // 10240 halves = 20 KB
+
+struct B16Args {
+  const __bf16* A; const __bf16* B; void* C; const float* bias;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int splitk, tiles_m, tiles_n;
+};
+
+#ifndef SMML_B16_MINBLOCKS
+#define SMML_B16_MINBLOCKS 2
+#endif
+template <bool TN, bool OUT_BF16>
+__global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Args g) {
+  constexpr int PLANE = TN ? RC_PLANE : KC_PLANE;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * PLANE];
+  __bf16* As = smem;
+  __bf16* Bs = smem + PLANE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: hardware hands consecutive workgroup ids to the 8 XCDs in turn; id -> (xcd, position) -> a contiguous tile range
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r = ntiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * GM, n0 = tn * GN;
+  const int ks = blockIdx.y;
+  const int ktiles = (g.K + GK - 1) / GK;
+  const int tps = (ktiles + g.splitk - 1) / g.splitk;
+  const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
+
+  uint4v ra[4], rb[4];
+  const uint4v zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * GK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      if (!TN) {
+        const int row = idx >> 3, kc = (idx & 7) * 8;          // 8 lanes cover one 128-byte row segment
+        const long long am = min(m0 + row, g.M - 1), bn = min(n0 + row, g.N - 1);
+        const bool ok = (k0 + kc) < g.K;                         // K is a multiple of 8: a chunk is whole or absent
+        const int kk = ok ? (k0 + kc) : 0;
+        const uint4v a = *reinterpret_cast<const uint4v*>(g.A + am * g.lda + kk);
+        const uint4v b = *reinterpret_cast<const uint4v*>(g.B + bn * g.ldb + kk);
+        ra[i] = ok ? a : zero4;
+        rb[i] = ok ? b : zero4;
+      } else {
+        const int k = idx >> 4, rc = (idx & 15) * 8;             // 16 lanes cover one 256-byte k-row
+        const bool kok = (k0 + k) < g.K;
+        const long long kk = kok ? (k0 + k) : 0;
+        const bool aok = kok && (m0 + rc) < g.M, bok = kok && (n0 + rc) < g.N;     // M, N multiples of 8
+        const uint4v a = *reinterpret_cast<const uint4v*>(g.A + kk * g.lda + (aok ? (m0 + rc) : 0));
+        const uint4v b = *reinterpret_cast<const uint4v*>(g.B + kk * g.ldb + (bok ? (n0 + rc) : 0));
+        ra[i] = aok ? a : zero4;
+        rb[i] = bok ? b : zero4;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int off = TN ? ((idx >> 4) * RC_LD + (idx & 15) * 8) : ((idx >> 3) * KC_LD + (idx & 7) * 8);
+      *reinterpret_cast<uint4v*>(&As[off]) = ra[i];
+      *reinterpret_cast<uint4v*>(&Bs[off]) = rb[i];
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = floatx16{0};
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  if (kt0 < kt1) load_tile(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    __syncthreads();                          // the previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt1) load_tile(kt + 1);      // in flight during the MFMAs below
+#pragma unroll
+    for (int kb = 0; kb < GK / 16; ++kb) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int rbase = wm * 64 + mi * 32;
+        if (!TN) af[mi] = *reinterpret_cast<const bf16x8*>(&As[(rbase + c) * KC_LD + 16 * kb + 8 * hf]);
+        else {
+          const __bf16* p = &As[(16 * kb + 8 * hf + trq) * RC_LD + rbase + trc];
+          af[mi] = lds_frag_tr(p, p + 4 * RC_LD);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int cbase = wn * 64 + ni * 32;
+        if (!TN) bf[ni] = *reinterpret_cast<const bf16x8*>(&Bs[(cbase + c) * KC_LD + 16 * kb + 8 * hf]);
+        else {
+          const __bf16* p = &Bs[(16 * kb + 8 * hf + trq) * RC_LD + cbase + trc];
+          bf[ni] = lds_frag_tr(p, p + 4 * RC_LD);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)      // bf16 output: the transposed block (rows on lanes, 4 consecutive columns per register group)
+          acc[mi][ni] = OUT_BF16 ? mfma16b(bf[ni], af[mi], acc[mi][ni]) : mfma16b(af[mi], bf[ni], acc[mi][ni]);
+    }
+  }
+
+  if (OUT_BF16) {
+    // Epilogue through LDS: each wave packs its 64 x 64 block into its own [64][72]-half image (rows on lanes: ds_write_b64 of 4 columns),
+    // then stores whole 128-byte row segments (8 lanes x 16 bytes) - 8 store instructions per wave instead of 64 two-byte ones.
+    __syncthreads();                                   // every wave is done with the operand images
+    __bf16* img = smem + wave * (64 * KC_LD);          // 4 x 9216 bytes = the two operand planes of the NT form; TN planes are larger
+    const int nb = n0 + wn * 64, mb = m0 + wm * 64;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int col = ni * 32 + 8 * gq + 4 * hf;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && nb + col + 3 < g.N) bv = *reinterpret_cast<const float4*>(g.bias + nb + col);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const float2v lo = {acc[mi][ni][4 * gq] + bv.x, acc[mi][ni][4 * gq + 1] + bv.y};
+          const float2v hi = {acc[mi][ni][4 * gq + 2] + bv.z, acc[mi][ni][4 * gq + 3] + bv.w};
+          const uint2v pk = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
+                             __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+          *reinterpret_cast<uint2v*>(&img[(mi * 32 + c) * KC_LD + col]) = pk;
+        }
+      }
+    wave_lds_fence();
+    __bf16* Cb = reinterpret_cast<__bf16*>(g.C);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 8 * it + (lane >> 3), ch = (lane & 7) * 8;
+      const uint4v v = *reinterpret_cast<const uint4v*>(&img[row * KC_LD + ch]);
+      if (mb + row < g.M && nb + ch < g.N) *reinterpret_cast<uint4v*>(Cb + (long long)(mb + row) * g.ldc + nb + ch) = v;     // N % 8 == 0
+    }
+    return;
+  }
+
+  // epilogue: lane (c, hf) holds column n = .. + c, rows acc_row(r, hf) of each 32 x 32 block
+  const bool interior = (m0 + GM <= g.M) && (n0 + GN <= g.N);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + c;
+      const int mb = m0 + wm * 64 + mi * 32;
+      if (!interior && n >= g.N) continue;
+      const float bv = (g.bias && ks == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + acc_row(r, hf);
+        if (!interior && m >= g.M) continue;
+        const float v = acc[mi][ni][r] + bv;
+        if (g.splitk > 1) atomicAdd(&reinterpret_cast<float*>(g.C)[(long long)m * g.ldc + n], v);
+        else reinterpret_cast<float*>(g.C)[(long long)m * g.ldc + n] = v;
+      }
+    }
+}
+
+}  // namespace
+
+// C = A B^T (trans = 0: A [M, K], B [N, K], leading dimensions lda / ldb in elements) or C = A^T B (trans = 1: A [K, M], B [K, N]);
+// A, B bf16; C bf16 (out_bf16 = 1, ldc in bf16 elements) or fp32; bias (fp32 [N], may be null) is added once.  splitk > 1: fp32 output only,
+// the K range is cut into splitk slices whose partial products are ADDED to C atomically - the caller zeroes C first.
+extern "C" int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
+                             long long ldb, long long ldc, int trans, int out_bf16, int splitk, void* stream) {
+  SMML_REQUIRE(A && B && C, "smml_gemm_b16: null operand");
+  SMML_REQUIRE(M > 0 && N > 0 && K > 0, "smml_gemm_b16: non-positive size (M=%d N=%d K=%d)", M, N, K);
+  SMML_REQUIRE(splitk >= 1 && splitk <= 65535, "smml_gemm_b16: bad splitk %d", splitk);
+  SMML_REQUIRE(!(splitk > 1 && out_bf16), "smml_gemm_b16: split-K accumulates in an fp32 output");
+  auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
+  SMML_REQUIRE(al16(A) && al16(B) && (lda % 8) == 0 && (ldb % 8) == 0, "smml_gemm_b16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  if (!trans) SMML_REQUIRE((K % 8) == 0 && lda >= K && ldb >= K, "smml_gemm_b16: NT form needs K %% 8 == 0 and lda, ldb >= K (K=%d)", K);
+  else SMML_REQUIRE((M % 8) == 0 && (N % 8) == 0 && lda >= M && ldb >= N, "smml_gemm_b16: TN form needs M, N %% 8 == 0 and lda >= M, ldb >= N (M=%d N=%d)", M, N);
+  SMML_REQUIRE(ldc >= N, "smml_gemm_b16: ldc < N");
+  if (out_bf16) SMML_REQUIRE((N % 8) == 0 && (ldc % 8) == 0 && al16(C), "smml_gemm_b16: a bf16 result needs N %% 8 == 0, ldc %% 8 == 0 and a 16-byte aligned C (N=%d)", N);
+  const long long tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN;
+  SMML_REQUIRE(tm * tn < (1LL << 31), "smml_gemm_b16: grid too large");
+  B16Args g{reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(B), C, bias, M, N, K, lda, ldb, ldc, splitk, (int)tm, (int)tn};
+  dim3 grid((unsigned)(tm * tn), (unsigned)splitk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (trans) {
+    if (out_bf16) hipLaunchKernelGGL((gemm_b16_kernel<true, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_b16_kernel<true, false>), grid, block, 0, st, g);
+  } else {
+    if (out_bf16) hipLaunchKernelGGL((gemm_b16_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_b16_kernel<false, false>), grid, block, 0, st, g);
+  }
+  SMML_LAUNCH_CHECK("smml_gemm_b16");
+  return SMML_OK;
+}

@@ -226,6 +226,102 @@ def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, re
 
 
 # ------------------------------------------------------------------------------------------------
+# bf16-storage linear (csrc/gemm_b16.hip): x bf16 [.., K], W an fp32 parameter [N, K] -> y bf16 or fp32 [.., N]
+# ------------------------------------------------------------------------------------------------
+def _bptr(t: torch.Tensor):
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f"smml bf16 kernel got dtype {t.dtype}")
+    return capi.ptr(t)
+
+
+def gemm_b16(A, B, C, *, M, N, K, lda, ldb, ldc, trans=False, bias=None, splitk=1):
+    """C = A B^T (trans False: A [M, K], B [N, K]) or A^T B (trans True: A [K, M], B [K, N]); A, B bf16, C bf16 or fp32."""
+    if C.dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError(f"gemm_b16: output dtype {C.dtype}")
+    capi.check(capi.lib().smml_gemm_b16(_bptr(A), _bptr(B), capi.ptr(C), capi.fptr(bias), M, N, K, lda, ldb, ldc, int(trans),
+                                        int(C.dtype == torch.bfloat16), splitk, capi.stream()), "gemm_b16")
+
+
+def _splitk_b16(out_rows: int, out_cols: int, k: int) -> int:
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    return int(max(1, min(1024 // max(tiles, 1), (k + 511) // 512)))
+
+
+class _LinearB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_bf16):
+        if x.dtype != torch.bfloat16:
+            raise RuntimeError("linear_b16: x must be bf16 (the caller casts once)")
+        x = x if x.is_contiguous() else x.contiguous()
+        wb = weight.detach().to(torch.bfloat16)                 # the parameter stays fp32; [N, K] bf16 is 1.5 MB at most here
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = weight.shape[0]
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        gemm_b16(x, wb, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=_c(bias) if bias is not None else None)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, wb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = wb.shape[0]
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(_c(dy).reshape(1, M, N))[0]
+        dyb = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
+        dyb = dyb if dyb.is_contiguous() else dyb.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = wb.t().contiguous()                            # [K, N]: dx = dy (W^T)^T is the k-contiguous form again
+            dx = torch.empty_like(x)
+            gemm_b16(dyb, wt, dx, M=M, N=K, K=N, lda=N, ldb=N, ldc=K)
+        if ctx.needs_input_grad[1]:
+            dw = _ZEROS.zeros((N, K), x.device)
+            gemm_b16(dyb, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=_splitk_b16(N, K, M))
+        return dx, dw, db, None
+
+
+def linear_b16(x, weight, bias=None, out_bf16: bool = True):
+    """x W^T (+ bias) with bf16 operands in memory and fp32 accumulation; x bf16, weight / bias fp32 parameters (gradients fp32), the
+    result bf16 (out_bf16) or fp32; dx is bf16."""
+    return _LinearB16.apply(x, weight, bias, out_bf16)
+
+
+class _HeadMajorQKV(torch.autograd.Function):
+    """qkv [b, n, 3 h d] (bf16, token-major: what the projection writes) -> q, k, v fp32 [b, h, n, d], three slices of one buffer filled by
+    ONE strided copy; backward writes the three gradients into one bf16 token-major buffer (no stack / cat of fp32 head-major pieces)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        b, n, c = qkv.shape
+        d = c // (3 * heads)
+        ctx.shape = (b, n, heads, d)
+        buf = torch.empty(3, b, heads, n, d, device=qkv.device, dtype=torch.float32)
+        buf.copy_(qkv.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4))
+        return buf[0], buf[1], buf[2]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        b, n, h, d = ctx.shape
+        dqkv = torch.empty(b, n, 3, h, d, device=dq.device, dtype=torch.bfloat16)
+        view = dqkv.permute(2, 0, 3, 1, 4)
+        for i, g in enumerate((dq, dk, dv)):
+            if g is None:
+                view[i].zero_()
+            else:
+                view[i].copy_(g)
+        return dqkv.view(b, n, 3 * h * d), None
+
+
+def head_major_qkv(qkv, heads: int):
+    return _HeadMajorQKV.apply(qkv, heads)
+
+
+# ------------------------------------------------------------------------------------------------
 # grouped 1x1 convolution on token-major data: x [B, n, Cin], w [Cout, Cin / groups] -> [B, n, Cout]
 # ------------------------------------------------------------------------------------------------
 class _GroupedPointwise(torch.autograd.Function):

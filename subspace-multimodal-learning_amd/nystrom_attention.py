@@ -32,50 +32,46 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _capi as capi
 from . import functional as Fh
 
 
 class _NewtonSchulz(torch.autograd.Function):
     """z_{k+1} = 1/4 z_k (13 I - x z_k (15 I - x z_k (7 I - x z_k))), `iters` times, as four batched GEMMs per iteration with the
     affine parts in the GEMM epilogues (xz; a = 7 xz - xz xz; b = 15 xz - xz a; z' = 3.25 z - 0.25 z b), and a hand-written
-    backward of eight GEMMs + one elementwise add per iteration (autograd through the same products needed ~2 elementwise
-    launches per GEMM to scale and accumulate the five uses of xz):
+    backward of eight GEMMs + one elementwise update per iteration:
         dz = 3.25 dz' - 0.25 dz' b^T        db = -0.25 z^T dz'
         dxz = 15 db - db a^T                da = -xz^T db
         dxz += 7 da - da xz^T - xz^T da
-        dx += dxz z^T                       dz += x^T dxz"""
+        dx += dxz z^T                       dz += x^T dxz
+    Each direction is ONE call into the C-ABI (csrc/pinv_chain.hip), which issues the 24 / 54 launches from a C loop: issued one by
+    one from here they cost more host time (~25 us each) than GPU time (~17 us)."""
 
     @staticmethod
     def forward(ctx, x, z0, iters):
-        z = z0
-        saved = []
-        for _ in range(iters):
-            xz = Fh.matmul4(x, z)
-            a = Fh.matmul4(xz, xz, xz, alpha=-1.0, beta=7.0)
-            b = Fh.matmul4(xz, a, xz, alpha=-1.0, beta=15.0)
-            saved += [z, xz, a, b]
-            z = Fh.matmul4(z, b, z, alpha=-0.25, beta=3.25)
+        x, z0 = Fh._c(x), Fh._c(z0)
+        m = x.shape[-1]
+        nb = x.numel() // (m * m)
+        saved = torch.empty(iters, 4, *x.shape, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(x)
+        capi.check(capi.lib().smml_newton_schulz_fwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(z), nb, m, iters,
+                                                     capi.stream()), "newton_schulz_fwd")
         ctx.iters = iters
-        ctx.save_for_backward(x, *saved)
+        ctx.save_for_backward(x, z0, saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, *saved = ctx.saved_tensors
-        dz = dz.contiguous()
-        dx = None
-        for k in reversed(range(ctx.iters)):
-            z, xz, a, b = saved[4 * k:4 * k + 4]
-            dzk = Fh.matmul4(dz, b, dz, tb=True, alpha=-0.25, beta=3.25)
-            db = Fh.matmul4(z, dz, ta=True, alpha=-0.25)
-            dxz = Fh.matmul4(db, a, db, tb=True, alpha=-1.0, beta=15.0)
-            da = Fh.matmul4(xz, db, ta=True, alpha=-1.0)
-            t = Fh.matmul4(da, xz, dxz, tb=True, alpha=-1.0)
-            t = Fh.matmul4(xz, da, t, ta=True, alpha=-1.0)
-            dxz = torch.add(t, da, alpha=7.0)
-            dx = Fh.matmul4(dxz, z, dx, tb=True)
-            dz = Fh.matmul4(x, dxz, dzk, ta=True)
-        return dx, dz, None
+        x, z0, saved = ctx.saved_tensors
+        dz = Fh._c(dz)
+        m = x.shape[-1]
+        nb = x.numel() // (m * m)
+        dx, dz0 = torch.empty_like(x), torch.empty_like(x)
+        scratch = torch.empty(7, *x.shape, device=x.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_newton_schulz_bwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(dz), capi.fptr(dx),
+                                                     capi.fptr(dz0), capi.fptr(scratch), nb, m, ctx.iters, capi.stream()),
+                   "newton_schulz_bwd")
+        return dx, dz0, None
 
 
 def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
@@ -131,6 +127,9 @@ class _PinvFork:
             self.main.wait_stream(self.side)
             for t in outputs:
                 t.record_stream(self.main)
+
+
+B16_PROJECTIONS = os.environ.get("SMML_NYSTROM_B16", "1") != "0"      # measurement switch: 0 = fp32-storage projections in bf16 mode too
 
 
 class NystromAttention(nn.Module):
@@ -208,14 +207,21 @@ class NystromAttention(nn.Module):
         b, n, dim = x.shape
         h, m, d = self.heads, self.num_landmarks, self.dim_head
         pad = (m - n % m) % m
-        x = x.float()
-        if pad:
-            x = F.pad(x, (0, 0, pad, 0), value=0)
         npad = n + pad
         l = math.ceil(n / m)
-        gm = 0 if fp16 else 3                                   # projections: exact in fp16 mode, single-term bf16 in bf16 mode
-        qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
-        q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
+        b16 = not fp16 and B16_PROJECTIONS                      # bf16 mode: the projections read and write bf16 (csrc/gemm_b16.hip)
+        if b16:
+            x = x.to(torch.bfloat16)
+            if pad:
+                x = F.pad(x, (0, 0, pad, 0), value=0)
+            q, k, v = Fh.head_major_qkv(Fh.linear_b16(x, self.to_qkv.weight), h)               # each [b, h, n', d] fp32
+        else:
+            x = x.float()
+            if pad:
+                x = F.pad(x, (0, 0, pad, 0), value=0)
+            gm = 0 if fp16 else 3                               # projections: exact in fp16 mode, single-term bf16 operands otherwise
+            qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
+            q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
         sc = self.scale
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
@@ -227,7 +233,7 @@ class NystromAttention(nn.Module):
         w = Fh.matmul4(z, right)                                                               # z (attn3 v)          [b, h, m, d]
         out = Fh.attention16(q, kl, w, scale=sc, fp16=fp16, merged=True, residual=res)         # softmax(q kl^T) w + res
         wo, bo = self.to_out[0].weight, self.to_out[0].bias
-        out = Fh.linear(out, wo, bo, prec=gm)
+        out = Fh.linear_b16(out.to(torch.bfloat16), wo, bo, out_bf16=False) if b16 else Fh.linear(out, wo, bo, prec=gm)
         out = self.to_out[1](out)
         return out[:, -n:]
 

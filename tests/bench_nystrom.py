@@ -35,7 +35,8 @@ if a.graph:
 for _ in range(3): run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): run()
+t_issue = (time.perf_counter() - t0) / a.steps        # host time to enqueue a step (equals the step time when the step is host-bound)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 fl = 3 * nystrom_fwd_flop(a.n) * a.bags
 print(json.dumps({"workload": f"NystromAttention fwd+bwd, {a.bags} x {a.n} x 512 {a.dtype}, 256 landmarks", "ms_per_step": dt * 1e3,
-                  "bags_per_s": a.bags / dt, "algorithmic_TFLOPs": fl / dt / 1e12, "pipe": mod.matrix_pipe(x.dtype), "graph": bool(a.graph)}))
+                  "bags_per_s": a.bags / dt, "algorithmic_TFLOPs": fl / dt / 1e12, "pipe": mod.matrix_pipe(x.dtype), "graph": bool(a.graph), "host_issue_ms": t_issue * 1e3}))
