@@ -202,6 +202,7 @@ int smml_tile_rows_f32(const float* src, float* dst, long long nb, int R, int C,
  * products (4 per iteration forward, 8 + one update backward) on `stream`.
  * fwd: saved [iters][4][NB, m, m] receives (z_k, x z, a, b) of every iteration for the backward (slot [0][0] stays unwritten: z_0 is z0);
  *      z_out [NB, m, m] = the result.   bwd: dx, dz0 [NB, m, m] overwritten; scratch = 7 x NB x m x m floats. */
+void smml_newton_schulz_set_fast(int on);   /* 0: every product through smml_gemm_f32 (test / measurement switch); default 1: m = 256 uses the chain kernel */
 int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, void* stream);
 int smml_newton_schulz_bwd(const float* x, const float* z0, const float* saved, const float* dz_in, float* dx, float* dz0,
                            float* scratch, int NB, int m, int iters, void* stream);

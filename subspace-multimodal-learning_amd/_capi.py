@@ -56,6 +56,7 @@ SIGNATURES = {
     "smml_softmax_fwd_f32": (_i, [_f, _f, _ll, _i, _f]),
     "smml_softmax_bwd_f32": (_i, [_f, _f, _f, _ll, _i, _f]),
     "smml_tile_rows_f32": (_i, [_f, _f, _ll, _i, _i, _fl, _f]),
+    "smml_newton_schulz_set_fast": (None, [_i]),
     "smml_newton_schulz_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_newton_schulz_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_resconv_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),

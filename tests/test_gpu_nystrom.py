@@ -258,3 +258,36 @@ def test_pinv_side_stream_is_bit_identical(cuda):
             assert torch.equal(a, b), f"tensor {i} differs between overlapped and serial execution"
         else:
             assert_close(f"param grad {i} overlapped vs serial", a, b, 1e-6)
+
+
+@pytest.mark.parametrize("m,fast", [(256, 1), (256, 0), (64, 1), (48, 1)])
+def test_newton_schulz_chain_vs_fp64(cuda, m, fast):
+    """The pseudo-inverse chain (csrc/pinv_chain.hip: one C call per direction) against the same iteration in fp64 with autograd:
+    m = 256 runs the panel-prefetch chain kernel (fast = 1) or, like every other m, the generic batched GEMM (fast = 0).  z0 is an
+    independent input here: as a function of x it carries max(row sums) of a row-stochastic matrix - all ties - whose gradient goes
+    to whichever row the max picks (tests of the whole block cover that part against the golden vectors)."""
+    import importlib
+    na = importlib.import_module(smml.__name__ + ".nystrom_attention")
+    gen = torch.Generator().manual_seed(m + fast)
+    a2 = torch.softmax(torch.randn(2, 3, m, m, generator=gen) * 0.5 + 4.0 * torch.eye(m), dim=-1)
+    z0 = (a2.transpose(-1, -2) / (a2.abs().sum(-1).max() * a2.abs().sum(-2).max())).contiguous()
+    wo = torch.randn(2, 3, m, m, generator=gen)
+    xr, zr = a2.double().requires_grad_(), z0.double().requires_grad_()
+    eye = torch.eye(m, dtype=torch.float64)
+    z = zr
+    for _ in range(6):                                     # models/NystromAttention.py:28-33
+        xz = xr @ z
+        z = 0.25 * z @ (13 * eye - xz @ (15 * eye - xz @ (7 * eye - xz)))
+    (z * wo.double()).sum().backward()
+    L = smml.lib()
+    L.smml_newton_schulz_set_fast(fast)
+    try:
+        xd, zd = a2.to(cuda).requires_grad_(), z0.to(cuda).requires_grad_()
+        got = na._NewtonSchulz.apply(xd, zd, 6)
+        (got * wo.to(cuda)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        L.smml_newton_schulz_set_fast(1)
+    assert_close(f"pinv chain m={m} fast={fast} z", got, z.detach(), 1e-5)
+    assert_close(f"pinv chain m={m} fast={fast} dx", xd.grad, xr.grad, 1e-5)
+    assert_close(f"pinv chain m={m} fast={fast} dz0", zd.grad, zr.grad, 2e-4)
