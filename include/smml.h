@@ -197,6 +197,20 @@ int smml_softmax_bwd_f32(const float* y, const float* dy, float* dx, long long r
 int smml_tile_rows_f32(const float* src, float* dst, long long nb, int R, int C, float scale, void* stream);
 /* depthwise residual convolution along the tokens (:72,144-145): v [B, H, n, D], w [H, KW] ->
  * out_merged [B, n, H*D] (heads merged, the layout the output projection consumes). */
+/* bf16-STORAGE forms of the n'-sized kernels of the block's bf16 compute mode; qkv / dqkv are the token-major bf16 buffers
+ * [B, n, 3, H, D] the projection GEMM writes / its backward reads (n = m l).
+ *   segment_mean: qmean, kmean fp32 [B, H, m, D] = landmark means of q and of k (models/NystromAttention.py:102-118)
+ *   segment_mean_bwd_add: dqkv(q, k parts) += (dqmean, dkmean) broadcast / l
+ *   resconv: 33-tap depthwise convolution over tokens (:62-66,144-145); element (b, t, h, d) of in at b i_bs + t i_rs + h D + d (elements),
+ *            of out at b o_bs + t o_rs + h D + d; flip = 1 applies the reversed taps (gradient w.r.t. the input)
+ *   resconv_wgrad: dw fp32 [H, 33] += sum dout[b, t, h, d] v[b, t + k - 16, h, d] */
+int smml_segment_mean_b16(const void* qkv, float* qmean, float* kmean, int B, int n, int l, int H, int D, void* stream);
+int smml_segment_mean_bwd_add_b16(void* dqkv, const float* dqmean, const float* dkmean, int B, int n, int l, int H, int D, void* stream);
+int smml_resconv_b16(const void* in, const float* w, void* out, int B, int H, int n, int D, int KW, long long i_bs, long long i_rs,
+                     long long o_bs, long long o_rs, int flip, void* stream);
+int smml_resconv_wgrad_b16(const void* dout, const void* v, float* dw, int B, int H, int n, int D, int KW, long long g_bs, long long g_rs,
+                           long long v_bs, long long v_rs, void* stream);
+
 /* Newton-Schulz pseudo-inverse iteration (models/NystromAttention.py:28-33; dup cmta_utils.py:152-157), `iters` times, on NB problems of
  * m x m (row-major, contiguous): z <- 1/4 z (13 I - x z (15 I - x z (7 I - x z))).  One host call issues the whole chain of batched
  * products (4 per iteration forward, 8 + one update backward) on `stream`.
@@ -260,6 +274,21 @@ int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* o
  * kernel with all keys resident in LDS wherever its 256-query workgroups fill the chip, 2 = wherever Lk <= 256.  The two-pass kernel
  * halves the vector instructions per MFMA but the launch is HBM-bound with fp32 storage (csrc/attn16.hip). */
 void smml_attn16_set_fewkeys(int mode);
+/* bf16-STORAGE forms of the two attention-shaped products (bf16 compute mode with bf16 bags): the LONG side (long_side 0: keys / values -
+ * softmax(ql k^T) v; 1: queries - softmax(q kl^T) w) is bf16 in memory at element strides (s_bs, s_hs, s_rs) per (bag, head, row) - q / k / v
+ * are read in the token-major [b, n', 3, h, 64] buffer the projection wrote - the short (landmark) side is fp32 [B H, L, 64].
+ *   long_side 0: q fp32, k / v bf16, out fp32 [B H, Lq, 64]; residual must be NULL
+ *   long_side 1: q bf16, k / v fp32, out = attention + residual, both bf16 at strides (o_bs, o_hs, o_rs) (residual may be NULL)
+ * Backward: gradients of the long side are bf16 at strides (g_bs, g_hs, g_rs) (e.g. inside the gradient of the qkv buffer), those of the
+ * short side fp32.  long_side 0: dout / out fp32, dq fp32, dk written, dv written or added to (dv_accumulate);
+ * long_side 1: out / residual / dout bf16 at the o strides, dq bf16 written, dk / dv fp32.  Workspaces as for the fp32-storage entries. */
+int smml_attn16_fwd_b16(const void* q, const void* k, const void* v, void* out, const void* residual, float* lse2, void* workspace,
+                        size_t workspace_bytes, int B, int H, int Lq, int Lk, float scale, int long_side, long long s_bs, long long s_hs,
+                        long long s_rs, long long o_bs, long long o_hs, long long o_rs, void* stream);
+int smml_attn16_bwd_b16(const void* q, const void* k, const void* v, const void* out, const void* residual, const void* dout,
+                        const float* lse2, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, int B, int H, int Lq,
+                        int Lk, float scale, int long_side, long long s_bs, long long s_hs, long long s_rs, long long o_bs, long long o_hs,
+                        long long o_rs, long long g_bs, long long g_hs, long long g_rs, int dv_accumulate, void* stream);
 size_t smml_attn16_bwd_workspace_bytes(int BH, int Lq, int Lk);
 int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* residual, const float* dout,
                         const float* lse2, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, int BH, int Lq,

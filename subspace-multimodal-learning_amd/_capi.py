@@ -32,6 +32,8 @@ SIGNATURES = {
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
     "smml_attn16_set_fewkeys": (None, [_i]),
+    "smml_attn16_fwd_b16": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _ll, _ll, _ll, _ll, _ll, _ll, _f]),
+    "smml_attn16_bwd_b16": (_i, [_f] * 11 + [_sz, _i, _i, _i, _i, _fl, _i] + [_ll] * 9 + [_i, _f]),
     "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_bwd_f32": (_i, [_f] * 10 + [_f, _sz, _i, _i, _i, _i, _fl, _i, _i, _f]),
     "smml_layernorm_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _ll, _i, _fl, _f]),
@@ -56,6 +58,10 @@ SIGNATURES = {
     "smml_softmax_fwd_f32": (_i, [_f, _f, _ll, _i, _f]),
     "smml_softmax_bwd_f32": (_i, [_f, _f, _f, _ll, _i, _f]),
     "smml_tile_rows_f32": (_i, [_f, _f, _ll, _i, _i, _fl, _f]),
+    "smml_segment_mean_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_segment_mean_bwd_add_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_resconv_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _f]),
+    "smml_resconv_wgrad_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f]),
     "smml_newton_schulz_set_fast": (None, [_i]),
     "smml_newton_schulz_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_newton_schulz_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),

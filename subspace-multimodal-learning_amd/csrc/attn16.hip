@@ -8,9 +8,13 @@
 // [m, m] x [m, d] one; the [n', m] and [m, n'] probability matrices are never written to HBM - forward keeps one log-sum-exp
 // per query, backward recomputes the probabilities from it.)
 //
-// Storage stays fp32 (q, k, v, out, gradients; head-major [BH, L, 64]); operands are converted to bf16 / fp16 when a tile is
-// staged into LDS or a fragment is built in registers, products accumulate in fp32.  This is the "16-bit compute" path of the
+// Storage is fp32 (q, k, v, out, gradients; head-major [BH, L, 64]) with operands converted to bf16 / fp16 when a tile is staged
+// into LDS or a fragment is built in registers - or, for the LONG side of either product in bf16 mode, bf16 in memory at arbitrary
+// (bag, head, row) strides: the n'-sized q / k / v are then read where the projection GEMM left them (token-major [b, n', 3, h, 64])
+// and their gradients are written there, the output / its gradient are bf16 [b, n', h 64] as the output projection reads them; only
+// the 256-row landmark-side tensors stay fp32 head-major.  Products accumulate in fp32.  This is the "16-bit compute" path of the
 // block (BASELINE configs 2 / 4 / 5 name bf16 / fp16); the default fp32 path keeps the exact-fp32 GEMM composition.
+// The softmax scale is applied to the fp32 scores (one FMA with the running maximum inside the exponential's argument), not to q.
 //
 // Orientation (as in deform_attn.hip): S^T = K Q^T puts keys on accumulator rows and queries on lanes, so the softmax
 // reduction is in-lane (16 registers + one cross-half exchange) and the probabilities are the B operand of O^T = V^T P^T as
@@ -30,7 +34,6 @@ constexpr int AK = 32;        // keys per tile
 constexpr int RLD = AD + 8;   // halves per row of a row-read image (144-byte rows: conflict-free ds_read_b128 of 32 rows)
 constexpr int TLD = AD + 32;  // halves per row of a transposed-read image (192-byte rows, see deform_attn.hip)
 constexpr float LOG2E_F = 1.4426950408889634f;
-constexpr float LN2_F = 0.6931471805599453f;
 
 // layout of O / dO (floats): element (bh, query, d) at (bh / H) * bs + (bh % H) * hs + query * rs + d.  Head-major [BH, Lq, 64] is
 // {H Lq 64, Lq 64, 64}; heads merged [B, Lq, H 64] - what the block's output projection consumes - is {Lq H 64, 64, H 64}.
@@ -78,23 +81,129 @@ __device__ __forceinline__ typename Pipe<T>::x8 frag_tr(const T* p0, const T* p1
   const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
   return __builtin_bit_cast(typename Pipe<T>::x8, r);
 }
-// this lane's 8 consecutive head-dim values of k-step s (d = 16 s + 8 half + j) of one fp32 row, times `mul`, as a fragment
+// this lane's 8 consecutive head-dim values of k-step s (d = 16 s + 8 half + j) of one row as a fragment: converted from fp32
+// storage, or as they stand from 16-bit storage
 template <typename T>
-__device__ __forceinline__ typename Pipe<T>::x8 row_frag(const float* row, int s, int hf, float mul) {
+__device__ __forceinline__ typename Pipe<T>::x8 row_frag(const float* row, int s, int hf) {
   const float4 a = *reinterpret_cast<const float4*>(row + 16 * s + 8 * hf), b = *reinterpret_cast<const float4*>(row + 16 * s + 8 * hf + 4);
-  const float x[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   return pack8<T>(x);
 }
+template <typename T>
+__device__ __forceinline__ typename Pipe<T>::x8 row_frag(const T* row, int s, int hf) {
+  return *reinterpret_cast<const typename Pipe<T>::x8*>(row + 16 * s + 8 * hf);
+}
+// 8 consecutive values of a row as floats
+__device__ __forceinline__ void load8f(const float* p, float (&x)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+template <typename T>
+__device__ __forceinline__ void load8f(const T* p, float (&x)[8]) {
+  const typename Pipe<T>::x8 v = *reinterpret_cast<const typename Pipe<T>::x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (float)v[i];
+}
+// 4 consecutive values: load as floats / store from floats
+__device__ __forceinline__ float4 load4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <typename T>
+__device__ __forceinline__ float4 load4f(const T* p) {
+  typedef T x4 __attribute__((ext_vector_type(4)));
+  const x4 v = *reinterpret_cast<const x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4f(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <typename T>
+__device__ __forceinline__ void store4f(T* p, const float4 v) { *reinterpret_cast<uint2v*>(p) = pack4<T>(v); }
+
+// Store this lane's 64 values of one output row - the two transposed accumulators o0 (d < 32) and o1 (d >= 32) of O^T[d, row]: lane half hf
+// holds d = 32 blk + 8 rg + 4 hf + (0..3) in registers 4 rg .. 4 rg + 3 - as mul * o + add (add: the lane's own pieces of a residual / a running
+// sum, zero when absent).  fp32 storage: 16-byte stores, the two halves of a lane pair write adjacent pieces (32 contiguous bytes per row).
+// 16-bit storage: a piece is 8 bytes, and 16-byte fragments scattered over 32 rows would make every 32-byte sector a partial write; the two
+// halves therefore exchange pieces first (v_permlane32_swap: half 0 keeps piece rg = 2 j and receives half 1's rg = 2 j, half 1 receives
+// half 0's rg = 2 j + 1), so that each lane stores 16 contiguous bytes and a lane pair 32.
+__device__ __forceinline__ void store_row(float* rowp, const floatx16& o0, const floatx16& o1, float mul, const float4 (&ra)[4],
+                                          const float4 (&rb)[4], int hf) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int d = 8 * rg + 4 * hf;
+    *reinterpret_cast<float4*>(rowp + d) = make_float4(fmaf(o0[4 * rg], mul, ra[rg].x), fmaf(o0[4 * rg + 1], mul, ra[rg].y),
+                                                       fmaf(o0[4 * rg + 2], mul, ra[rg].z), fmaf(o0[4 * rg + 3], mul, ra[rg].w));
+    *reinterpret_cast<float4*>(rowp + 32 + d) = make_float4(fmaf(o1[4 * rg], mul, rb[rg].x), fmaf(o1[4 * rg + 1], mul, rb[rg].y),
+                                                            fmaf(o1[4 * rg + 2], mul, rb[rg].z), fmaf(o1[4 * rg + 3], mul, rb[rg].w));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_row(T* rowp, const floatx16& o0, const floatx16& o1, float mul, const float4 (&ra)[4],
+                                          const float4 (&rb)[4], int hf) {
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const floatx16& o = blk ? o1 : o0;
+    uint2v pk[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 r = blk ? rb[rg] : ra[rg];
+      pk[rg] = pack4<T>(make_float4(fmaf(o[4 * rg], mul, r.x), fmaf(o[4 * rg + 1], mul, r.y), fmaf(o[4 * rg + 2], mul, r.z), fmaf(o[4 * rg + 3], mul, r.w)));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+      const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+      *reinterpret_cast<uint4v*>(rowp + 32 * blk + 16 * j + 8 * hf) = (uint4v){w0[0], w1[0], w0[1], w1[1]};
+    }
+  }
+}
+
+// One 32-row x 64 tile of a staged operand held by 256 threads between its global load and its LDS store.
+//   fp32 storage: rows (tid >> 4) and (tid >> 4) + 16, 4 consecutive d each (two float4), converted when stored (8-byte LDS stores)
+//   16-bit storage: row tid >> 3, 8 consecutive d (one 16-byte load, one 16-byte LDS store per image)
+template <typename T, typename TS> struct TileRegs;
+template <typename T> struct TileRegs<T, float> {
+  float4 r[2];
+  __device__ __forceinline__ void load(const float* base, long long rs, int row0, int nrows, int tid) {     // rows >= nrows read as zero
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row0 + (tid >> 4) + 16 * i;
+      r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) r[i] = *reinterpret_cast<const float4*>(base + (size_t)row * rs + (tid & 15) * 4);
+    }
+  }
+  __device__ __forceinline__ void store(T* img, int ld, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint2v*>(&img[((tid >> 4) + 16 * i) * ld + (tid & 15) * 4]) = pack4<T>(r[i]);
+  }
+  __device__ __forceinline__ void store2(T* img0, int ld0, T* img1, int ld1, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint2v pk = pack4<T>(r[i]);
+      *reinterpret_cast<uint2v*>(&img0[((tid >> 4) + 16 * i) * ld0 + (tid & 15) * 4]) = pk;
+      *reinterpret_cast<uint2v*>(&img1[((tid >> 4) + 16 * i) * ld1 + (tid & 15) * 4]) = pk;
+    }
+  }
+};
+template <typename T> struct TileRegs<T, T> {
+  uint4v r;
+  __device__ __forceinline__ void load(const T* base, long long rs, int row0, int nrows, int tid) {
+    const int row = row0 + (tid >> 3);
+    r = (uint4v){0u, 0u, 0u, 0u};
+    if (row < nrows) r = *reinterpret_cast<const uint4v*>(base + (size_t)row * rs + (tid & 7) * 8);
+  }
+  __device__ __forceinline__ void store(T* img, int ld, int tid) const { *reinterpret_cast<uint4v*>(&img[(tid >> 3) * ld + (tid & 7) * 8]) = r; }
+  __device__ __forceinline__ void store2(T* img0, int ld0, T* img1, int ld1, int tid) const {
+    *reinterpret_cast<uint4v*>(&img0[(tid >> 3) * ld0 + (tid & 7) * 8]) = r;
+    *reinterpret_cast<uint4v*>(&img1[(tid >> 3) * ld1 + (tid & 7) * 8]) = r;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
-// forward: O = softmax(scale Q K^T) V, LSE2 = log2-sum-exp2 of the scaled scores per query (base 2: what the backward needs)
-//   Q [BH, Lq, 64]  K, V [BH, Lk, 64]  O [BH, Lq, 64]  LSE2 [BH, Lq]     grid (ceil(Lq / 128), BH)
+// forward: O = softmax(scale Q K^T) V (+ RES), LSE2 = log2-sum-exp2 of the scaled scores per query (base 2: what the backward needs)
+//   Q, O, RES: storage TQ at layouts ql / ol;  K, V: storage TK at layout kl;  LSE2 [BH, Lq]     grid (ceil(Lq / 128), BH, key chunks)
+//   RES may be O itself (the fp32 path accumulates into an output that already holds the residual)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                            const float* __restrict__ V, float* __restrict__ O,
-                                                            float* __restrict__ LSE2, int Lq, int Lk, float qscale, OLayout ol,
-                                                            int accumulate, int chunk, float* __restrict__ Opart,
+template <typename T, typename TQ, typename TK>
+__global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict__ Q, const TK* __restrict__ K, const TK* __restrict__ V,
+                                                            TQ* O, const TQ* RES, float* __restrict__ LSE2, int Lq, int Lk, float qscale,
+                                                            OLayout ql, OLayout kl, OLayout ol, int chunk, float* __restrict__ Opart,
                                                             float* __restrict__ Lpart) {
   typedef typename Pipe<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
@@ -107,47 +216,29 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
   // key range of this workgroup: the whole row, or one of gridDim.z chunks (few queries, many keys - the [m, n'] side of the
   // Nystrom block has only m / 32 waves per head: the chunks' partial results are merged by attn16_merge_kernel)
   const int kbeg = blockIdx.z * chunk, kend = min(Lk, kbeg + chunk);
-  const float* Kb = K + ((size_t)bh * Lk + kbeg) * AD;
-  const float* Vb = V + ((size_t)bh * Lk + kbeg) * AD;
+  const TK* Kb = K + obase(kl, bh) + (size_t)kbeg * kl.rs;
+  const TK* Vb = V + obase(kl, bh) + (size_t)kbeg * kl.rs;
   Lk = kend - kbeg;                                   // from here on: keys of this chunk only
 
   x8 qf[4];
   {
-    const float* qrow = Q + ((size_t)bh * Lq + qi) * AD;
+    const TQ* qrow = Q + obase(ql, bh) + (size_t)qi * ql.rs;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = row_frag<T>(qrow, s, hf, qscale);
+    for (int s = 0; s < 4; ++s) qf[s] = row_frag<T>(qrow, s, hf);
   }
-  // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
-  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  float4 kreg[2], vreg[2];
-  auto fetch = [&](int j0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = j0 + skey + 16 * i;
-      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
-      if (key < Lk) {
-        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * AD + sd4);
-        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * AD + sd4);
-      }
-    }
-  };
-  fetch(0);
+  TileRegs<T, TK> kreg, vreg;
+  kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
   floatx16 o0 = {0}, o1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
   const int ntiles = (Lk + AK - 1) / AK;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int j0 = kt * AK, buf = kt & 1;
     const int nk = min(AK, Lk - j0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = skey + 16 * i;
-      *reinterpret_cast<uint2v*>(&Kr[buf][key * RLD + sd4]) = pack4<T>(kreg[i]);
-      *reinterpret_cast<uint2v*>(&Vt[buf][key * TLD + sd4]) = pack4<T>(vreg[i]);
-    }
+    kreg.store(Kr[buf], RLD, tid); vreg.store(Vt[buf], TLD, tid);
     __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2: one barrier per tile is enough
-    if (kt + 1 < ntiles) fetch(j0 + AK);
-    // S^T[key, query] = K (qscale Q)^T
+    if (kt + 1 < ntiles) { kreg.load(Kb, kl.rs, j0 + AK, Lk, tid); vreg.load(Vb, kl.rs, j0 + AK, Lk, tid); }
+    // S^T[key, query] = K Q^T (unscaled)
     floatx16 s = {0};
 #pragma unroll
     for (int st = 0; st < 4; ++st) s = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Kr[buf][c * RLD + 16 * st + 8 * hf]), qf[st], s);
@@ -157,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
       if (acc_row(r, hf) >= nk) s[r] = -INFINITY;
       tmax = fmaxf(tmax, s[r]);
     }
-    tmax = xhalf_max(tmax);
+    tmax = xhalf_max(tmax) * qscale;
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -m_new)); psum += s[r]; }
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
@@ -195,21 +286,22 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const float* __restr
     }
     return;
   }
-  if (qvalid) {
-    float* op = O + obase(ol, bh) + (size_t)qi * ol.rs;
+  {
+    const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
+    // the residual is fetched as ONE batch of loads (a load inside the store loop makes hipcc wait for each in turn)
+    float4 ra[4], rb[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int d = 8 * rg + 4 * hf;
-      float4 a = make_float4(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
-      float4 b = make_float4(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
-      if (accumulate) {                       // O already holds the residual (depthwise convolution of v, NystromAttention.py:144-145)
-        const float4 ra = *reinterpret_cast<const float4*>(op + d), rb = *reinterpret_cast<const float4*>(op + 32 + d);
-        a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w; b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
-      }
-      *reinterpret_cast<float4*>(op + d) = a;
-      *reinterpret_cast<float4*>(op + 32 + d) = b;
+    for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
+    if (RES) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(RES + oo + 8 * rg + 4 * hf); rb[rg] = load4f(RES + oo + 32 + 8 * rg + 4 * hf); }
     }
-    if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+    // every lane takes part in the store (the 16-bit form exchanges pieces between the halves of a lane pair, whose rows are the same);
+    // rows past Lq are clamped to the last row and skipped
+    if (qvalid) {
+      store_row(O + oo, o0, o1, inv, ra, rb, hf);
+      if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+    }
   }
 }
 
@@ -285,11 +377,11 @@ __global__ __launch_bounds__(512, 2) void attn16_fwd_fewkeys_kernel(const float*
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const float4 a = qraw[2 * st], b = qraw[2 * st + 1];
-      const float x[8] = {a.x * qscale, a.y * qscale, a.z * qscale, a.w * qscale, b.x * qscale, b.y * qscale, b.z * qscale, b.w * qscale};
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       qf[st] = pack8<T>(x);
     }
     if (blk + 1 < blk1) load_q(blk + 1);              // next block's rows arrive during this block's MFMAs
-    // pass 1: S^T = K (qscale Q)^T for every tile, row maximum
+    // pass 1: S^T = K Q^T (unscaled) for every tile, row maximum
     floatx16 s[SK_MAX / AK];
     float m = -INFINITY;
 #pragma unroll
@@ -308,15 +400,15 @@ __global__ __launch_bounds__(512, 2) void attn16_fwd_fewkeys_kernel(const float*
         for (int r = 0; r < 16; ++r) m = fmaxf(m, s[t][r]);
       }
     }
-    m = xhalf_max(m);
-    // pass 2: P^T = 2^(S^T - m), row sum, O^T += V^T P^T
+    m = xhalf_max(m) * qscale;
+    // pass 2: P^T = 2^(qscale S^T - m), row sum, O^T += V^T P^T
     floatx16 o0 = {0}, o1 = {0};
     float l = 0.f;
 #pragma unroll
     for (int t = 0; t < SK_MAX / AK; ++t) {
       if (t < nt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m); l += s[t][r]; }
+        for (int r = 0; r < 16; ++r) { s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], qscale, -m)); l += s[t][r]; }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
           float p8[8];
@@ -389,14 +481,16 @@ __global__ void attn16_merge_kernel(const float* __restrict__ Opart, const float
 
 // ------------------------------------------------------------------------------------------------
 // backward pass 1 (query owners): P^T recomputed from LSE2, dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ = scale dS K;
-// also writes delta = rowsum(dO . O) [BH, Lq] for pass 2.          grid (ceil(Lq / 128), BH)
+// also writes delta = rowsum(dO . (O - R)) [BH, Lq] for pass 2.          grid (ceil(Lq / 128), BH, key chunks)
+//   Q, O, dO, R, dQ: storage TQ (layouts ql, ol, ol, ol, dql);  K, V: storage TK (layout kl);  key-split launches (fp32 storage only)
+//   write their partial dQ to fp32 slabs [chunk][BH, Lq, 64] instead
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                               const float* __restrict__ V, const float* __restrict__ O,
-                                                               const float* __restrict__ dO, const float* __restrict__ LSE2,
-                                                               float* __restrict__ dQ, float* __restrict__ DELTA, int Lq, int Lk,
-                                                               float qscale, float scale, OLayout ol, const float* __restrict__ R,
+template <typename T, typename TQ, typename TK>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const TQ* __restrict__ Q, const TK* __restrict__ K, const TK* __restrict__ V,
+                                                               const TQ* __restrict__ O, const TQ* __restrict__ dO,
+                                                               const float* __restrict__ LSE2, TQ* __restrict__ dQ, float* __restrict__ dQslab,
+                                                               float* __restrict__ DELTA, int Lq, int Lk, float qscale, float scale,
+                                                               OLayout ql, OLayout kl, OLayout ol, OLayout dql, const TQ* __restrict__ R,
                                                                int chunk) {
   typedef typename Pipe<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
@@ -407,62 +501,47 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
   const int q0 = blockIdx.x * (AQ * AW) + wave * AQ;
   const bool qvalid = (q0 + c) < Lq;
   const int qi = qvalid ? (q0 + c) : (Lq - 1);
-  // key range: the whole row or one of gridDim.z chunks (partial dQ slabs [chunk][BH, Lq, 64], added by attn16_sum_kernel)
   const int kbeg = blockIdx.z * chunk, kend = min(Lk, kbeg + chunk);
-  const float* Kb = K + ((size_t)bh * Lk + kbeg) * AD;
-  const float* Vb = V + ((size_t)bh * Lk + kbeg) * AD;
+  const TK* Kb = K + obase(kl, bh) + (size_t)kbeg * kl.rs;
+  const TK* Vb = V + obase(kl, bh) + (size_t)kbeg * kl.rs;
   Lk = kend - kbeg;
   x8 qf[4], dof[4];
   float delta = 0.f;
   {
-    const size_t off = ((size_t)bh * Lq + qi) * AD;
+    const TQ* qrow = Q + obase(ql, bh) + (size_t)qi * ql.rs;
     const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = row_frag<T>(Q + off, s, hf, qscale);
-      dof[s] = row_frag<T>(dO + oo, s, hf, 1.f);
-      const float4 t0 = *reinterpret_cast<const float4*>(dO + oo + 16 * s + 8 * hf), t1 = *reinterpret_cast<const float4*>(dO + oo + 16 * s + 8 * hf + 4);
-      float4 u0 = *reinterpret_cast<const float4*>(O + oo + 16 * s + 8 * hf), u1 = *reinterpret_cast<const float4*>(O + oo + 16 * s + 8 * hf + 4);
-      if (R) {            // the forward accumulated a residual into O: delta needs the attention output alone
-        const float4 r0 = *reinterpret_cast<const float4*>(R + oo + 16 * s + 8 * hf), r1 = *reinterpret_cast<const float4*>(R + oo + 16 * s + 8 * hf + 4);
-        u0.x -= r0.x; u0.y -= r0.y; u0.z -= r0.z; u0.w -= r0.w; u1.x -= r1.x; u1.y -= r1.y; u1.z -= r1.z; u1.w -= r1.w;
+      qf[s] = row_frag<T>(qrow, s, hf);
+      dof[s] = row_frag<T>(dO + oo, s, hf);
+      float t[8], u[8];
+      load8f(dO + oo + 16 * s + 8 * hf, t);
+      load8f(O + oo + 16 * s + 8 * hf, u);
+      if (R) {            // the forward added a residual to O: delta needs the attention output alone
+        float rr[8];
+        load8f(R + oo + 16 * s + 8 * hf, rr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] -= rr[i];
       }
-      delta += t0.x * u0.x + t0.y * u0.y + t0.z * u0.z + t0.w * u0.w + t1.x * u1.x + t1.y * u1.y + t1.z * u1.z + t1.w * u1.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) delta = fmaf(t[i], u[i], delta);
     }
   }
   delta = xhalf_sum(delta);
   const float lse2 = LSE2[(size_t)bh * Lq + qi];
   if (qvalid && hf == 0 && blockIdx.z == 0) DELTA[(size_t)bh * Lq + qi] = delta;
-  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  float4 kreg[2], vreg[2];
-  auto fetch = [&](int j0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = j0 + skey + 16 * i;
-      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
-      if (key < Lk) {
-        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * AD + sd4);
-        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * AD + sd4);
-      }
-    }
-  };
-  fetch(0);
+  TileRegs<T, TK> kreg, vreg;
+  kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
   floatx16 dq0 = {0}, dq1 = {0};
   const int ntiles = (Lk + AK - 1) / AK;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int j0 = kt * AK, buf = kt & 1;
     const int nk = min(AK, Lk - j0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = skey + 16 * i;
-      const uint2v kp = pack4<T>(kreg[i]);
-      *reinterpret_cast<uint2v*>(&Kr[buf][key * RLD + sd4]) = kp;
-      *reinterpret_cast<uint2v*>(&Kt[buf][key * TLD + sd4]) = kp;
-      *reinterpret_cast<uint2v*>(&Vr[buf][key * RLD + sd4]) = pack4<T>(vreg[i]);
-    }
+    kreg.store2(Kr[buf], RLD, Kt[buf], TLD, tid);
+    vreg.store(Vr[buf], RLD, tid);
     __syncthreads();
-    if (kt + 1 < ntiles) fetch(j0 + AK);
+    if (kt + 1 < ntiles) { kreg.load(Kb, kl.rs, j0 + AK, Lk, tid); vreg.load(Vb, kl.rs, j0 + AK, Lk, tid); }
     floatx16 s = {0}, dp = {0};
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -472,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = (acc_row(r, hf) < nk) ? __builtin_amdgcn_exp2f(s[r] - lse2) : 0.f;
+      const float p = (acc_row(r, hf) < nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lse2)) : 0.f;
       ds[r] = p * (dp[r] - delta);
     }
 #pragma unroll
@@ -487,29 +566,36 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const float* __re
     }
   }
   if (qvalid) {
-    float* qp = dQ + (((size_t)blockIdx.z * gridDim.y + bh) * Lq + qi) * AD;       // gridDim.z == 1: dQ itself
+    if (dQslab) {
+      float* qp = dQslab + (((size_t)blockIdx.z * gridDim.y + bh) * Lq + qi) * AD;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int d = 8 * rg + 4 * hf;
-      *reinterpret_cast<float4*>(qp + d) = make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale, dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale);
-      *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale, dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = 8 * rg + 4 * hf;
+        *reinterpret_cast<float4*>(qp + d) = make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale, dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale);
+        *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale, dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
+      }
+    } else {
+      float4 z4[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) z4[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
+      store_row(dQ + obase(dql, bh) + (size_t)qi * dql.rs, dq0, dq1, scale, z4, z4, hf);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward pass 2 (key owners): a wave owns 32 keys (key on the lane axis) and sweeps one slice of the query tiles:
-//   S = (qscale Q) K^T, P = exp2(S - LSE2[q]), dP = dO V^T, dS = P (dP - delta[q]),
-//   dV^T += dO^T P, dK^T += (qscale Q)^T dS  (times ln 2 at the end: qscale carries log2 e).
-// Partial sums of the query slices go to slabs [nparts][BH, Lk, 64] (nparts == 1: straight into dK / dV).
+//   S = Q K^T, P = exp2(qscale S - LSE2[q]), dP = dO V^T, dS = P (dP - delta[q]),  dV^T += dO^T P, dK^T += Q^T dS  (times scale at the end).
+// fp32 key-side storage: partial sums of the query slices go to slabs [nparts][BH, Lk, 64] (nparts == 1: straight into dK / dV);
+// 16-bit key-side storage (nparts == 1): dK is written, dV written or added to, at layout dkl.
 //   grid (ceil(Lk / 128), nparts, BH)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                                const float* __restrict__ V, const float* __restrict__ dO,
-                                                                const float* __restrict__ LSE2, const float* __restrict__ DELTA,
-                                                                float* __restrict__ dKp, float* __restrict__ dVp, int Lq, int Lk,
-                                                                float qscale, int tiles_per_part, size_t part_stride, OLayout ol) {
+template <typename T, typename TQ, typename TK>
+__global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __restrict__ Q, const TK* __restrict__ K, const TK* __restrict__ V,
+                                                                const TQ* __restrict__ dO, const float* __restrict__ LSE2,
+                                                                const float* __restrict__ DELTA, TK* dKp, TK* dVp, int Lq, int Lk,
+                                                                float qscale, float scale, int tiles_per_part, size_t part_stride, OLayout ql,
+                                                                OLayout kl, OLayout ol, OLayout dkl, int dv_accumulate) {
   typedef typename Pipe<T>::x8 x8;
   __shared__ __attribute__((aligned(16))) T Qr[2][AQ * RLD];
   __shared__ __attribute__((aligned(16))) T Qt[2][AQ * TLD];
@@ -524,28 +610,20 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __r
   const bool wave_has_keys = j0 < Lk;
   x8 kf[4], vf[4];
   {
-    const size_t off = ((size_t)bh * Lk + key) * AD;
+    const size_t off = obase(kl, bh) + (size_t)key * kl.rs;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = row_frag<T>(K + off, s, hf, 1.f); vf[s] = row_frag<T>(V + off, s, hf, 1.f); }
+    for (int s = 0; s < 4; ++s) { kf[s] = row_frag<T>(K + off, s, hf); vf[s] = row_frag<T>(V + off, s, hf); }
   }
   const int nqt = (Lq + AQ - 1) / AQ;
   const int qt_begin = part * tiles_per_part, qt_end = min(qt_begin + tiles_per_part, nqt);
-  const int srow = tid >> 4, sd4 = (tid & 15) * 4;
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const float* Qb = Q + (size_t)bh * Lq * AD;
-  const float* dOb = dO + obase(ol, bh);
-  float4 qreg[2], dreg[2];
+  const TQ* Qb = Q + obase(ql, bh);
+  const TQ* dOb = dO + obase(ol, bh);
+  TileRegs<T, TQ> qreg, dreg;
   float lreg = 0.f, ereg = 0.f;
   auto fetch = [&](int q0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = q0 + srow + 16 * i;
-      qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); dreg[i] = qreg[i];
-      if (row < Lq) {
-        qreg[i] = *reinterpret_cast<const float4*>(Qb + (size_t)row * AD + sd4);
-        dreg[i] = *reinterpret_cast<const float4*>(dOb + (size_t)row * ol.rs + sd4);
-      }
-    }
+    qreg.load(Qb, ql.rs, q0, Lq, tid);
+    dreg.load(dOb, ol.rs, q0, Lq, tid);
     if (tid < AQ) {
       const int row = min(q0 + tid, Lq - 1);
       lreg = LSE2[(size_t)bh * Lq + row];
@@ -556,16 +634,8 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __r
   if (qt_begin < qt_end) fetch(qt_begin * AQ);
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     const int q0 = qt * AQ, buf = (qt - qt_begin) & 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow + 16 * i;
-      const float4 qs = make_float4(qreg[i].x * qscale, qreg[i].y * qscale, qreg[i].z * qscale, qreg[i].w * qscale);
-      const uint2v qp = pack4<T>(qs), dp = pack4<T>(dreg[i]);
-      *reinterpret_cast<uint2v*>(&Qr[buf][row * RLD + sd4]) = qp;
-      *reinterpret_cast<uint2v*>(&Qt[buf][row * TLD + sd4]) = qp;
-      *reinterpret_cast<uint2v*>(&Dr[buf][row * RLD + sd4]) = dp;
-      *reinterpret_cast<uint2v*>(&Dt[buf][row * TLD + sd4]) = dp;
-    }
+    qreg.store2(Qr[buf], RLD, Qt[buf], TLD, tid);
+    dreg.store2(Dr[buf], RLD, Dt[buf], TLD, tid);
     if (tid < AQ) { lsd[buf][0][tid] = lreg; lsd[buf][1][tid] = ereg; }
     __syncthreads();
     if (qt + 1 < qt_end) fetch(q0 + AQ);
@@ -586,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __r
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * rg + i;
           const bool ok = kvalid && (q0 + acc_row(r, hf)) < Lq;
-          const float pv = ok ? __builtin_amdgcn_exp2f(s[r] - lv[i]) : 0.f;
+          const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lv[i])) : 0.f;
           p[r] = pv;
           ds[r] = pv * (dp[r] - ev[i]);
         }
@@ -606,17 +676,21 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const float* __r
     }
   }
   if (kvalid) {
-    const size_t off = (size_t)part * part_stride + ((size_t)bh * Lk + (j0 + c)) * AD;
-    float* kp = dKp + off;
-    float* vp = dVp + off;
+    const size_t off = (size_t)part * part_stride + obase(dkl, bh) + (size_t)(j0 + c) * dkl.rs;
+    TK* kp = dKp + off;
+    TK* vp = dVp + off;
+    float4 va[4], vb[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int d = 8 * rg + 4 * hf;
-      *reinterpret_cast<float4*>(kp + d) = make_float4(dk0[4 * rg] * LN2_F, dk0[4 * rg + 1] * LN2_F, dk0[4 * rg + 2] * LN2_F, dk0[4 * rg + 3] * LN2_F);
-      *reinterpret_cast<float4*>(kp + 32 + d) = make_float4(dk1[4 * rg] * LN2_F, dk1[4 * rg + 1] * LN2_F, dk1[4 * rg + 2] * LN2_F, dk1[4 * rg + 3] * LN2_F);
-      *reinterpret_cast<float4*>(vp + d) = make_float4(dv0[4 * rg], dv0[4 * rg + 1], dv0[4 * rg + 2], dv0[4 * rg + 3]);
-      *reinterpret_cast<float4*>(vp + 32 + d) = make_float4(dv1[4 * rg], dv1[4 * rg + 1], dv1[4 * rg + 2], dv1[4 * rg + 3]);
+    for (int rg = 0; rg < 4; ++rg) { va[rg] = make_float4(0.f, 0.f, 0.f, 0.f); vb[rg] = va[rg]; }
+    if (dv_accumulate) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { va[rg] = load4f(vp + 8 * rg + 4 * hf); vb[rg] = load4f(vp + 32 + 8 * rg + 4 * hf); }
     }
+    float4 z4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) z4[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
+    store_row(kp, dk0, dk1, scale, z4, z4, hf);
+    store_row(vp, dv0, dv1, 1.f, va, vb, hf);
   }
 }
 
@@ -708,6 +782,7 @@ static int attn16_layout(const char* fn, int BH, int Lq, int heads_merged, OLayo
   *ol = OLayout{(long long)Lq * heads_merged * AD, AD, (long long)heads_merged * AD, heads_merged};
   return SMML_OK;
 }
+static OLayout head_major(int L) { return OLayout{(long long)L * AD, 0, AD, 1}; }
 
 int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse2, void* workspace,
                         size_t workspace_bytes, int BH, int Lq, int Lk, int D, float scale, int use_fp16, int heads_merged,
@@ -750,8 +825,10 @@ int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* o
     return SMML_OK;
   }
   dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, ns), block(256);
-  if (use_fp16) hipLaunchKernelGGL(attn16_fwd_kernel<_Float16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
-  else hipLaunchKernelGGL(attn16_fwd_kernel<__bf16>, grid, block, 0, st, q, k, v, out, lse2, Lq, Lk, qscale, ol, accumulate, chunk, opart, lpart);
+  const OLayout ql = head_major(Lq), kl = head_major(Lk);
+  const float* res = accumulate ? out : nullptr;      // the output buffer already holds the residual
+  if (use_fp16) hipLaunchKernelGGL((attn16_fwd_kernel<_Float16, float, float>), grid, block, 0, st, q, k, v, out, res, lse2, Lq, Lk, qscale, ql, kl, ol, chunk, opart, lpart);
+  else hipLaunchKernelGGL((attn16_fwd_kernel<__bf16, float, float>), grid, block, 0, st, q, k, v, out, res, lse2, Lq, Lk, qscale, ql, kl, ol, chunk, opart, lpart);
   SMML_LAUNCH_CHECK("smml_attn16_fwd_f32");
   if (ns > 1) {
     const size_t n = (size_t)BH * Lq * (AD / 4);
@@ -781,9 +858,10 @@ int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const fl
   float* slabs = qslabs + (ns > 1 ? (size_t)ns * BH * Lq * AD : 0);
   dim3 block(256);
   dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH, ns);
-  float* dq_out = ns > 1 ? qslabs : dq;
-  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dq_kernel<_Float16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq_out, delta, Lq, Lk, qscale, scale, ol, residual, chunk);
-  else hipLaunchKernelGGL(attn16_bwd_dq_kernel<__bf16>, gq, block, 0, st, q, k, v, out, dout, lse2, dq_out, delta, Lq, Lk, qscale, scale, ol, residual, chunk);
+  const OLayout ql = head_major(Lq), kl = head_major(Lk);
+  float* qs = ns > 1 ? qslabs : nullptr;
+  if (use_fp16) hipLaunchKernelGGL((attn16_bwd_dq_kernel<_Float16, float, float>), gq, block, 0, st, q, k, v, out, dout, lse2, dq, qs, delta, Lq, Lk, qscale, scale, ql, kl, ol, ql, residual, chunk);
+  else hipLaunchKernelGGL((attn16_bwd_dq_kernel<__bf16, float, float>), gq, block, 0, st, q, k, v, out, dout, lse2, dq, qs, delta, Lq, Lk, qscale, scale, ql, kl, ol, ql, residual, chunk);
   SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dq");
   if (ns > 1) {
     const size_t n4 = (size_t)BH * Lq * AD / 4;
@@ -797,14 +875,153 @@ int smml_attn16_bwd_f32(const float* q, const float* k, const float* v, const fl
   float* dkp = parts > 1 ? slabs : dk;
   float* dvp = parts > 1 ? slabs + (size_t)parts * per : dv;
   dim3 gk((Lk + AK * AW - 1) / (AK * AW), parts, BH);
-  if (use_fp16) hipLaunchKernelGGL(attn16_bwd_dkv_kernel<_Float16>, gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, tpp, per, ol);
-  else hipLaunchKernelGGL(attn16_bwd_dkv_kernel<__bf16>, gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, tpp, per, ol);
+  if (use_fp16) hipLaunchKernelGGL((attn16_bwd_dkv_kernel<_Float16, float, float>), gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, scale, tpp, per, ql, kl, ol, kl, 0);
+  else hipLaunchKernelGGL((attn16_bwd_dkv_kernel<__bf16, float, float>), gk, block, 0, st, q, k, v, dout, lse2, delta, dkp, dvp, Lq, Lk, qscale, scale, tpp, per, ql, kl, ol, kl, 0);
   SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/dkv");
   if (parts > 1) {
     const size_t n4 = per / 4;
     hipLaunchKernelGGL(attn16_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(dkp),
                        reinterpret_cast<const float4*>(dvp), reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts);
     SMML_LAUNCH_CHECK("smml_attn16_bwd_f32/reduce");
+  }
+  return SMML_OK;
+}
+
+// ---- bf16-storage forms: the LONG side of the product (long_side 0: keys / values, 1: queries) is bf16 in memory at strides
+// (s_bs, s_hs, s_rs) per (bag, head, row), in elements; the short side is fp32 head-major [B H, L, 64].
+//   long_side 0 ("a3": softmax(ql k^T) v):  q fp32, k / v bf16 strided, out fp32 [B H, Lq, 64]
+//   long_side 1 ("a1": softmax(q kl^T) w):  q bf16 strided, k / v fp32, out = attention + residual in bf16 at strides (o_bs, o_hs, o_rs);
+//                                           residual (same strides, may be NULL)
+static int b16_check(const char* fn, int B, int H, int Lq, int Lk, int long_side, long long s_bs, long long s_hs, long long s_rs) {
+  SMML_REQUIRE(B > 0 && H > 0 && (long long)B * H <= 65535 && Lq > 0 && Lk > 0, "%s: bad sizes (B=%d H=%d Lq=%d Lk=%d)", fn, B, H, Lq, Lk);
+  SMML_REQUIRE(long_side == 0 || long_side == 1, "%s: long_side must be 0 (keys) or 1 (queries)", fn);
+  SMML_REQUIRE((s_bs % 8) == 0 && (s_hs % 8) == 0 && (s_rs % 8) == 0 && s_rs >= AD, "%s: bf16 strides must be multiples of 8 elements (16-byte rows)", fn);
+  return SMML_OK;
+}
+static bool al16p(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+int smml_attn16_fwd_b16(const void* q, const void* k, const void* v, void* out, const void* residual, float* lse2, void* workspace,
+                        size_t workspace_bytes, int B, int H, int Lq, int Lk, float scale, int long_side, long long s_bs, long long s_hs,
+                        long long s_rs, long long o_bs, long long o_hs, long long o_rs, void* stream) {
+  SMML_REQUIRE(q && k && v && out && lse2, "smml_attn16_fwd_b16: null pointer");
+  int rc = b16_check("smml_attn16_fwd_b16", B, H, Lq, Lk, long_side, s_bs, s_hs, s_rs);
+  if (rc) return rc;
+  const int BH = B * H;
+  hipStream_t st = (hipStream_t)stream;
+  const float qscale = scale * LOG2E_F;
+  const OLayout sl{s_bs, s_hs, s_rs, H};
+  dim3 block(256);
+  if (long_side == 0) {
+    SMML_REQUIRE(!residual, "smml_attn16_fwd_b16: no residual on the keys-long form");
+    SMML_REQUIRE(al16p(k) && al16p(v), "smml_attn16_fwd_b16: k / v must be 16-byte aligned");
+    int chunk;
+    const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
+    float *opart = nullptr, *lpart = nullptr;
+    if (ns > 1) {
+      SMML_REQUIRE(workspace && workspace_bytes >= smml_attn16_fwd_workspace_bytes(BH, Lq, Lk) && al16p(workspace),
+                   "smml_attn16_fwd_b16: this shape runs key-split and needs a 16-byte aligned workspace of %zu bytes",
+                   smml_attn16_fwd_workspace_bytes(BH, Lq, Lk));
+      opart = reinterpret_cast<float*>(workspace);
+      lpart = opart + (size_t)ns * BH * Lq * AD;
+    }
+    const OLayout ql = head_major(Lq);
+    dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, ns);
+    hipLaunchKernelGGL((attn16_fwd_kernel<__bf16, float, __bf16>), grid, block, 0, st, reinterpret_cast<const float*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<float*>(out),
+                       (const float*)nullptr, lse2, Lq, Lk, qscale, ql, sl, ql, chunk, opart, lpart);
+    SMML_LAUNCH_CHECK("smml_attn16_fwd_b16/keys");
+    if (ns > 1) {
+      const size_t n = (size_t)BH * Lq * (AD / 4);
+      hipLaunchKernelGGL(attn16_merge_kernel, dim3((unsigned)((n + 255) / 256)), block, 0, st, opart, lpart, reinterpret_cast<float*>(out), lse2, BH, Lq, ns, ql, 0);
+      SMML_LAUNCH_CHECK("smml_attn16_fwd_b16/merge");
+    }
+    return SMML_OK;
+  }
+  SMML_REQUIRE((o_bs % 8) == 0 && (o_hs % 8) == 0 && (o_rs % 8) == 0 && al16p(q) && al16p(out) && al16p(residual),
+               "smml_attn16_fwd_b16: bf16 operands must be 16-byte aligned with strides that are multiples of 8");
+  const OLayout ol{o_bs, o_hs, o_rs, H}, kl = head_major(Lk);
+  dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, 1);
+  hipLaunchKernelGGL((attn16_fwd_kernel<__bf16, __bf16, float>), grid, block, 0, st, reinterpret_cast<const __bf16*>(q),
+                     reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<__bf16*>(out),
+                     reinterpret_cast<const __bf16*>(residual), lse2, Lq, Lk, qscale, sl, kl, ol, Lk, (float*)nullptr, (float*)nullptr);
+  SMML_LAUNCH_CHECK("smml_attn16_fwd_b16/queries");
+  return SMML_OK;
+}
+
+// Backward of the forms above.  Gradients of the long side are bf16 at strides (g_bs, g_hs, g_rs) - they may live in another buffer than
+// the operands (the gradient of the qkv buffer); gradients of the short side are fp32 head-major.
+//   long_side 0: dout fp32 [B H, Lq, 64], out fp32; dq fp32; dk written, dv written or (dv_accumulate) added to
+//   long_side 1: out, residual, dout bf16 at the o strides; dq bf16 written; dk, dv fp32
+// workspace: smml_attn16_bwd_workspace_bytes(B H, Lq, Lk) bytes, 16-byte aligned.  The keys-long form never slices the queries (dk / dv go
+// straight to their bf16 rows), the queries-long form never splits the keys.
+int smml_attn16_bwd_b16(const void* q, const void* k, const void* v, const void* out, const void* residual, const void* dout,
+                        const float* lse2, void* dq, void* dk, void* dv, void* workspace, size_t workspace_bytes, int B, int H, int Lq,
+                        int Lk, float scale, int long_side, long long s_bs, long long s_hs, long long s_rs, long long o_bs, long long o_hs,
+                        long long o_rs, long long g_bs, long long g_hs, long long g_rs, int dv_accumulate, void* stream) {
+  SMML_REQUIRE(q && k && v && out && dout && lse2 && dq && dk && dv && workspace, "smml_attn16_bwd_b16: null pointer");
+  int rc = b16_check("smml_attn16_bwd_b16", B, H, Lq, Lk, long_side, s_bs, s_hs, s_rs);
+  if (rc) return rc;
+  const int BH = B * H;
+  SMML_REQUIRE(workspace_bytes >= smml_attn16_bwd_workspace_bytes(BH, Lq, Lk) && al16p(workspace), "smml_attn16_bwd_b16: workspace too small or misaligned");
+  SMML_REQUIRE((g_bs % 8) == 0 && (g_hs % 8) == 0 && (g_rs % 8) == 0 && g_rs >= AD, "smml_attn16_bwd_b16: gradient strides must be multiples of 8");
+  hipStream_t st = (hipStream_t)stream;
+  const float qscale = scale * LOG2E_F;
+  const OLayout sl{s_bs, s_hs, s_rs, H}, gl{g_bs, g_hs, g_rs, H};
+  float* delta = reinterpret_cast<float*>(workspace);
+  dim3 block(256);
+  if (long_side == 0) {
+    SMML_REQUIRE(!residual, "smml_attn16_bwd_b16: no residual on the keys-long form");
+    SMML_REQUIRE(al16p(k) && al16p(v) && al16p(dk) && al16p(dv), "smml_attn16_bwd_b16: bf16 operands must be 16-byte aligned");
+    int chunk;
+    const int ns = attn16_ksplit(BH, Lq, Lk, &chunk);
+    float* qslabs = delta + (((size_t)BH * Lq + 3) & ~(size_t)3);
+    const OLayout ql = head_major(Lq);
+    dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH, ns);
+    hipLaunchKernelGGL((attn16_bwd_dq_kernel<__bf16, float, __bf16>), gq, block, 0, st, reinterpret_cast<const float*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const float*>(out),
+                       reinterpret_cast<const float*>(dout), lse2, reinterpret_cast<float*>(dq), ns > 1 ? qslabs : (float*)nullptr, delta, Lq, Lk,
+                       qscale, scale, ql, sl, ql, ql, (const float*)nullptr, chunk);
+    SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/keys dq");
+    if (ns > 1) {
+      const size_t n4 = (size_t)BH * Lq * AD / 4;
+      hipLaunchKernelGGL(attn16_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(qslabs),
+                         reinterpret_cast<float4*>(dq), n4, ns);
+      SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/dq_sum");
+    }
+    const int nqt = (Lq + AQ - 1) / AQ;
+    dim3 gk((Lk + AK * AW - 1) / (AK * AW), 1, BH);
+    hipLaunchKernelGGL((attn16_bwd_dkv_kernel<__bf16, float, __bf16>), gk, block, 0, st, reinterpret_cast<const float*>(q),
+                       reinterpret_cast<const __bf16*>(k), reinterpret_cast<const __bf16*>(v), reinterpret_cast<const float*>(dout), lse2, delta,
+                       reinterpret_cast<__bf16*>(dk), reinterpret_cast<__bf16*>(dv), Lq, Lk, qscale, scale, nqt, (size_t)0, ql, sl, ql, gl,
+                       dv_accumulate);
+    SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/keys dkv");
+    return SMML_OK;
+  }
+  SMML_REQUIRE((o_bs % 8) == 0 && (o_hs % 8) == 0 && (o_rs % 8) == 0 && al16p(q) && al16p(out) && al16p(residual) && al16p(dout) && al16p(dq),
+               "smml_attn16_bwd_b16: bf16 operands must be 16-byte aligned with strides that are multiples of 8");
+  const OLayout ol{o_bs, o_hs, o_rs, H}, kl = head_major(Lk);      // no key split on this form: the long side is the query side
+  dim3 gq((Lq + AQ * AW - 1) / (AQ * AW), BH, 1);
+  hipLaunchKernelGGL((attn16_bwd_dq_kernel<__bf16, __bf16, float>), gq, block, 0, st, reinterpret_cast<const __bf16*>(q),
+                     reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<const __bf16*>(out),
+                     reinterpret_cast<const __bf16*>(dout), lse2, reinterpret_cast<__bf16*>(dq), (float*)nullptr, delta, Lq, Lk, qscale, scale, sl,
+                     kl, ol, gl, reinterpret_cast<const __bf16*>(residual), Lk);
+  SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/queries dq");
+  const int parts = attn16_parts(BH, Lq, Lk);
+  const int nqt = (Lq + AQ - 1) / AQ, tpp = (nqt + parts - 1) / parts;
+  const size_t per = (size_t)BH * Lk * AD;
+  float* slabs = delta + (((size_t)BH * Lq + 3) & ~(size_t)3);
+  float* dkp = parts > 1 ? slabs : reinterpret_cast<float*>(dk);
+  float* dvp = parts > 1 ? slabs + (size_t)parts * per : reinterpret_cast<float*>(dv);
+  dim3 gk((Lk + AK * AW - 1) / (AK * AW), parts, BH);
+  hipLaunchKernelGGL((attn16_bwd_dkv_kernel<__bf16, __bf16, float>), gk, block, 0, st, reinterpret_cast<const __bf16*>(q),
+                     reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<const __bf16*>(dout), lse2, delta, dkp, dvp,
+                     Lq, Lk, qscale, scale, tpp, per, sl, kl, ol, kl, 0);
+  SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/queries dkv");
+  if (parts > 1) {
+    const size_t n4 = per / 4;
+    hipLaunchKernelGGL(attn16_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(dkp),
+                       reinterpret_cast<const float4*>(dvp), reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts);
+    SMML_LAUNCH_CHECK("smml_attn16_bwd_b16/reduce");
   }
   return SMML_OK;
 }

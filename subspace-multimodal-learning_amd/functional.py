@@ -9,6 +9,8 @@ import math
 import os
 from typing import Optional
 
+import ctypes as C
+
 import torch
 
 from . import _capi as capi
@@ -289,6 +291,222 @@ def linear_b16(x, weight, bias=None, out_bf16: bool = True):
     """x W^T (+ bias) with bf16 operands in memory and fp32 accumulation; x bf16, weight / bias fp32 parameters (gradients fp32), the
     result bf16 (out_bf16) or fp32; dx is bf16."""
     return _LinearB16.apply(x, weight, bias, out_bf16)
+
+
+# ------------------------------------------------------------------------------------------------
+# The bf16-storage pipeline of the Nystrom block (bf16 compute mode): q / k / v stay in the token-major bf16 buffer qkv [b, n, 3, h, 64]
+# the projection writes; the four Functions below read them there at their strides and assemble ONE gradient buffer dqkv of the same
+# layout, which the projection's backward consumes.  The buffer is threaded through the chain as an extra output of each stage
+#   qkv_project16 -> attention16_keys_long -> resconv16 -> attention16_queries_long
+# (each stage returns qkv itself): in backward the chain runs in reverse, the LAST stage allocates dqkv and writes dq, resconv16 writes the v
+# part, attention16_keys_long writes dk and adds its dv, qkv_project16 adds the landmark means' gradients and runs the two GEMMs - no stage
+# returns a full-size gradient of its own for autograd to add up (six n'-sized adds / copies per step in the fp32-storage composition).
+# A stage modifies the incoming dqkv in place: it was produced by the stage after it for this purpose and nobody else holds it.
+# ------------------------------------------------------------------------------------------------
+def _qkv_dims(qkv, heads):
+    b, n, c = qkv.shape
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or c % (3 * heads):
+        raise RuntimeError("qkv must be a contiguous bf16 [b, n, 3 h d] buffer")
+    d = c // (3 * heads)
+    if d != 64:
+        raise RuntimeError("the bf16-storage attention is built for head dim 64")
+    return b, n, c, d
+
+
+def _part(t, i, hd):
+    """device pointer of part i (0 q, 1 k, 2 v) of a qkv-shaped bf16 buffer (same strides, shifted base)"""
+    _bptr(t)
+    return C.c_void_p(t.data_ptr() + 2 * i * hd)
+
+
+class _QKVProject16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, heads, l):
+        if x.dtype != torch.bfloat16:
+            raise RuntimeError("qkv_project16: x must be bf16")
+        x = x if x.is_contiguous() else x.contiguous()
+        wb = weight.detach().to(torch.bfloat16)
+        b, n, K = x.shape
+        N = weight.shape[0]
+        d = N // (3 * heads)
+        qkv = torch.empty(b, n, N, device=x.device, dtype=torch.bfloat16)
+        gemm_b16(x, wb, qkv, M=b * n, N=N, K=K, lda=K, ldb=K, ldc=N)
+        m = n // l
+        ql = torch.empty(b, heads, m, d, device=x.device, dtype=torch.float32)
+        kl = torch.empty_like(ql)
+        capi.check(capi.lib().smml_segment_mean_b16(_bptr(qkv), capi.fptr(ql), capi.fptr(kl), b, n, l, heads, d, capi.stream()), "segment_mean_b16")
+        ctx.cfg = (heads, l, d)
+        ctx.save_for_backward(x, wb)
+        return qkv, ql, kl
+
+    @staticmethod
+    def backward(ctx, dqkv, dql, dkl):
+        x, wb = ctx.saved_tensors
+        heads, l, d = ctx.cfg
+        b, n, K = x.shape
+        N = wb.shape[0]
+        if dqkv is None:
+            dqkv = torch.zeros(b, n, N, device=x.device, dtype=torch.bfloat16)
+        dqkv = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
+        if dql is not None or dkl is not None:
+            zero = None
+            if dql is None or dkl is None:
+                zero = torch.zeros(b, heads, n // l, d, device=x.device, dtype=torch.float32)
+            capi.check(capi.lib().smml_segment_mean_bwd_add_b16(_bptr(dqkv), capi.fptr(_c(dql) if dql is not None else zero),
+                                                                capi.fptr(_c(dkl) if dkl is not None else zero), b, n, l, heads, d,
+                                                                capi.stream()), "segment_mean_bwd_add_b16")
+        dx = dw = None
+        M = b * n
+        if ctx.needs_input_grad[0]:
+            wt = wb.t().contiguous()
+            dx = torch.empty_like(x)
+            gemm_b16(dqkv, wt, dx, M=M, N=K, K=N, lda=N, ldb=N, ldc=K)
+        if ctx.needs_input_grad[1]:
+            dw = _ZEROS.zeros((N, K), x.device)
+            gemm_b16(dqkv, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=_splitk_b16(N, K, M))
+        return dx, dw, None, None
+
+
+def qkv_project16(x, weight, heads: int, l: int):
+    """x bf16 [b, n, K] -> (qkv bf16 [b, n, 3 h d] = x W^T, ql, kl fp32 [b, h, n / l, d] = means of q / k over l consecutive tokens)"""
+    return _QKVProject16.apply(x, weight, heads, l)
+
+
+class _Attention16KeysLong(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ql, qkv, heads, scale, dv_accumulate):
+        b, n, c, d = _qkv_dims(qkv, heads)
+        ql = _c(ql)
+        m = ql.shape[2]
+        out = torch.empty(b, heads, m, d, device=qkv.device, dtype=torch.float32)
+        lse2 = torch.empty(b * heads, m, device=qkv.device, dtype=torch.float32)
+        L = capi.lib()
+        wsb = L.smml_attn16_fwd_workspace_bytes(b * heads, m, n)
+        ws = torch.empty((wsb + 3) // 4, device=qkv.device, dtype=torch.float32) if wsb else None
+        hd = heads * d
+        capi.check(L.smml_attn16_fwd_b16(capi.fptr(ql), _part(qkv, 1, hd), _part(qkv, 2, hd), capi.fptr(out), None, capi.fptr(lse2),
+                                         capi.fptr(ws), wsb, b, heads, m, n, float(scale), 0, n * c, d, c, 0, 0, 0, capi.stream()),
+                   "attn16_fwd_b16 (keys long)")
+        ctx.cfg = (heads, float(scale), bool(dv_accumulate))
+        ctx.save_for_backward(ql, qkv, out, lse2)
+        return out, qkv
+
+    @staticmethod
+    def backward(ctx, dout, dqkv):
+        ql, qkv, out, lse2 = ctx.saved_tensors
+        heads, scale, dv_acc = ctx.cfg
+        b, n, c, d = _qkv_dims(qkv, heads)
+        m = ql.shape[2]
+        hd = heads * d
+        if dqkv is None:                                   # nothing after this stage contributed: start the buffer here
+            dqkv = torch.zeros_like(qkv)
+            dv_acc = True
+        if dout is None:
+            return None, dqkv, None, None, None
+        dout = _c(dout)
+        dql = torch.empty_like(ql)
+        L = capi.lib()
+        wsb = L.smml_attn16_bwd_workspace_bytes(b * heads, m, n)
+        ws = torch.empty((wsb + 3) // 4, device=qkv.device, dtype=torch.float32)
+        capi.check(L.smml_attn16_bwd_b16(capi.fptr(ql), _part(qkv, 1, hd), _part(qkv, 2, hd), capi.fptr(out), None, capi.fptr(dout),
+                                         capi.fptr(lse2), capi.fptr(dql), _part(dqkv, 1, hd), _part(dqkv, 2, hd), capi.fptr(ws), wsb, b,
+                                         heads, m, n, scale, 0, n * c, d, c, 0, 0, 0, n * c, d, c, int(dv_acc), capi.stream()),
+                   "attn16_bwd_b16 (keys long)")
+        return dql, dqkv, None, None, None
+
+
+def attention16_keys_long(ql, qkv, *, heads: int, scale: float, dv_accumulate: bool):
+    """softmax(scale ql k^T) v with k / v read in the qkv buffer -> (fp32 [b, h, m, 64], qkv).  Backward writes dk into the k part of the
+    threaded gradient buffer and writes (dv_accumulate False) or adds (True: a stage after this one already wrote dv) its dv."""
+    return _Attention16KeysLong.apply(ql, qkv, heads, scale, dv_accumulate)
+
+
+class _ResConv16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, w, heads):
+        b, n, c, d = _qkv_dims(qkv, heads)
+        hd = heads * d
+        kw = w.shape[2]
+        w2 = _c(w.reshape(heads, kw))
+        res = torch.empty(b, n, hd, device=qkv.device, dtype=torch.bfloat16)
+        capi.check(capi.lib().smml_resconv_b16(_part(qkv, 2, hd), capi.fptr(w2), _bptr(res), b, heads, n, d, kw, n * c, c, n * hd, hd, 0,
+                                               capi.stream()), "resconv_b16")
+        ctx.cfg = (heads, kw, tuple(w.shape))
+        ctx.save_for_backward(qkv, w2)
+        return res, qkv
+
+    @staticmethod
+    def backward(ctx, dres, dqkv):
+        qkv, w2 = ctx.saved_tensors
+        heads, kw, wshape = ctx.cfg
+        b, n, c, d = _qkv_dims(qkv, heads)
+        hd = heads * d
+        if dqkv is None:
+            dqkv = torch.zeros_like(qkv)
+        dw = None
+        if dres is not None:
+            dres = dres if dres.is_contiguous() else dres.contiguous()
+            L = capi.lib()
+            capi.check(L.smml_resconv_b16(_bptr(dres), capi.fptr(w2), _part(dqkv, 2, hd), b, heads, n, d, kw, n * hd, hd, n * c, c, 1,
+                                          capi.stream()), "resconv_b16 (data gradient)")
+            if ctx.needs_input_grad[1]:
+                dw2 = _ZEROS.zeros((heads, kw), qkv.device)
+                capi.check(L.smml_resconv_wgrad_b16(_bptr(dres), _part(qkv, 2, hd), capi.fptr(dw2), b, heads, n, d, kw, n * hd, hd, n * c, c,
+                                                    capi.stream()), "resconv_wgrad_b16")
+                dw = dw2.view(wshape)
+        return dqkv, dw, None
+
+
+def resconv16(qkv, w, *, heads: int):
+    """depthwise 33-tap convolution of v over tokens, v read in the qkv buffer -> (bf16 [b, n, h 64], qkv).  Backward WRITES the v part of the
+    threaded gradient buffer (it is the first stage of the backward chain that touches it)."""
+    return _ResConv16.apply(qkv, w, heads)
+
+
+class _Attention16QueriesLong(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, kl, w, residual, heads, scale):
+        b, n, c, d = _qkv_dims(qkv, heads)
+        kl, w = _c(kl), _c(w)
+        m = kl.shape[2]
+        hd = heads * d
+        if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (b, n, hd) or not residual.is_contiguous()):
+            raise RuntimeError("attention16_queries_long: the residual is a contiguous bf16 [b, n, h 64] tensor")
+        out = torch.empty(b, n, hd, device=qkv.device, dtype=torch.bfloat16)
+        lse2 = torch.empty(b * heads, n, device=qkv.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_attn16_fwd_b16(_part(qkv, 0, hd), capi.fptr(kl), capi.fptr(w), _bptr(out),
+                                                  _bptr(residual) if residual is not None else None, capi.fptr(lse2), None, 0, b, heads, n, m,
+                                                  float(scale), 1, n * c, d, c, n * hd, d, hd, capi.stream()), "attn16_fwd_b16 (queries long)")
+        ctx.cfg = (heads, float(scale), residual is not None)
+        ctx.save_for_backward(qkv, kl, w, out, residual, lse2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, kl, w, out, residual, lse2 = ctx.saved_tensors
+        heads, scale, has_res = ctx.cfg
+        b, n, c, d = _qkv_dims(qkv, heads)
+        m = kl.shape[2]
+        hd = heads * d
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dqkv = torch.empty_like(qkv)                       # the head of the backward chain: q part written here, k / v parts by the earlier stages
+        dkl, dw = torch.empty_like(kl), torch.empty_like(w)
+        L = capi.lib()
+        wsb = L.smml_attn16_bwd_workspace_bytes(b * heads, n, m)
+        ws = torch.empty((wsb + 3) // 4, device=qkv.device, dtype=torch.float32)
+        capi.check(L.smml_attn16_bwd_b16(_part(qkv, 0, hd), capi.fptr(kl), capi.fptr(w), _bptr(out), _bptr(residual) if has_res else None,
+                                         _bptr(dout), capi.fptr(lse2), _part(dqkv, 0, hd), capi.fptr(dkl), capi.fptr(dw), capi.fptr(ws), wsb,
+                                         b, heads, n, m, scale, 1, n * c, d, c, n * hd, d, hd, n * c, d, c, 0, capi.stream()),
+                   "attn16_bwd_b16 (queries long)")
+        return dqkv, dkl, dw, (dout if has_res else None), None, None
+
+
+def attention16_queries_long(qkv, kl, w, residual=None, *, heads: int, scale: float):
+    """softmax(scale q kl^T) w + residual with q read in the qkv buffer -> bf16 [b, n, h 64] (the output projection's operand).  Backward
+    allocates the threaded gradient buffer dqkv and writes its q part; the k and v parts are left to the stages before this one."""
+    return _Attention16QueriesLong.apply(qkv, kl, w, residual, heads, scale)
 
 
 class _HeadMajorQKV(torch.autograd.Function):

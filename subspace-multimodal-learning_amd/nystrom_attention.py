@@ -129,7 +129,11 @@ class _PinvFork:
                 t.record_stream(self.main)
 
 
-B16_PROJECTIONS = os.environ.get("SMML_NYSTROM_B16", "1") != "0"      # measurement switch: 0 = fp32-storage projections in bf16 mode too
+# measurement switches of the bf16 compute mode: SMML_NYSTROM_B16 = 2 (default) bf16 storage end to end, 1 = bf16-storage projections around
+# the fp32-storage attention kernels (round-3 intermediate), 0 = fp32 storage everywhere (round 2)
+_B16_LEVEL = int(os.environ.get("SMML_NYSTROM_B16", "2"))
+B16_PROJECTIONS = _B16_LEVEL >= 1
+B16_STORAGE = _B16_LEVEL >= 2
 
 
 class NystromAttention(nn.Module):
@@ -209,6 +213,26 @@ class NystromAttention(nn.Module):
         pad = (m - n % m) % m
         npad = n + pad
         l = math.ceil(n / m)
+        sc = self.scale
+        wo, bo = self.to_out[0].weight, self.to_out[0].bias
+        if not fp16 and B16_STORAGE and (not self.residual or self.res_conv.weight.shape[2] == 33):
+            # bf16 storage end to end (functional.py, "bf16-storage pipeline"): q / k / v live in the projection's token-major bf16 buffer
+            x = x.to(torch.bfloat16)
+            if pad:
+                x = F.pad(x, (0, 0, pad, 0), value=0)
+            qkv, ql, kl = Fh.qkv_project16(x, self.to_qkv.weight, h, l)
+            a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                         # [b, h, m, m], exact fp32
+            fork = _PinvFork(a2)                                                                # beside attn3 v and the residual convolution
+            z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
+            right, qkv = Fh.attention16_keys_long(ql, qkv, heads=h, scale=sc, dv_accumulate=self.residual)   # softmax(ql k^T) v
+            res = None
+            if self.residual:
+                res, qkv = Fh.resconv16(qkv, self.res_conv.weight, heads=h)                     # bf16 [b, n', h d]
+            fork.join(z)
+            w = Fh.matmul4(z, right)                                                            # z (attn3 v)          [b, h, m, d]
+            out = Fh.attention16_queries_long(qkv, kl, w, res, heads=h, scale=sc)               # softmax(q kl^T) w + res, bf16
+            out = Fh.linear_b16(out, wo, bo, out_bf16=False)
+            return self.to_out[1](out)[:, -n:]
         b16 = not fp16 and B16_PROJECTIONS                      # bf16 mode: the projections read and write bf16 (csrc/gemm_b16.hip)
         if b16:
             x = x.to(torch.bfloat16)
@@ -223,7 +247,6 @@ class NystromAttention(nn.Module):
             qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
             q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
-        sc = self.scale
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
         fork = _PinvFork(a2)                                                                   # beside attn3 v and the residual convolution
         z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
@@ -232,7 +255,6 @@ class NystromAttention(nn.Module):
         fork.join(z)
         w = Fh.matmul4(z, right)                                                               # z (attn3 v)          [b, h, m, d]
         out = Fh.attention16(q, kl, w, scale=sc, fp16=fp16, merged=True, residual=res)         # softmax(q kl^T) w + res
-        wo, bo = self.to_out[0].weight, self.to_out[0].bias
         out = Fh.linear_b16(out.to(torch.bfloat16), wo, bo, out_bf16=False) if b16 else Fh.linear(out, wo, bo, prec=gm)
         out = self.to_out[1](out)
         return out[:, -n:]
