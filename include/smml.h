@@ -213,13 +213,18 @@ int smml_resconv_wgrad_b16(const void* dout, const void* v, float* dw, int B, in
 
 /* Newton-Schulz pseudo-inverse iteration (models/NystromAttention.py:28-33; dup cmta_utils.py:152-157), `iters` times, on NB problems of
  * m x m (row-major, contiguous): z <- 1/4 z (13 I - x z (15 I - x z (7 I - x z))).  One host call issues the whole chain of batched
- * products (4 per iteration forward, 8 + one update backward) on `stream`.
- * fwd: saved [iters][4][NB, m, m] receives (z_k, x z, a, b) of every iteration for the backward (slot [0][0] stays unwritten: z_0 is z0);
- *      z_out [NB, m, m] = the result.   bwd: dx, dz0 [NB, m, m] overwritten; scratch = 7 x NB x m x m floats. */
-void smml_newton_schulz_set_fast(int on);   /* 0: every product through smml_gemm_f32 (test / measurement switch); default 1: m = 256 uses the chain kernel */
-int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, void* stream);
+ * products (4 per iteration forward, 8 + one update backward) on `stream`.  reduced != 0: the caller accepts products with 16-bit
+ * mantissas (the block's 16-bit compute mode; m = 256 then runs as two bf16 planes per matrix on the 16-bit matrix pipe); reduced = 0:
+ * exact fp32 products.  The forward and the backward of one call take the same `reduced`.
+ * fwd: saved (smml_newton_schulz_saved_floats floats) receives what the backward needs of every iteration; z_out [NB, m, m] = the result.
+ * bwd: dx, dz0 [NB, m, m] overwritten; scratch = smml_newton_schulz_scratch_floats floats.  All buffers 16-byte aligned. */
+size_t smml_newton_schulz_saved_floats(int NB, int m, int iters, int reduced);     /* sizes, in floats, of `saved` and `scratch` below */
+size_t smml_newton_schulz_scratch_floats(int NB, int m, int iters, int reduced);
+/* measurement / test switch: 0 every product through smml_gemm_f32; 1 the exact-fp32 chain kernel for m = 256 whatever `reduced`; 2 (default) */
+void smml_newton_schulz_set_fast(int on);
+int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, int reduced, void* stream);
 int smml_newton_schulz_bwd(const float* x, const float* z0, const float* saved, const float* dz_in, float* dx, float* dz0,
-                           float* scratch, int NB, int m, int iters, void* stream);
+                           float* scratch, int NB, int m, int iters, int reduced, void* stream);
 
 int smml_resconv_fwd_f32(const float* v, const float* w, float* out_merged, int B, int H, int n, int D, int KW,
                          void* stream);

@@ -63,8 +63,10 @@ SIGNATURES = {
     "smml_resconv_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _f]),
     "smml_resconv_wgrad_b16": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f]),
     "smml_newton_schulz_set_fast": (None, [_i]),
-    "smml_newton_schulz_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _f]),
-    "smml_newton_schulz_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
+    "smml_newton_schulz_saved_floats": (_sz, [_i, _i, _i, _i]),
+    "smml_newton_schulz_scratch_floats": (_sz, [_i, _i, _i, _i]),
+    "smml_newton_schulz_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
+    "smml_newton_schulz_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "smml_resconv_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_resconv_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_dwconv7_fwd_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),

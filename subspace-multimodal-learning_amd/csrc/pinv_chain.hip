@@ -18,6 +18,12 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
                              long long sbias1, int bias_mode, int rows_per_bias, long long bias_ld, int act, int splitk, int accumulate,
                              float alpha, float beta, void* stream);
 
+#define SMML_TRY(call)      \
+  do {                      \
+    int rc_ = (call);       \
+    if (rc_) return rc_;    \
+  } while (0)
+
 namespace {
 
 __global__ void axpy_kernel(float4* __restrict__ y, const float4* __restrict__ x, float a, size_t n4) {
@@ -113,13 +119,194 @@ __global__ __launch_bounds__(256, 2) void chain_mm_kernel(const float* __restric
   for (int r = 0; r < 16; ++r) C[(size_t)(rowb + acc_row(r, hf)) * CM + col] = fmaf(beta, rv[r], alpha * acc[r]);
 }
 
-static int g_chain_fast = -1;      // -1: read SMML_CHAIN_FAST (default 1); 0: every product through smml_gemm_f32 (measurement / test switch)
+// ------------------------------------------------------------------------------------------------
+// The same product on the 16-bit matrix pipe ("planes" form, m = 256) for the block's 16-bit compute mode: every matrix of the chain
+// lives in memory as TWO bf16 planes [2][NB, m, m] - x = h + l to 2^-17 relative, fp32's exponent range - written once by the product
+// that makes it (16 values per lane to split) and read as they stand by the products that consume it; three of the four cross products
+// are kept (h h, h l, l h: <= 2^-16 |a||b| per product, i.e. ~100x finer than the bf16 attention products around the chain, and the
+// forward iteration corrects its own errors).  A 32 x 32 x 16 block costs 3 MFMAs of 32 cycles instead of 8 fp32 MFMAs of 64 (1.5 us of
+// matrix time per SIMD and product instead of 7.8) at the same bytes per element as fp32.  Measured on 32 problems (tests/bench_pinv_chain.py),
+// a product of the chain takes 13-15 us as an exact-fp32 launch, of which ~5 us are the kernel boundary and ~8 the matrix pipe; a
+// three-plane fp32-grade form (six products, 6 bytes per element) was built and dropped: 15-18 us - the launch is then bound by the
+// 112 MB its 512 workgroups pull through L2, not by the MFMAs.
+// Tile 64 x 64 per workgroup (2 x 2 waves), K in four steps of 64 through one LDS buffer; the loads of the first two steps are issued up
+// front, those of step s + 2 right after step s has been written to LDS.  Images as in gemm.hip: k-contiguous operand [row][64 k + 8]
+// (ds_read_b128 fragments), row-contiguous [k][64 rows + 32] (ds_read_b64_tr_b16).  The accumulator is transposed (rows on lanes, 4
+// consecutive columns per register group) so that the epilogue reads R and writes C as 8-byte pieces per plane.
+// ------------------------------------------------------------------------------------------------
+constexpr int NPL = 2;                          // planes per matrix
+// four fp32 -> two planes of four bf16: h = rn(v), l = rn(v - h)
+__device__ __forceinline__ void split4_b2(const float4 v, uint2v& h, uint2v& l) {
+  const float2v a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const float2v ra = bf16_residual2(a, ha), rb = bf16_residual2(b, hb);
+  const bf16x2 la = __builtin_convertvector(ra, bf16x2), lb = __builtin_convertvector(rb, bf16x2);
+  h = (uint2v){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  l = (uint2v){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+constexpr int PK_LD = CKS + 8;                  // halves per row, k-contiguous image
+constexpr int PR_LD = CT + 32;                  // halves per k-row, row-contiguous image
+constexpr int PIMG = CT * PR_LD;                // halves per image (6144; the k-contiguous one needs 64 x 72 = 4608)
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void chain_bf3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C,
+                                                           const __bf16* R, float* __restrict__ Cf, float alpha, float beta, int NB,
+                                                           size_t plane) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * PIMG];      // [A | B][plane]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = NB * 16, id = blockIdx.x;
+  const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r8 = ntiles & 7;
+  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + pos;
+  const int prob = lin >> 4, tile = lin & 15;
+  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
+  const size_t pb = (size_t)prob * CM * CM;
+  const int t8 = tid & 7, th = tid >> 3;                                 // 8 lanes cover 128 contiguous bytes
+  uint4v ra[2][2 * NPL], rb[2][2 * NPL];                                 // [ring slot][plane x 2 loads]
+  auto load_step = [&](int s, int slot) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rr = th + 32 * j;                                      // row (k-contiguous) or k (row-contiguous) within the step
+        const __bf16* ap = A + p * plane + pb + (TA ? (size_t)(CKS * s + rr) * CM + i0 + 8 * t8 : (size_t)(i0 + rr) * CM + CKS * s + 8 * t8);
+        const __bf16* bp = B + p * plane + pb + (TB ? (size_t)(n0 + rr) * CM + CKS * s + 8 * t8 : (size_t)(CKS * s + rr) * CM + n0 + 8 * t8);
+        ra[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(ap);
+        rb[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(bp);
+      }
+  };
+  load_step(0, 0);
+  load_step(1, 1);
+  // the residual: this lane's row i, columns 8 g + 4 hf .. + 3 of the wave's 32 x 32 block, three planes
+  const int row = i0 + wm * 32 + c, colb = n0 + wn * 32 + 4 * hf;
+  float rv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+  if (R) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(R + p * plane + pb + (size_t)row * CM + colb + 8 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rv[4 * g + i] += (float)v[i];       // h + l is exact
+      }
+  }
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  floatx16 acc = {0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int slot = s & 1;
+    if (s) __syncthreads();                                              // the previous step's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rr = th + 32 * j;
+        *reinterpret_cast<uint4v*>(&smem[p * PIMG + (TA ? rr * PR_LD : rr * PK_LD) + 8 * t8]) = ra[slot][2 * p + j];
+        *reinterpret_cast<uint4v*>(&smem[(NPL + p) * PIMG + (TB ? rr * PK_LD : rr * PR_LD) + 8 * t8]) = rb[slot][2 * p + j];
+      }
+    __syncthreads();
+    if (s + 2 < 4) load_step(s + 2, slot);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bf16x8 af[NPL], bf[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const __bf16* ia = &smem[p * PIMG];
+        const __bf16* ib = &smem[(NPL + p) * PIMG];
+        if (!TA) af[p] = *reinterpret_cast<const bf16x8*>(&ia[(wm * 32 + c) * PK_LD + 16 * kb + 8 * hf]);
+        else {
+          const __bf16* q0 = &ia[(16 * kb + 8 * hf + trq) * PR_LD + wm * 32 + trc];
+          af[p] = lds_frag_tr(q0, q0 + 4 * PR_LD);
+        }
+        if (TB) bf[p] = *reinterpret_cast<const bf16x8*>(&ib[(wn * 32 + c) * PK_LD + 16 * kb + 8 * hf]);
+        else {
+          const __bf16* q0 = &ib[(16 * kb + 8 * hf + trq) * PR_LD + wn * 32 + trc];
+          bf[p] = lds_frag_tr(q0, q0 + 4 * PR_LD);
+        }
+      }
+      // transposed block: D^T[n, i] = sum_k opB(k, n) opA(i, k) - the B fragments are the MFMA's A operand
+      acc = mfma16b(bf[1], af[0], acc);      // smallest terms first
+      acc = mfma16b(bf[0], af[1], acc);
+      acc = mfma16b(bf[0], af[0], acc);
+    }
+  }
+  // epilogue: lane = row i, register 4 g + j = column 8 g + 4 hf + j
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = make_float4(fmaf(beta, rv[4 * g], alpha * acc[4 * g]), fmaf(beta, rv[4 * g + 1], alpha * acc[4 * g + 1]),
+                                 fmaf(beta, rv[4 * g + 2], alpha * acc[4 * g + 2]), fmaf(beta, rv[4 * g + 3], alpha * acc[4 * g + 3]));
+    uint2v h, l;
+    split4_b2(v, h, l);
+    const size_t off = pb + (size_t)row * CM + colb + 8 * g;
+    *reinterpret_cast<uint2v*>(C + off) = h;
+    *reinterpret_cast<uint2v*>(C + plane + off) = l;
+    if (Cf) *reinterpret_cast<float4*>(Cf + off) = v;
+  }
+}
+
+// fp32 [n] -> two bf16 planes
+__global__ void split_planes_kernel(const float4* __restrict__ x, __bf16* __restrict__ P, size_t n4, size_t plane) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  uint2v h, l;
+  split4_b2(x[i], h, l);
+  *reinterpret_cast<uint2v*>(P + 4 * i) = h;
+  *reinterpret_cast<uint2v*>(P + plane + 4 * i) = l;
+}
+// y += a x on planes
+__global__ void axpy_planes_kernel(__bf16* __restrict__ Y, const __bf16* __restrict__ X, float a, size_t n4, size_t plane) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float y[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(Y + p * plane + 4 * i), xv = *reinterpret_cast<const bf16x4*>(X + p * plane + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y[e] += (float)yv[e]; x[e] += (float)xv[e]; }
+  }
+  uint2v h, l;
+  split4_b2(make_float4(fmaf(a, x[0], y[0]), fmaf(a, x[1], y[1]), fmaf(a, x[2], y[2]), fmaf(a, x[3], y[3])), h, l);
+  *reinterpret_cast<uint2v*>(Y + 4 * i) = h;
+  *reinterpret_cast<uint2v*>(Y + plane + 4 * i) = l;
+}
+
+// planes form of mm(): C (and, when Cf is given, its fp32 copy) = alpha op(A) op(B) + beta R;  R may be C itself
+int mm_p(const __bf16* A, bool ta, const __bf16* B, bool tb, __bf16* C, const __bf16* R, float* Cf, float alpha, float beta, int NB, void* st) {
+  const size_t plane = (size_t)NB * CM * CM;
+  dim3 grid((unsigned)(NB * 16)), block(256);
+  hipStream_t s = (hipStream_t)st;
+  if (ta && tb) hipLaunchKernelGGL((chain_bf3_kernel<true, true>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
+  else if (ta) hipLaunchKernelGGL((chain_bf3_kernel<true, false>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
+  else if (tb) hipLaunchKernelGGL((chain_bf3_kernel<false, true>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
+  else hipLaunchKernelGGL((chain_bf3_kernel<false, false>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
+  SMML_LAUNCH_CHECK("smml_newton_schulz/chain_bf3");
+  return SMML_OK;
+}
+int split_p(const float* x, __bf16* P, int NB, void* st) {
+  const size_t plane = (size_t)NB * CM * CM;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)st,
+                     reinterpret_cast<const float4*>(x), P, plane / 4, plane);
+  SMML_LAUNCH_CHECK("smml_newton_schulz/split");
+  return SMML_OK;
+}
+
+// Which form a chain of m x m problems runs in: 0 every product through smml_gemm_f32 (any m), 1 the exact-fp32 chain kernel (m = 256),
+// 2 the two-plane form on the 16-bit pipe (m = 256, only where the caller asked for reduced precision: the 16-bit compute mode).
+// The switch (smml_newton_schulz_set_fast / SMML_CHAIN_FAST): 0 = form 0 everywhere, 1 = form 1 also where reduced precision was asked for,
+// 2 (default) = as described.
+static int g_chain_fast = -1;
+static int chain_form(int m, int reduced) {
+  if (g_chain_fast < 0) { const char* e = getenv("SMML_CHAIN_FAST"); g_chain_fast = e ? atoi(e) : 2; }
+  if (m != CM || g_chain_fast == 0) return 0;
+  return (reduced && g_chain_fast == 2) ? 2 : 1;
+}
 
 // C = alpha op(A) op(B) + beta R over NB problems of m x m (row-major, contiguous); R may be C itself
 int mm(const float* A, bool ta, const float* B, bool tb, float* C, const float* R, float alpha, float beta, int NB, int m, void* st) {
-  if (g_chain_fast < 0) { const char* e = getenv("SMML_CHAIN_FAST"); g_chain_fast = e ? atoi(e) : 1; }
   auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
-  if (g_chain_fast && m == CM && al16(A) && al16(B) && (long long)NB * 16 < (1LL << 31)) {
+  if (chain_form(m, 0) && al16(A) && al16(B) && (long long)NB * 16 < (1LL << 31)) {
     dim3 grid((unsigned)(NB * 16)), block(256);
     hipStream_t s = (hipStream_t)st;
     if (ta && tb) hipLaunchKernelGGL((chain_mm_kernel<true, true>), grid, block, 0, s, A, B, C, R, alpha, beta, NB);
@@ -136,21 +323,85 @@ int mm(const float* A, bool ta, const float* B, bool tb, float* C, const float* 
 
 }  // namespace
 
-#define SMML_TRY(call)      \
-  do {                      \
-    int rc_ = (call);       \
-    if (rc_) return rc_;    \
-  } while (0)
-
 extern "C" {
 
 void smml_newton_schulz_set_fast(int on) { g_chain_fast = on; }
 
-// saved: [iters][4][NB, m, m] fp32 = (z_k, xz, a, b) of every iteration (slot [0][0] is not written: z_0 is the caller's z0);
-// z_out [NB, m, m] = z_iters.  x, z0, saved, z_out must not overlap.
-int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, void* stream) {
+// sizes (in floats) of the buffers the two entry points below need: they depend on the form the chain runs in
+size_t smml_newton_schulz_saved_floats(int NB, int m, int iters, int reduced) {
+  if (NB <= 0 || m <= 0 || iters <= 0) return 0;
+  const size_t per = (size_t)NB * m * m;
+  const int form = chain_form(m, reduced);
+  return form == 2 ? (size_t)(3 + 4 * iters) * (NPL * per / 2) : (size_t)iters * 4 * per;
+}
+size_t smml_newton_schulz_scratch_floats(int NB, int m, int iters, int reduced) {
+  if (NB <= 0 || m <= 0 || iters <= 0) return 0;
+  const size_t per = (size_t)NB * m * m;
+  const int form = chain_form(m, reduced);
+  return form == 2 ? (size_t)10 * (NPL * per / 2) : (size_t)7 * per;
+}
+
+// planes form: saved = [x | z0 | (z_k, xz, a, b) per iteration | spare] as bf16 planes tensors of NPL NB m m halves each
+static int ns_fwd_planes(const float* x, const float* z0, float* saved, float* z_out, int NB, int iters, void* stream) {
+  const size_t P = (size_t)NPL * NB * CM * CM;
+  __bf16* base = reinterpret_cast<__bf16*>(saved);
+  __bf16 *xp = base, *z0p = base + P, *spare = base + (size_t)(2 + 4 * iters) * P;
+  SMML_TRY(split_p(x, xp, NB, stream));
+  SMML_TRY(split_p(z0, z0p, NB, stream));
+  for (int k = 0; k < iters; ++k) {
+    __bf16* slot = base + (size_t)(2 + 4 * k) * P;
+    const __bf16* z = k == 0 ? z0p : slot;
+    __bf16 *xz = slot + P, *a = slot + 2 * P, *b = slot + 3 * P;
+    const bool last = k + 1 == iters;
+    __bf16* zn = last ? spare : slot + 4 * P;
+    SMML_TRY(mm_p(xp, false, z, false, xz, nullptr, nullptr, 1.f, 0.f, NB, stream));
+    SMML_TRY(mm_p(xz, false, xz, false, a, xz, nullptr, -1.f, 7.f, NB, stream));
+    SMML_TRY(mm_p(xz, false, a, false, b, xz, nullptr, -1.f, 15.f, NB, stream));
+    SMML_TRY(mm_p(z, false, b, false, zn, z, last ? z_out : nullptr, -0.25f, 3.25f, NB, stream));
+  }
+  return SMML_OK;
+}
+
+static int ns_bwd_planes(const float* saved, const float* dz_in, float* dx, float* dz0, float* scratch, int NB, int iters, void* stream) {
+  const size_t P = (size_t)NPL * NB * CM * CM, plane = P / NPL;
+  const __bf16* base = reinterpret_cast<const __bf16*>(saved);
+  const __bf16 *xp = base, *z0p = base + P;
+  __bf16* sc = reinterpret_cast<__bf16*>(scratch);
+  __bf16 *dzi = sc, *pp[2] = {sc + P, sc + 2 * P}, *dzk = sc + 3 * P, *db = sc + 4 * P, *dxz = sc + 5 * P, *da = sc + 6 * P, *t = sc + 7 * P,
+         *dxp = sc + 8 * P, *dz0p = sc + 9 * P;
+  SMML_TRY(split_p(dz_in, dzi, NB, stream));
+  const __bf16* dz = dzi;
+  for (int k = iters - 1; k >= 0; --k) {
+    const __bf16* slot = base + (size_t)(2 + 4 * k) * P;
+    const __bf16* z = k == 0 ? z0p : slot;
+    const __bf16 *xz = slot + P, *a = slot + 2 * P, *b = slot + 3 * P;
+    __bf16* dzn = k == 0 ? dz0p : pp[k & 1];
+    SMML_TRY(mm_p(dz, false, b, true, dzk, dz, nullptr, -0.25f, 3.25f, NB, stream));
+    SMML_TRY(mm_p(z, true, dz, false, db, nullptr, nullptr, -0.25f, 0.f, NB, stream));
+    SMML_TRY(mm_p(db, false, a, true, dxz, db, nullptr, -1.f, 15.f, NB, stream));
+    SMML_TRY(mm_p(xz, true, db, false, da, nullptr, nullptr, -1.f, 0.f, NB, stream));
+    SMML_TRY(mm_p(da, false, xz, true, t, dxz, nullptr, -1.f, 1.f, NB, stream));
+    SMML_TRY(mm_p(xz, true, da, false, t, t, nullptr, -1.f, 1.f, NB, stream));
+    hipLaunchKernelGGL(axpy_planes_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, da, 7.f, plane / 4, plane);
+    SMML_LAUNCH_CHECK("smml_newton_schulz_bwd/axpy_planes");
+    SMML_TRY(mm_p(t, false, z, true, dxp, (k == iters - 1) ? nullptr : dxp, k == 0 ? dx : nullptr, 1.f, 1.f, NB, stream));
+    SMML_TRY(mm_p(xp, true, t, false, dzn, dzk, k == 0 ? dz0 : nullptr, 1.f, 1.f, NB, stream));
+    dz = dzn;
+  }
+  return SMML_OK;
+}
+
+
+// reduced != 0: the caller accepts 16-bit-mantissa products (the block's 16-bit compute mode).
+// saved: smml_newton_schulz_saved_floats(NB, m, iters, reduced) floats - what the backward needs of every iteration ((z_k, xz, a, b) in fp32, or
+// in the planes form also x and z0, as bf16 planes); the forward and the backward of one call must run in the same form (the mode switch is
+// not to be changed between them).  z_out [NB, m, m] = z_iters.  x, z0, saved, z_out must not overlap.
+int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float* z_out, int NB, int m, int iters, int reduced, void* stream) {
   SMML_REQUIRE(x && z0 && saved && z_out, "smml_newton_schulz_fwd: null pointer");
   SMML_REQUIRE(NB > 0 && m > 0 && iters > 0, "smml_newton_schulz_fwd: bad sizes (NB=%d m=%d iters=%d)", NB, m, iters);
+  auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
+  SMML_REQUIRE(al16(x) && al16(z0) && al16(saved) && al16(z_out), "smml_newton_schulz_fwd: 16-byte aligned buffers needed");
+  if (chain_form(m, reduced) == 2) return ns_fwd_planes(x, z0, saved, z_out, NB, iters, stream);
   const size_t per = (size_t)NB * m * m;
   for (int k = 0; k < iters; ++k) {
     float* slot = saved + (size_t)k * 4 * per;
@@ -165,11 +416,14 @@ int smml_newton_schulz_fwd(const float* x, const float* z0, float* saved, float*
   return SMML_OK;
 }
 
-// dz_in [NB, m, m]: gradient of z_iters.  dx, dz0 [NB, m, m] are overwritten.  scratch: 7 x [NB, m, m] floats.
+// dz_in [NB, m, m]: gradient of z_iters.  dx, dz0 [NB, m, m] are overwritten.  scratch: smml_newton_schulz_scratch_floats(NB, m, iters, reduced) floats.
 int smml_newton_schulz_bwd(const float* x, const float* z0, const float* saved, const float* dz_in, float* dx, float* dz0, float* scratch,
-                           int NB, int m, int iters, void* stream) {
+                           int NB, int m, int iters, int reduced, void* stream) {
   SMML_REQUIRE(x && z0 && saved && dz_in && dx && dz0 && scratch, "smml_newton_schulz_bwd: null pointer");
   SMML_REQUIRE(NB > 0 && m > 0 && iters > 0, "smml_newton_schulz_bwd: bad sizes (NB=%d m=%d iters=%d)", NB, m, iters);
+  auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
+  SMML_REQUIRE(al16(x) && al16(z0) && al16(saved) && al16(dz_in) && al16(dx) && al16(dz0) && al16(scratch), "smml_newton_schulz_bwd: 16-byte aligned buffers needed");
+  if (chain_form(m, reduced) == 2) return ns_bwd_planes(saved, dz_in, dx, dz0, scratch, NB, iters, stream);
   const size_t per = (size_t)NB * m * m;
   SMML_REQUIRE(per % 4 == 0, "smml_newton_schulz_bwd: NB m m must be a multiple of 4");
   float *pp[2] = {scratch, scratch + per}, *dzk = scratch + 2 * per, *db = scratch + 3 * per, *dxz = scratch + 4 * per,

@@ -48,15 +48,17 @@ class _NewtonSchulz(torch.autograd.Function):
     one from here they cost more host time (~25 us each) than GPU time (~17 us)."""
 
     @staticmethod
-    def forward(ctx, x, z0, iters):
+    def forward(ctx, x, z0, iters, reduced=False):
         x, z0 = Fh._c(x), Fh._c(z0)
+        red = int(bool(reduced))
         m = x.shape[-1]
         nb = x.numel() // (m * m)
-        saved = torch.empty(iters, 4, *x.shape, device=x.device, dtype=torch.float32)
+        L = capi.lib()
+        saved = torch.empty(L.smml_newton_schulz_saved_floats(nb, m, iters, red), device=x.device, dtype=torch.float32)
         z = torch.empty_like(x)
-        capi.check(capi.lib().smml_newton_schulz_fwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(z), nb, m, iters,
-                                                     capi.stream()), "newton_schulz_fwd")
-        ctx.iters = iters
+        capi.check(L.smml_newton_schulz_fwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(z), nb, m, iters, red,
+                                      capi.stream()), "newton_schulz_fwd")
+        ctx.iters, ctx.red = iters, red
         ctx.save_for_backward(x, z0, saved)
         return z
 
@@ -67,15 +69,17 @@ class _NewtonSchulz(torch.autograd.Function):
         m = x.shape[-1]
         nb = x.numel() // (m * m)
         dx, dz0 = torch.empty_like(x), torch.empty_like(x)
-        scratch = torch.empty(7, *x.shape, device=x.device, dtype=torch.float32)
-        capi.check(capi.lib().smml_newton_schulz_bwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(dz), capi.fptr(dx),
-                                                     capi.fptr(dz0), capi.fptr(scratch), nb, m, ctx.iters, capi.stream()),
+        L = capi.lib()
+        scratch = torch.empty(L.smml_newton_schulz_scratch_floats(nb, m, ctx.iters, ctx.red), device=x.device, dtype=torch.float32)
+        capi.check(L.smml_newton_schulz_bwd(capi.fptr(x), capi.fptr(z0), capi.fptr(saved), capi.fptr(dz), capi.fptr(dx),
+                                                     capi.fptr(dz0), capi.fptr(scratch), nb, m, ctx.iters, ctx.red, capi.stream()),
                    "newton_schulz_bwd")
-        return dx, dz0, None
+        return dx, dz0, None, None
 
 
-def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
+def moore_penrose_iter_pinv(x, iters=6, per_bag=False, reduced=False):
     """x [B, h, m, m] -> Newton-Schulz pseudo-inverse (NystromAttention.py:20-35).
+    reduced=True (the block's 16-bit compute mode): products with 16-bit operand mantissas are acceptable (csrc/pinv_chain.hip).
     z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz))) evaluated as four GEMMs per iteration (see _NewtonSchulz).
     per_bag=True (corrected semantics, off by default): the initial scale uses each bag's own max row / column sums instead
     of the max over the whole batch (:26), so that a bag's result does not depend on which other bags share its batch."""
@@ -87,7 +91,7 @@ def moore_penrose_iter_pinv(x, iters=6, per_bag=False):
         z = (x.transpose(-1, -2) / (ax.sum(dim=-1).max() * ax.sum(dim=-2).max())).contiguous()
     if iters <= 0:
         return z
-    return _NewtonSchulz.apply(x.contiguous(), z, iters)
+    return _NewtonSchulz.apply(x.contiguous(), z, iters, reduced)
 
 
 _SIDE_STREAMS = {}
@@ -223,7 +227,7 @@ class NystromAttention(nn.Module):
             qkv, ql, kl = Fh.qkv_project16(x, self.to_qkv.weight, h, l)
             a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                         # [b, h, m, m], exact fp32
             fork = _PinvFork(a2)                                                                # beside attn3 v and the residual convolution
-            z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
+            z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale, reduced=True), a2)
             right, qkv = Fh.attention16_keys_long(ql, qkv, heads=h, scale=sc, dv_accumulate=self.residual)   # softmax(ql k^T) v
             res = None
             if self.residual:
@@ -249,7 +253,7 @@ class NystromAttention(nn.Module):
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
         fork = _PinvFork(a2)                                                                   # beside attn3 v and the residual convolution
-        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
+        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale, reduced=not fp16), a2)
         right = Fh.attention16(ql, k, v, scale=sc, fp16=fp16)                                  # softmax(ql k^T) v   [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None                   # [b, n', h d]
         fork.join(z)
