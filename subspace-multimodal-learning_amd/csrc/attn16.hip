@@ -229,6 +229,15 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   TileRegs<T, TK> kreg, vreg;
   kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
+  // the residual row is requested now (one batch of loads, consumed after the key loop): at the end it would be an exposed HBM round trip
+  const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
+  if (RES && !Opart) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(RES + oo + 8 * rg + 4 * hf); rb[rg] = load4f(RES + oo + 32 + 8 * rg + 4 * hf); }
+  }
   floatx16 o0 = {0}, o1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
   const int ntiles = (Lk + AK - 1) / AK;
@@ -242,22 +251,32 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict
     floatx16 s = {0};
 #pragma unroll
     for (int st = 0; st < 4; ++st) s = Pipe<T>::mfma(*reinterpret_cast<const x8*>(&Kr[buf][c * RLD + 16 * st + 8 * hf]), qf[st], s);
-    float tmax = -INFINITY;
+    if (nk < AK) {                                    // ragged last tile only (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (acc_row(r, hf) >= nk) s[r] = -INFINITY;
-      tmax = fmaxf(tmax, s[r]);
+      for (int r = 0; r < 16; ++r)
+        if (acc_row(r, hf) >= nk) s[r] = -INFINITY;
     }
+    float tmax = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     tmax = xhalf_max(tmax) * qscale;
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // Lazy reference point: the running reference m_run only has to keep the exponentials in range, it need not be the maximum.  It
+    // is moved (and the 32 output registers rescaled) only when some query's tile maximum exceeds it by more than 2^LAZY - after the
+    // first tile that is rare, so most tiles skip the rescale; probabilities then reach at most 2^LAZY, far inside bf16 / fp16 / fp32
+    // range (fp16: 2^8 x 256 keys of row sum is accumulated in fp32), and the log-sum-exp m_run + log2(l_run) is unaffected.
+    constexpr float LAZY = 8.f;
+    if (__builtin_amdgcn_ballot_w64(tmax > m_run + LAZY)) {      // wave-uniform
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -m_new)); psum += s[r]; }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -m_run)); psum += s[r]; }
+    l_run += psum;
     // O^T[d, query] += V^T P^T: the probabilities of k-step kb are accumulator registers 8 kb .. 8 kb + 7
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -287,15 +306,6 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict
     return;
   }
   {
-    const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
-    // the residual is fetched as ONE batch of loads (a load inside the store loop makes hipcc wait for each in turn)
-    float4 ra[4], rb[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
-    if (RES) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(RES + oo + 8 * rg + 4 * hf); rb[rg] = load4f(RES + oo + 32 + 8 * rg + 4 * hf); }
-    }
     // every lane takes part in the store (the 16-bit form exchanges pieces between the halves of a lane pair, whose rows are the same);
     // rows past Lq are clamped to the last row and skipped
     if (qvalid) {
@@ -550,9 +560,11 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const TQ* __restr
     }
     float ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = (acc_row(r, hf) < nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lse2)) : 0.f;
-      ds[r] = p * (dp[r] - delta);
+    for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lse2)) * (dp[r] - delta);
+    if (nk < AK) {                                    // ragged last tile only (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (acc_row(r, hf) >= nk) ds[r] = 0.f;
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -631,6 +643,15 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
     }
   };
   floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  // a running dV (16-bit key side: the residual convolution's gradient is already there) is requested now, not after the sweep
+  float4 va[4], vb[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) { va[rg] = make_float4(0.f, 0.f, 0.f, 0.f); vb[rg] = va[rg]; }
+  if (dv_accumulate) {
+    const TK* vp0 = dVp + (size_t)part * part_stride + obase(dkl, bh) + (size_t)key * dkl.rs;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { va[rg] = load4f(vp0 + 8 * rg + 4 * hf); vb[rg] = load4f(vp0 + 32 + 8 * rg + 4 * hf); }
+  }
   if (qt_begin < qt_end) fetch(qt_begin * AQ);
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     const int q0 = qt * AQ, buf = (qt - qt_begin) & 1;
@@ -655,11 +676,14 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * rg + i;
-          const bool ok = kvalid && (q0 + acc_row(r, hf)) < Lq;
-          const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lv[i])) : 0.f;
-          p[r] = pv;
-          ds[r] = pv * (dp[r] - ev[i]);
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], qscale, -lv[i]));
+          ds[r] = p[r] * (dp[r] - ev[i]);
         }
+      }
+      if (q0 + AQ > Lq || j0 + AK > Lk) {                  // ragged query tile or key block only (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!(kvalid && (q0 + acc_row(r, hf)) < Lq)) { p[r] = 0.f; ds[r] = 0.f; }
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -679,13 +703,6 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
     const size_t off = (size_t)part * part_stride + obase(dkl, bh) + (size_t)(j0 + c) * dkl.rs;
     TK* kp = dKp + off;
     TK* vp = dVp + off;
-    float4 va[4], vb[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) { va[rg] = make_float4(0.f, 0.f, 0.f, 0.f); vb[rg] = va[rg]; }
-    if (dv_accumulate) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) { va[rg] = load4f(vp + 8 * rg + 4 * hf); vb[rg] = load4f(vp + 32 + 8 * rg + 4 * hf); }
-    }
     float4 z4[4];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) z4[rg] = make_float4(0.f, 0.f, 0.f, 0.f);

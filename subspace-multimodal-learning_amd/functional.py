@@ -245,8 +245,9 @@ def gemm_b16(A, B, C, *, M, N, K, lda, ldb, ldc, trans=False, bias=None, splitk=
 
 
 def _splitk_b16(out_rows: int, out_cols: int, k: int) -> int:
+    # three 256-thread workgroups fit a CU: aim at one full round of 768 (1008 of them ran as one round and a third)
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    return int(max(1, min(1024 // max(tiles, 1), (k + 511) // 512)))
+    return int(max(1, min(768 // max(tiles, 1), (k + 511) // 512)))
 
 
 class _LinearB16(torch.autograd.Function):
