@@ -142,3 +142,45 @@ def test_nystrom_16bit_mode_follows_the_bag_dtype(cuda):
         assert rel_err(o16, ref) < 3e-2 and not torch.equal(o16, ref)
         mod.compute_dtype = "fp32"
         assert torch.equal(mod(x.to(torch.bfloat16)), mod(x.to(torch.bfloat16).float()))
+
+
+@pytest.mark.parametrize("cfg", [dict(residual=False), dict(num_landmarks=64), dict(heads=4, dim=256), dict(x_fp32=True), dict(B=3, n=513)])
+def test_nystrom_bf16_storage_configurations(cuda, cfg):
+    """The bf16-storage pipeline (functional.py: qkv_project16 -> attention16_keys_long -> resconv16 -> attention16_queries_long) in the
+    configurations the main comparison does not visit: no residual convolution (attention16_keys_long then WRITES dv), 64 landmarks (the
+    pseudo-inverse chain through the generic GEMM, 64 keys on the queries-long side), 4 heads, an fp32 bag with compute_dtype='bf16' (the
+    input gradient comes back as fp32), three bags of a length that needs padding - each against the fp64 oracle, and each checked to have
+    taken the bf16-storage branch."""
+    import importlib
+    cfg = dict(cfg)
+    B, n = cfg.pop("B", 2), cfg.pop("n", 700)
+    x_fp32 = cfg.pop("x_fp32", False)
+    dim, heads = cfg.pop("dim", 512), cfg.pop("heads", 8)
+    m = cfg.pop("num_landmarks", 256)
+    residual = cfg.pop("residual", True)
+    tag = f"nys16cfg:{B}:{n}:{dim}:{heads}:{m}:{int(residual)}:{int(x_fp32)}"
+    mod = smml.NystromAttention(dim=dim, dim_head=64, heads=heads, num_landmarks=m, residual=residual, dropout=0.1, compute_dtype="bf16")
+    params = params_for(mod, 43, tag)
+    mod = _load(mod, params, cuda)
+    x = synth.normal((B, n, dim), 43, tag + ":x") * 0.5
+    wo = synth.normal((B, n, dim), 43, tag + ":wo")
+    pr = {k: v.clone().double().requires_grad_() for k, v in params.items()}
+    xr = x.clone().double().requires_grad_()
+    o64 = nystrom_attention(xr, pr, heads=heads, dim_head=64, num_landmarks=m, residual=residual)
+    (o64 * wo.double()).sum().backward()
+    calls = []
+    orig = Fh.qkv_project16
+    Fh.qkv_project16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xd = (x if x_fp32 else x.to(torch.bfloat16)).to(cuda).requires_grad_()
+        out = mod(xd)
+        (out * wo.to(cuda)).sum().backward()
+    finally:
+        Fh.qkv_project16 = orig
+    assert calls, "the bf16-storage branch was not taken"
+    assert out.dtype == torch.float32 and xd.grad.dtype == xd.dtype
+    tol = TOL[False]                        # (a bf16 bag is rounded once more than the oracle's: inside the same gate)
+    assert_close(tag + " out", out, o64, tol)
+    assert_close(tag + " dx", xd.grad, xr.grad, tol)
+    for k, p in mod.named_parameters():
+        assert_close(tag + " d" + k, p.grad, pr[k].grad, 2 * tol)
