@@ -50,22 +50,20 @@ constexpr int CM = 256, CT = 64, CKS = 64;     // matrix size, tile, K step
 constexpr int KC_LDF = CKS + 4;                // floats per row of a k-contiguous image
 constexpr int IMG = CT * KC_LDF;               // floats per image (the row-contiguous one, 64 x 64, fits too)
 
+// workgroup id -> contiguous range of work items per XCD
+__device__ __forceinline__ int xcd_linear(int id, int nitems) {
+  const int xcd = id & 7, pos = id >> 3, q = nitems >> 3, r8 = nitems & 7;
+  return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + pos;
+}
+
+// one exact-fp32 product into `acc` (rows on the register axis, column on the lane) in two parts: every panel load issued (the caller
+// requests its residual right after), then the K loop; smem: [buffer][A | B] images
+struct F32Panels { floatx4 pa[16], pbv[16]; };                         // every load of a workgroup's two 64 x 256 operand panels
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void chain_mm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
-                                                          const float* R, float alpha, float beta, int NB) {
-  __shared__ __attribute__((aligned(16))) float smem[2][2][IMG];      // [buffer][A | B]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = NB * 16, id = blockIdx.x;
-  const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r8 = ntiles & 7;
-  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + pos;
-  const int prob = lin >> 4, tile = lin & 15;
-  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
-  const size_t pb = (size_t)prob * CM * CM;
-  A += pb; B += pb; C += pb;
-  const int t16 = tid & 15, th = tid >> 4;                              // 16 lanes cover 256 contiguous bytes
-  // every load of the two panels, then the residual
-  floatx4 pa[16], pbv[16];
+__device__ __forceinline__ void f32_load(const float* __restrict__ A, const float* __restrict__ B, F32Panels& P, int i0, int n0) {
+  const int tid = threadIdx.x, t16 = tid & 15, th = tid >> 4;          // 16 lanes cover 256 contiguous bytes
+  floatx4 (&pa)[16] = P.pa;
+  floatx4 (&pbv)[16] = P.pbv;
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -76,12 +74,14 @@ __global__ __launch_bounds__(256, 2) void chain_mm_kernel(const float* __restric
       pbv[4 * s + j] = TB ? *reinterpret_cast<const floatx4*>(B + (size_t)(n0 + rr) * CM + CKS * s + 4 * t16)      // B stored [n][k]
                           : *reinterpret_cast<const floatx4*>(B + (size_t)(CKS * s + rr) * CM + n0 + 4 * t16);     // B stored [k][n]
     }
-  const int col = n0 + wn * 32 + c, rowb = i0 + wm * 32;
-  float rv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rv[r] = R ? R[pb + (size_t)(rowb + acc_row(r, hf)) * CM + col] : 0.f;
-
-  floatx16 acc = {0};
+}
+template <bool TA, bool TB>
+__device__ __forceinline__ void f32_compute(const F32Panels& P, float (*smem)[2][IMG], floatx16& acc) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t16 = tid & 15, th = tid >> 4;
+  const floatx4 (&pa)[16] = P.pa;
+  const floatx4 (&pbv)[16] = P.pbv;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     float* As = smem[s & 1][0];
@@ -115,8 +115,78 @@ __global__ __launch_bounds__(256, 2) void chain_mm_kernel(const float* __restric
       for (int j = 0; j < 4; ++j) acc = mfma32(a[j], b[j], acc);
     }
   }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void chain_mm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
+                                                          const float* R, float alpha, float beta, int NB) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][IMG];      // [buffer][A | B]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+  const int lin = xcd_linear(blockIdx.x, NB * 16);
+  const int prob = lin >> 4, tile = lin & 15;
+  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
+  const size_t pb = (size_t)prob * CM * CM;
+  const size_t col = pb + n0 + (wave & 1) * 32 + c;
+  const int rowb = i0 + (wave >> 1) * 32;
+  F32Panels P;
+  f32_load<TA, TB>(A + pb, B + pb, P, i0, n0);
+  // the residual, requested behind the panels; ONE branch around all sixteen loads (a select per element makes hipcc wait for each in turn)
+  float rv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) C[(size_t)(rowb + acc_row(r, hf)) * CM + col] = fmaf(beta, rv[r], alpha * acc[r]);
+  for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+  if (R) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = R[col + (size_t)(rowb + acc_row(r, hf)) * CM];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] *= beta;
+  }
+  floatx16 acc = {0};
+  f32_compute<TA, TB>(P, smem, acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) C[col + (size_t)(rowb + acc_row(r, hf)) * CM] = fmaf(alpha, acc[r], rv[r]);
+}
+
+// two products of the backward chain in one launch, as chain_bf3_dual_kernel below (see there): j0 an A B^T product, j1 an A^T B one
+struct FJob { const float* A; const float* B; float* C; const float* R; float alpha, beta; };
+__global__ __launch_bounds__(256, 2) void chain_mm_dual_kernel(FJob j0, FJob j1, int fuse, int NB) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][IMG];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+  const int lin = xcd_linear(blockIdx.x, fuse ? NB * 16 : NB * 32);
+  const int prob = fuse ? (lin >> 4) : (lin >> 5), job = fuse ? 0 : ((lin >> 4) & 1), tile = lin & 15;
+  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
+  const size_t pb = (size_t)prob * CM * CM;
+  const size_t col = pb + n0 + (wave & 1) * 32 + c;
+  const int rowb = i0 + (wave >> 1) * 32;
+  const FJob& jj = (fuse || job == 0) ? j0 : j1;
+  F32Panels P;
+  if (fuse || job == 0) f32_load<false, true>(j0.A + pb, j0.B + pb, P, i0, n0);      // workgroup-uniform
+  else f32_load<true, false>(j1.A + pb, j1.B + pb, P, i0, n0);
+  float rv[16], rw[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { rv[r] = 0.f; rw[r] = 0.f; }
+  if (jj.R) {                                                            // one branch around each batch of sixteen loads
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = jj.R[col + (size_t)(rowb + acc_row(r, hf)) * CM];
+  }
+  if (fuse && j1.R) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rw[r] = j1.R[col + (size_t)(rowb + acc_row(r, hf)) * CM];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rv[r] = fmaf(j1.beta, rw[r], jj.beta * rv[r]);
+  floatx16 acc = {0};
+  if (fuse) {
+    f32_compute<false, true>(P, smem, acc);
+    f32_load<true, false>(j1.A + pb, j1.B + pb, P, i0, n0);
+    __syncthreads();                                                     // the images are read to the end before the second product refills them
+    f32_compute<true, false>(P, smem, acc);
+  } else if (job == 0) {
+    f32_compute<false, true>(P, smem, acc);
+  } else {
+    f32_compute<true, false>(P, smem, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) jj.C[col + (size_t)(rowb + acc_row(r, hf)) * CM] = fmaf(jj.alpha, acc[r], rv[r]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -148,52 +218,34 @@ constexpr int PK_LD = CKS + 8;                  // halves per row, k-contiguous 
 constexpr int PR_LD = CT + 32;                  // halves per k-row, row-contiguous image
 constexpr int PIMG = CT * PR_LD;                // halves per image (6144; the k-contiguous one needs 64 x 72 = 4608)
 
+// the K loop of one product into `acc` (the transposed 32 x 32 block of this wave); smem: [A | B][plane] images, free on entry
+struct PlaneRing { uint4v ra[2][2 * NPL], rb[2][2 * NPL]; };            // [ring slot][plane x 2 loads]
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void chain_bf3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C,
-                                                           const __bf16* R, float* __restrict__ Cf, float alpha, float beta, int NB,
-                                                           size_t plane) {
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * PIMG];      // [A | B][plane]
+__device__ __forceinline__ void planes_load_step(const __bf16* __restrict__ A, const __bf16* __restrict__ B, PlaneRing& Q, int s, int slot, size_t pb,
+                                                 int i0, int n0, size_t plane) {
+  const int tid = threadIdx.x, t8 = tid & 7, th = tid >> 3;              // 8 lanes cover 128 contiguous bytes
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = th + 32 * j;                                        // row (k-contiguous) or k (row-contiguous) within the step
+      const __bf16* ap = A + p * plane + pb + (TA ? (size_t)(CKS * s + rr) * CM + i0 + 8 * t8 : (size_t)(i0 + rr) * CM + CKS * s + 8 * t8);
+      const __bf16* bp = B + p * plane + pb + (TB ? (size_t)(n0 + rr) * CM + CKS * s + 8 * t8 : (size_t)(CKS * s + rr) * CM + n0 + 8 * t8);
+      Q.ra[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(ap);
+      Q.rb[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(bp);
+    }
+}
+// the K loop; the loads of steps 0 and 1 are already in the ring (planes_load_step: the caller requests its residual behind them)
+template <bool TA, bool TB>
+__device__ __forceinline__ void planes_product(const __bf16* __restrict__ A, const __bf16* __restrict__ B, PlaneRing& Q, __bf16* smem, floatx16& acc,
+                                               size_t pb, int i0, int n0, size_t plane) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = NB * 16, id = blockIdx.x;
-  const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r8 = ntiles & 7;
-  const int lin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + pos;
-  const int prob = lin >> 4, tile = lin & 15;
-  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
-  const size_t pb = (size_t)prob * CM * CM;
-  const int t8 = tid & 7, th = tid >> 3;                                 // 8 lanes cover 128 contiguous bytes
-  uint4v ra[2][2 * NPL], rb[2][2 * NPL];                                 // [ring slot][plane x 2 loads]
-  auto load_step = [&](int s, int slot) {
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int rr = th + 32 * j;                                      // row (k-contiguous) or k (row-contiguous) within the step
-        const __bf16* ap = A + p * plane + pb + (TA ? (size_t)(CKS * s + rr) * CM + i0 + 8 * t8 : (size_t)(i0 + rr) * CM + CKS * s + 8 * t8);
-        const __bf16* bp = B + p * plane + pb + (TB ? (size_t)(n0 + rr) * CM + CKS * s + 8 * t8 : (size_t)(CKS * s + rr) * CM + n0 + 8 * t8);
-        ra[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(ap);
-        rb[slot][2 * p + j] = *reinterpret_cast<const uint4v*>(bp);
-      }
-  };
-  load_step(0, 0);
-  load_step(1, 1);
-  // the residual: this lane's row i, columns 8 g + 4 hf .. + 3 of the wave's 32 x 32 block, three planes
-  const int row = i0 + wm * 32 + c, colb = n0 + wn * 32 + 4 * hf;
-  float rv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-  if (R) {
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(R + p * plane + pb + (size_t)row * CM + colb + 8 * g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rv[4 * g + i] += (float)v[i];       // h + l is exact
-      }
-  }
+  const int t8 = tid & 7, th = tid >> 3;
+  uint4v (&ra)[2][2 * NPL] = Q.ra;
+  uint4v (&rb)[2][2 * NPL] = Q.rb;
+  auto load_step = [&](int s, int slot) { planes_load_step<TA, TB>(A, B, Q, s, slot, pb, i0, n0, plane); };
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  floatx16 acc = {0};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int slot = s & 1;
@@ -232,17 +284,97 @@ __global__ __launch_bounds__(256, 2) void chain_bf3_kernel(const __bf16* __restr
       acc = mfma16b(bf[0], af[0], acc);
     }
   }
-  // epilogue: lane = row i, register 4 g + j = column 8 g + 4 hf + j
+}
+// this lane's 16 values (row i, columns 8 g + 4 hf + j of the wave's block) of a planes matrix, times w, added to rv
+__device__ __forceinline__ void planes_residual(const __bf16* __restrict__ R, float w, float (&rv)[16], size_t off0, size_t plane) {
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(R + p * plane + off0 + 8 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rv[4 * g + i] = fmaf(w, (float)v[i], rv[4 * g + i]);     // h first, then l
+    }
+}
+// C (planes, and its fp32 copy when Cf is given) = alpha acc + rv
+__device__ __forceinline__ void planes_store(const floatx16& acc, const float (&rv)[16], __bf16* C, float* __restrict__ Cf, float alpha, size_t off0,
+                                             size_t plane) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4 v = make_float4(fmaf(beta, rv[4 * g], alpha * acc[4 * g]), fmaf(beta, rv[4 * g + 1], alpha * acc[4 * g + 1]),
-                                 fmaf(beta, rv[4 * g + 2], alpha * acc[4 * g + 2]), fmaf(beta, rv[4 * g + 3], alpha * acc[4 * g + 3]));
+    const float4 v = make_float4(fmaf(alpha, acc[4 * g], rv[4 * g]), fmaf(alpha, acc[4 * g + 1], rv[4 * g + 1]), fmaf(alpha, acc[4 * g + 2], rv[4 * g + 2]),
+                                 fmaf(alpha, acc[4 * g + 3], rv[4 * g + 3]));
     uint2v h, l;
     split4_b2(v, h, l);
-    const size_t off = pb + (size_t)row * CM + colb + 8 * g;
-    *reinterpret_cast<uint2v*>(C + off) = h;
-    *reinterpret_cast<uint2v*>(C + plane + off) = l;
-    if (Cf) *reinterpret_cast<float4*>(Cf + off) = v;
+    *reinterpret_cast<uint2v*>(C + off0 + 8 * g) = h;
+    *reinterpret_cast<uint2v*>(C + plane + off0 + 8 * g) = l;
+    if (Cf) *reinterpret_cast<float4*>(Cf + off0 + 8 * g) = v;
+  }
+}
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void chain_bf3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B, __bf16* C,
+                                                           const __bf16* R, float* __restrict__ Cf, float alpha, float beta, int NB,
+                                                           size_t plane) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * PIMG];      // [A | B][plane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lin = xcd_linear(blockIdx.x, NB * 16);
+  const int prob = lin >> 4, tile = lin & 15;
+  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
+  const size_t pb = (size_t)prob * CM * CM;
+  const size_t off0 = pb + (size_t)(i0 + (wave >> 1) * 32 + (lane & 31)) * CM + n0 + (wave & 1) * 32 + 4 * (lane >> 5);
+  PlaneRing Q;
+  planes_load_step<TA, TB>(A, B, Q, 0, 0, pb, i0, n0, plane);
+  planes_load_step<TA, TB>(A, B, Q, 1, 1, pb, i0, n0, plane);
+  float rv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+  if (R) planes_residual(R, beta, rv, off0, plane);                      // requested behind the first two steps' operands
+  floatx16 acc = {0};
+  planes_product<TA, TB>(A, B, Q, smem, acc, pb, i0, n0, plane);
+  planes_store(acc, rv, C, Cf, alpha, off0, plane);
+}
+
+// Two products of the backward chain in ONE launch - every pair the backward offers is an (A B^T, A^T B) pair:
+//   fuse = 0: two independent results, C0 = alpha0 A0 B0^T + beta0 R0 and C1 = alpha1 A1^T B1 + beta1 R1 (2 x NB x 16 workgroups; the
+//             two jobs of a problem sit next to each other so that they share one L2);
+//   fuse = 1: one result, C0 = alpha0 (A0 B0^T + A1^T B1) + beta0 R0 + beta1 R1 (dxz + 7 da - da xz^T - xz^T da in one kernel).
+// A launch boundary costs ~5 us against 5 - 7 us of work in a product: 9 launches per backward iteration become 4.
+struct PJob { const __bf16* A; const __bf16* B; __bf16* C; const __bf16* R; float* Cf; float alpha, beta; };
+__global__ __launch_bounds__(256, 2) void chain_bf3_dual_kernel(PJob j0, PJob j1, int fuse, int NB, size_t plane) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * PIMG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lin = xcd_linear(blockIdx.x, fuse ? NB * 16 : NB * 32);
+  const int prob = fuse ? (lin >> 4) : (lin >> 5), job = fuse ? 0 : ((lin >> 4) & 1), tile = lin & 15;
+  const int i0 = (tile >> 2) * CT, n0 = (tile & 3) * CT;
+  const size_t pb = (size_t)prob * CM * CM;
+  const size_t off0 = pb + (size_t)(i0 + (wave >> 1) * 32 + (lane & 31)) * CM + n0 + (wave & 1) * 32 + 4 * (lane >> 5);
+  float rv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+  floatx16 acc = {0};
+  PlaneRing Q;
+  if (fuse) {
+    planes_load_step<false, true>(j0.A, j0.B, Q, 0, 0, pb, i0, n0, plane);
+    planes_load_step<false, true>(j0.A, j0.B, Q, 1, 1, pb, i0, n0, plane);
+    if (j0.R) planes_residual(j0.R, j0.beta, rv, off0, plane);
+    if (j1.R) planes_residual(j1.R, j1.beta, rv, off0, plane);
+    planes_product<false, true>(j0.A, j0.B, Q, smem, acc, pb, i0, n0, plane);
+    planes_load_step<true, false>(j1.A, j1.B, Q, 0, 0, pb, i0, n0, plane);
+    planes_load_step<true, false>(j1.A, j1.B, Q, 1, 1, pb, i0, n0, plane);
+    __syncthreads();                                                     // the images are read to the end before the second product refills them
+    planes_product<true, false>(j1.A, j1.B, Q, smem, acc, pb, i0, n0, plane);
+    planes_store(acc, rv, j0.C, j0.Cf, j0.alpha, off0, plane);
+  } else if (job == 0) {                                                 // workgroup-uniform
+    planes_load_step<false, true>(j0.A, j0.B, Q, 0, 0, pb, i0, n0, plane);
+    planes_load_step<false, true>(j0.A, j0.B, Q, 1, 1, pb, i0, n0, plane);
+    if (j0.R) planes_residual(j0.R, j0.beta, rv, off0, plane);
+    planes_product<false, true>(j0.A, j0.B, Q, smem, acc, pb, i0, n0, plane);
+    planes_store(acc, rv, j0.C, j0.Cf, j0.alpha, off0, plane);
+  } else {
+    planes_load_step<true, false>(j1.A, j1.B, Q, 0, 0, pb, i0, n0, plane);
+    planes_load_step<true, false>(j1.A, j1.B, Q, 1, 1, pb, i0, n0, plane);
+    if (j1.R) planes_residual(j1.R, j1.beta, rv, off0, plane);
+    planes_product<true, false>(j1.A, j1.B, Q, smem, acc, pb, i0, n0, plane);
+    planes_store(acc, rv, j1.C, j1.Cf, j1.alpha, off0, plane);
   }
 }
 
@@ -255,23 +387,6 @@ __global__ void split_planes_kernel(const float4* __restrict__ x, __bf16* __rest
   *reinterpret_cast<uint2v*>(P + 4 * i) = h;
   *reinterpret_cast<uint2v*>(P + plane + 4 * i) = l;
 }
-// y += a x on planes
-__global__ void axpy_planes_kernel(__bf16* __restrict__ Y, const __bf16* __restrict__ X, float a, size_t n4, size_t plane) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float y[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < NPL; ++p) {
-    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(Y + p * plane + 4 * i), xv = *reinterpret_cast<const bf16x4*>(X + p * plane + 4 * i);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { y[e] += (float)yv[e]; x[e] += (float)xv[e]; }
-  }
-  uint2v h, l;
-  split4_b2(make_float4(fmaf(a, x[0], y[0]), fmaf(a, x[1], y[1]), fmaf(a, x[2], y[2]), fmaf(a, x[3], y[3])), h, l);
-  *reinterpret_cast<uint2v*>(Y + 4 * i) = h;
-  *reinterpret_cast<uint2v*>(Y + plane + 4 * i) = l;
-}
-
 // planes form of mm(): C (and, when Cf is given, its fp32 copy) = alpha op(A) op(B) + beta R;  R may be C itself
 int mm_p(const __bf16* A, bool ta, const __bf16* B, bool tb, __bf16* C, const __bf16* R, float* Cf, float alpha, float beta, int NB, void* st) {
   const size_t plane = (size_t)NB * CM * CM;
@@ -282,6 +397,14 @@ int mm_p(const __bf16* A, bool ta, const __bf16* B, bool tb, __bf16* C, const __
   else if (tb) hipLaunchKernelGGL((chain_bf3_kernel<false, true>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
   else hipLaunchKernelGGL((chain_bf3_kernel<false, false>), grid, block, 0, s, A, B, C, R, Cf, alpha, beta, NB, plane);
   SMML_LAUNCH_CHECK("smml_newton_schulz/chain_bf3");
+  return SMML_OK;
+}
+// two products in one launch (chain_bf3_dual_kernel): j0 is an A B^T product, j1 an A^T B one
+int mm_p2(const PJob& j0, const PJob& j1, int fuse, int NB, void* st) {
+  const size_t plane = (size_t)NB * CM * CM;
+  dim3 grid((unsigned)(NB * (fuse ? 16 : 32))), block(256);
+  hipLaunchKernelGGL(chain_bf3_dual_kernel, grid, block, 0, (hipStream_t)st, j0, j1, fuse, NB, plane);
+  SMML_LAUNCH_CHECK("smml_newton_schulz/chain_bf3_dual");
   return SMML_OK;
 }
 int split_p(const float* x, __bf16* P, int NB, void* st) {
@@ -322,6 +445,14 @@ int mm(const float* A, bool ta, const float* B, bool tb, float* C, const float* 
 }
 
 }  // namespace
+
+// exact-fp32 form: two products in one launch (chain_mm_dual_kernel)
+static int mm2(const FJob& j0, const FJob& j1, int fuse, int NB, void* st) {
+  dim3 grid((unsigned)(NB * (fuse ? 16 : 32))), block(256);
+  hipLaunchKernelGGL(chain_mm_dual_kernel, grid, block, 0, (hipStream_t)st, j0, j1, fuse, NB);
+  SMML_LAUNCH_CHECK("smml_newton_schulz/chain_mm_dual");
+  return SMML_OK;
+}
 
 extern "C" {
 
@@ -376,16 +507,12 @@ static int ns_bwd_planes(const float* saved, const float* dz_in, float* dx, floa
     const __bf16* z = k == 0 ? z0p : slot;
     const __bf16 *xz = slot + P, *a = slot + 2 * P, *b = slot + 3 * P;
     __bf16* dzn = k == 0 ? dz0p : pp[k & 1];
-    SMML_TRY(mm_p(dz, false, b, true, dzk, dz, nullptr, -0.25f, 3.25f, NB, stream));
-    SMML_TRY(mm_p(z, true, dz, false, db, nullptr, nullptr, -0.25f, 0.f, NB, stream));
-    SMML_TRY(mm_p(db, false, a, true, dxz, db, nullptr, -1.f, 15.f, NB, stream));
-    SMML_TRY(mm_p(xz, true, db, false, da, nullptr, nullptr, -1.f, 0.f, NB, stream));
-    SMML_TRY(mm_p(da, false, xz, true, t, dxz, nullptr, -1.f, 1.f, NB, stream));
-    SMML_TRY(mm_p(xz, true, da, false, t, t, nullptr, -1.f, 1.f, NB, stream));
-    hipLaunchKernelGGL(axpy_planes_kernel, dim3((unsigned)((plane / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, da, 7.f, plane / 4, plane);
-    SMML_LAUNCH_CHECK("smml_newton_schulz_bwd/axpy_planes");
-    SMML_TRY(mm_p(t, false, z, true, dxp, (k == iters - 1) ? nullptr : dxp, k == 0 ? dx : nullptr, 1.f, 1.f, NB, stream));
-    SMML_TRY(mm_p(xp, true, t, false, dzn, dzk, k == 0 ? dz0 : nullptr, 1.f, 1.f, NB, stream));
+    // four launches per iteration: [dzk | db], [dxz | da], t (two products + two residuals fused), [dx | dz]
+    SMML_TRY(mm_p2(PJob{dz, b, dzk, dz, nullptr, -0.25f, 3.25f}, PJob{z, dz, db, nullptr, nullptr, -0.25f, 0.f}, 0, NB, stream));
+    SMML_TRY(mm_p2(PJob{db, a, dxz, db, nullptr, -1.f, 15.f}, PJob{xz, db, da, nullptr, nullptr, -1.f, 0.f}, 0, NB, stream));
+    SMML_TRY(mm_p2(PJob{da, xz, t, dxz, nullptr, -1.f, 1.f}, PJob{xz, da, nullptr, da, nullptr, -1.f, 7.f}, 1, NB, stream));
+    SMML_TRY(mm_p2(PJob{t, z, dxp, (k == iters - 1) ? nullptr : dxp, k == 0 ? dx : nullptr, 1.f, 1.f},
+                   PJob{xp, t, dzn, dzk, k == 0 ? dz0 : nullptr, 1.f, 1.f}, 0, NB, stream));
     dz = dzn;
   }
   return SMML_OK;
@@ -434,6 +561,17 @@ int smml_newton_schulz_bwd(const float* x, const float* z0, const float* saved, 
     const float* z = k == 0 ? z0 : slot;
     const float *xz = slot + per, *a = slot + 2 * per, *b = slot + 3 * per;
     float* dzn = k == 0 ? dz0 : pp[k & 1];
+    auto al16f = [](const void* p) { return (((size_t)p) & 15) == 0; };
+    if (chain_form(m, 0) == 1 && al16f(x) && al16f(saved) && al16f(scratch) && al16f(dz_in) && al16f(dx) && al16f(dz0)) {
+      // four launches per iteration: [dzk | db], [dxz | da], t (two products + two residuals fused), [dx | dz]
+      // (the exact form is bound by the fp32 matrix pipe, 7.8 us per product: pairing buys it only the ~5 us launch boundaries)
+      SMML_TRY(mm2(FJob{dz, b, dzk, dz, -0.25f, 3.25f}, FJob{z, dz, db, nullptr, -0.25f, 0.f}, 0, NB, stream));
+      SMML_TRY(mm2(FJob{db, a, dxz, db, -1.f, 15.f}, FJob{xz, db, da, nullptr, -1.f, 0.f}, 0, NB, stream));
+      SMML_TRY(mm2(FJob{da, xz, t, dxz, -1.f, 1.f}, FJob{xz, da, nullptr, da, -1.f, 7.f}, 1, NB, stream));
+      SMML_TRY(mm2(FJob{t, z, dx, (k == iters - 1) ? nullptr : dx, 1.f, 1.f}, FJob{x, t, dzn, dzk, 1.f, 1.f}, 0, NB, stream));
+      dz = dzn;
+      continue;
+    }
     SMML_TRY(mm(dz, false, b, true, dzk, dz, -0.25f, 3.25f, NB, m, stream));
     SMML_TRY(mm(z, true, dz, false, db, nullptr, -0.25f, 0.f, NB, m, stream));
     SMML_TRY(mm(db, false, a, true, dxz, db, -1.f, 15.f, NB, m, stream));

@@ -402,7 +402,11 @@ class _Attention16KeysLong(torch.autograd.Function):
         if dqkv is None:                                   # nothing after this stage contributed: start the buffer here
             dqkv = torch.zeros_like(qkv)
             dv_acc = True
-        if dout is None:
+        if dout is None:                                   # this product has no gradient: its parts of the buffer must still be defined
+            parts = dqkv.view(b, n, 3, hd)
+            parts[:, :, 1].zero_()
+            if not dv_acc:
+                parts[:, :, 2].zero_()
             return None, dqkv, None, None, None
         dout = _c(dout)
         dql = torch.empty_like(ql)
@@ -445,7 +449,9 @@ class _ResConv16(torch.autograd.Function):
         if dqkv is None:
             dqkv = torch.zeros_like(qkv)
         dw = None
-        if dres is not None:
+        if dres is None:                                   # no gradient through the convolution: the v part must still be defined
+            dqkv.view(b, n, 3, hd)[:, :, 2].zero_()
+        else:
             dres = dres if dres.is_contiguous() else dres.contiguous()
             L = capi.lib()
             capi.check(L.smml_resconv_b16(_bptr(dres), capi.fptr(w2), _part(dqkv, 2, hd), b, heads, n, d, kw, n * hd, hd, n * c, c, 1,
