@@ -73,6 +73,11 @@ void smml_gemm_set_small_tile(int v);
  * products with bf16 bags (BASELINE configs 2 / 4): activations stay bf16 end to end. */
 int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                   long long ldc, int trans, int out_bf16, int splitk, void* stream);
+/* nb problems of that shape at element strides sa / sb / sc (multiples of 8) between them; sc = 0 (fp32 output only): the problems' products
+ * are ADDED into the one zeroed output, like split-K slices.  A bag's n real rows are addressed in place as one batch item (the zero rows
+ * the reference pads in front of a bag, NystromAttention.py:82, are never multiplied). */
+int smml_gemm_b16_batched(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
+                          long long ldc, int trans, int out_bf16, int splitk, int nb, long long sa, long long sb, long long sc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim C (<= 1024) of x [R, C]; saves mean / rstd per row.

@@ -29,6 +29,8 @@ struct B16Args {
   int M, N, K;
   long long lda, ldb, ldc;
   int splitk, tiles_m, tiles_n;
+  int atomic;                    // add the result into C (split-K slices, batches that share one output)
+  long long sa, sb, sc;          // batch strides in elements (gridDim.z problems; sc = 0 with split-K: the batches add up in one output)
 };
 
 #ifndef SMML_B16_MINBLOCKS
@@ -50,6 +52,9 @@ __global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Ar
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * GM, n0 = tn * GN;
   const int ks = blockIdx.y;
+  g.A += (long long)blockIdx.z * g.sa;
+  g.B += (long long)blockIdx.z * g.sb;
+  g.C = OUT_BF16 ? (void*)(reinterpret_cast<__bf16*>(g.C) + (long long)blockIdx.z * g.sc) : (void*)(reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sc);
   const int ktiles = (g.K + GK - 1) / GK;
   const int tps = (ktiles + g.splitk - 1) / g.splitk;
   const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
@@ -176,13 +181,13 @@ __global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Ar
       const int n = n0 + wn * 64 + ni * 32 + c;
       const int mb = m0 + wm * 64 + mi * 32;
       if (!interior && n >= g.N) continue;
-      const float bv = (g.bias && ks == 0) ? g.bias[n] : 0.f;
+      const float bv = (g.bias && ks == 0 && (g.sc != 0 || blockIdx.z == 0)) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + acc_row(r, hf);
         if (!interior && m >= g.M) continue;
         const float v = acc[mi][ni][r] + bv;
-        if (g.splitk > 1) atomicAdd(&reinterpret_cast<float*>(g.C)[(long long)m * g.ldc + n], v);
+        if (g.atomic) atomicAdd(&reinterpret_cast<float*>(g.C)[(long long)m * g.ldc + n], v);
         else reinterpret_cast<float*>(g.C)[(long long)m * g.ldc + n] = v;
       }
     }
@@ -193,10 +198,25 @@ __global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Ar
 // C = A B^T (trans = 0: A [M, K], B [N, K], leading dimensions lda / ldb in elements) or C = A^T B (trans = 1: A [K, M], B [K, N]);
 // A, B bf16; C bf16 (out_bf16 = 1, ldc in bf16 elements) or fp32; bias (fp32 [N], may be null) is added once.  splitk > 1: fp32 output only,
 // the K range is cut into splitk slices whose partial products are ADDED to C atomically - the caller zeroes C first.
+extern "C" int smml_gemm_b16_batched(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
+                                     long long ldb, long long ldc, int trans, int out_bf16, int splitk, int nb, long long sa, long long sb,
+                                     long long sc, void* stream);
 extern "C" int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
                              long long ldb, long long ldc, int trans, int out_bf16, int splitk, void* stream) {
+  return smml_gemm_b16_batched(A, B, C, bias, M, N, K, lda, ldb, ldc, trans, out_bf16, splitk, 1, 0, 0, 0, stream);
+}
+
+// nb problems of the same shape at element strides sa / sb / sc between them.  sc = 0 needs an fp32 output: the problems' products are then
+// ADDED into the one (zeroed) output atomically, like split-K slices - dW = sum over bags of dy_bag^T x_bag with each bag's rows addressed in
+// place.  This is how the front padding of a bag (models/NystromAttention.py:82) stays out of memory: a bag's n real rows are a batch item
+// whose output lands pad rows into its n'-row block.
+extern "C" int smml_gemm_b16_batched(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
+                                     long long ldb, long long ldc, int trans, int out_bf16, int splitk, int nb, long long sa, long long sb,
+                                     long long sc, void* stream) {
   SMML_REQUIRE(A && B && C, "smml_gemm_b16: null operand");
   SMML_REQUIRE(M > 0 && N > 0 && K > 0, "smml_gemm_b16: non-positive size (M=%d N=%d K=%d)", M, N, K);
+  SMML_REQUIRE(nb >= 1 && nb <= 65535 && (sa % 8) == 0 && (sb % 8) == 0 && (sc % 8) == 0, "smml_gemm_b16: bad batch (nb=%d; strides must be multiples of 8)", nb);
+  SMML_REQUIRE(!(nb > 1 && sc == 0 && out_bf16), "smml_gemm_b16: batches that add up need an fp32 output");
   SMML_REQUIRE(splitk >= 1 && splitk <= 65535, "smml_gemm_b16: bad splitk %d", splitk);
   SMML_REQUIRE(!(splitk > 1 && out_bf16), "smml_gemm_b16: split-K accumulates in an fp32 output");
   auto al16 = [](const void* p) { return (((size_t)p) & 15) == 0; };
@@ -207,8 +227,11 @@ extern "C" int smml_gemm_b16(const void* A, const void* B, void* C, const float*
   if (out_bf16) SMML_REQUIRE((N % 8) == 0 && (ldc % 8) == 0 && al16(C), "smml_gemm_b16: a bf16 result needs N %% 8 == 0, ldc %% 8 == 0 and a 16-byte aligned C (N=%d)", N);
   const long long tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN;
   SMML_REQUIRE(tm * tn < (1LL << 31), "smml_gemm_b16: grid too large");
-  B16Args g{reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(B), C, bias, M, N, K, lda, ldb, ldc, splitk, (int)tm, (int)tn};
-  dim3 grid((unsigned)(tm * tn), (unsigned)splitk), block(256);
+  // batches that add into one output take the atomic path like split-K slices: the kernel's "splitk > 1" test covers both
+  const int atomic_batches = (nb > 1 && sc == 0) ? 1 : 0;
+  B16Args g{reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(B), C, bias, M, N, K, lda, ldb, ldc, splitk, (int)tm, (int)tn,
+            (splitk > 1 || atomic_batches) ? 1 : 0, sa, sb, sc};
+  dim3 grid((unsigned)(tm * tn), (unsigned)splitk, (unsigned)nb), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (trans) {
     if (out_bf16) hipLaunchKernelGGL((gemm_b16_kernel<true, true>), grid, block, 0, st, g);

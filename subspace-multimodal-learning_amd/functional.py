@@ -9,7 +9,7 @@ import math
 import os
 from typing import Optional
 
-import ctypes as C
+import ctypes as C_
 
 import torch
 
@@ -236,12 +236,17 @@ def _bptr(t: torch.Tensor):
     return capi.ptr(t)
 
 
-def gemm_b16(A, B, C, *, M, N, K, lda, ldb, ldc, trans=False, bias=None, splitk=1):
-    """C = A B^T (trans False: A [M, K], B [N, K]) or A^T B (trans True: A [K, M], B [K, N]); A, B bf16, C bf16 or fp32."""
+def gemm_b16(A, B, C, *, M, N, K, lda, ldb, ldc, trans=False, bias=None, splitk=1, nb=1, sa=0, sb=0, sc=0, a_off=0, b_off=0, c_off=0):
+    """C = A B^T (trans False: A [M, K], B [N, K]) or A^T B (trans True: A [K, M], B [K, N]); A, B bf16, C bf16 or fp32.  nb problems at
+    element strides sa / sb / sc (sc = 0: they add up in one zeroed fp32 output); *_off: element offsets of the first problem."""
     if C.dtype not in (torch.bfloat16, torch.float32):
         raise RuntimeError(f"gemm_b16: output dtype {C.dtype}")
-    capi.check(capi.lib().smml_gemm_b16(_bptr(A), _bptr(B), capi.ptr(C), capi.fptr(bias), M, N, K, lda, ldb, ldc, int(trans),
-                                        int(C.dtype == torch.bfloat16), splitk, capi.stream()), "gemm_b16")
+    _bptr(A), _bptr(B), capi.ptr(C)                            # device / contiguity checks
+    pa = C_.c_void_p(A.data_ptr() + 2 * a_off)
+    pb = C_.c_void_p(B.data_ptr() + 2 * b_off)
+    pc = C_.c_void_p(C.data_ptr() + C.element_size() * c_off)
+    capi.check(capi.lib().smml_gemm_b16_batched(pa, pb, pc, capi.fptr(bias), M, N, K, lda, ldb, ldc, int(trans),
+                                                int(C.dtype == torch.bfloat16), splitk, nb, sa, sb, sc, capi.stream()), "gemm_b16")
 
 
 def _splitk_b16(out_rows: int, out_cols: int, k: int) -> int:
@@ -252,17 +257,26 @@ def _splitk_b16(out_rows: int, out_cols: int, k: int) -> int:
 
 class _LinearB16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, out_bf16):
+    def forward(ctx, x, weight, bias, out_bf16, skip):
         if x.dtype != torch.bfloat16:
             raise RuntimeError("linear_b16: x must be bf16 (the caller casts once)")
         x = x if x.is_contiguous() else x.contiguous()
         wb = weight.detach().to(torch.bfloat16)                 # the parameter stays fp32; [N, K] bf16 is 1.5 MB at most here
         K = x.shape[-1]
-        M = x.numel() // K
         N = weight.shape[0]
-        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-        gemm_b16(x, wb, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=_c(bias) if bias is not None else None)
+        if skip:
+            if x.dim() != 3 or not 0 < skip < x.shape[1]:
+                raise RuntimeError("linear_b16: skip needs x [b, rows, K] with 0 < skip < rows")
+            b, rows = x.shape[0], x.shape[1]
+            y = torch.empty(b, rows - skip, N, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+            gemm_b16(x, wb, y, M=rows - skip, N=N, K=K, lda=K, ldb=K, ldc=N, bias=_c(bias) if bias is not None else None, nb=b,
+                     sa=rows * K, sc=(rows - skip) * N, a_off=skip * K)
+        else:
+            M = x.numel() // K
+            y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+            gemm_b16(x, wb, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=_c(bias) if bias is not None else None)
         ctx.has_bias = bias is not None
+        ctx.skip = skip
         ctx.save_for_backward(x, wb)
         return y
 
@@ -270,14 +284,29 @@ class _LinearB16(torch.autograd.Function):
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
         K = x.shape[-1]
-        M = x.numel() // K
         N = wb.shape[0]
+        skip = ctx.skip
+        rows_y = dy.numel() // N
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(_c(dy).reshape(1, M, N))[0]
+            db = colsum(_c(dy).reshape(1, rows_y, N))[0]
         dyb = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
         dyb = dyb if dyb.is_contiguous() else dyb.contiguous()
         dx = dw = None
+        if skip:
+            b, rows = x.shape[0], x.shape[1]
+            n = rows - skip
+            if ctx.needs_input_grad[0]:
+                wt = wb.t().contiguous()
+                dx = torch.empty_like(x)
+                dx[:, :skip].zero_()                                # the skipped rows took no part
+                gemm_b16(dyb, wt, dx, M=n, N=K, K=N, lda=N, ldb=N, ldc=K, nb=b, sa=n * N, sc=rows * K, c_off=skip * K)
+            if ctx.needs_input_grad[1]:
+                dw = _ZEROS.zeros((N, K), x.device)
+                gemm_b16(dyb, x, dw, M=N, N=K, K=n, lda=N, ldb=K, ldc=K, trans=True, splitk=max(1, _splitk_b16(N, K, b * n) // b), nb=b,
+                         sa=n * N, sb=rows * K, sc=0, b_off=skip * K)
+            return dx, dw, db, None, None
+        M = x.numel() // K
         if ctx.needs_input_grad[0]:
             wt = wb.t().contiguous()                            # [K, N]: dx = dy (W^T)^T is the k-contiguous form again
             dx = torch.empty_like(x)
@@ -285,13 +314,14 @@ class _LinearB16(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _ZEROS.zeros((N, K), x.device)
             gemm_b16(dyb, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=_splitk_b16(N, K, M))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear_b16(x, weight, bias=None, out_bf16: bool = True):
+def linear_b16(x, weight, bias=None, out_bf16: bool = True, skip: int = 0):
     """x W^T (+ bias) with bf16 operands in memory and fp32 accumulation; x bf16, weight / bias fp32 parameters (gradients fp32), the
-    result bf16 (out_bf16) or fp32; dx is bf16."""
-    return _LinearB16.apply(x, weight, bias, out_bf16)
+    result bf16 (out_bf16) or fp32; dx is bf16.  skip > 0 (x [b, rows, K]): the first `skip` rows of every bag are left out - the result
+    is [b, rows - skip, N] (the zero rows the Nystrom block pads in front of a bag never reach the output projection)."""
+    return _LinearB16.apply(x, weight, bias, out_bf16, skip)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -317,34 +347,38 @@ def _qkv_dims(qkv, heads):
 def _part(t, i, hd):
     """device pointer of part i (0 q, 1 k, 2 v) of a qkv-shaped bf16 buffer (same strides, shifted base)"""
     _bptr(t)
-    return C.c_void_p(t.data_ptr() + 2 * i * hd)
+    return C_.c_void_p(t.data_ptr() + 2 * i * hd)
 
 
 class _QKVProject16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, heads, l):
+    def forward(ctx, x, weight, heads, l, pad):
         if x.dtype != torch.bfloat16:
             raise RuntimeError("qkv_project16: x must be bf16")
         x = x if x.is_contiguous() else x.contiguous()
         wb = weight.detach().to(torch.bfloat16)
-        b, n, K = x.shape
+        b, n0, K = x.shape
+        n = n0 + pad                                               # rows of a bag in the buffers: `pad` zero rows in front
         N = weight.shape[0]
         d = N // (3 * heads)
         qkv = torch.empty(b, n, N, device=x.device, dtype=torch.bfloat16)
-        gemm_b16(x, wb, qkv, M=b * n, N=N, K=K, lda=K, ldb=K, ldc=N)
+        if pad:
+            qkv[:, :pad].zero_()                                   # x W^T of a zero row (the projection has no bias)
+        gemm_b16(x, wb, qkv, M=n0, N=N, K=K, lda=K, ldb=K, ldc=N, nb=b, sa=n0 * K, sc=n * N, c_off=pad * N)
         m = n // l
         ql = torch.empty(b, heads, m, d, device=x.device, dtype=torch.float32)
         kl = torch.empty_like(ql)
         capi.check(capi.lib().smml_segment_mean_b16(_bptr(qkv), capi.fptr(ql), capi.fptr(kl), b, n, l, heads, d, capi.stream()), "segment_mean_b16")
-        ctx.cfg = (heads, l, d)
+        ctx.cfg = (heads, l, d, pad)
         ctx.save_for_backward(x, wb)
         return qkv, ql, kl
 
     @staticmethod
     def backward(ctx, dqkv, dql, dkl):
         x, wb = ctx.saved_tensors
-        heads, l, d = ctx.cfg
-        b, n, K = x.shape
+        heads, l, d, pad = ctx.cfg
+        b, n0, K = x.shape
+        n = n0 + pad
         N = wb.shape[0]
         if dqkv is None:
             dqkv = torch.zeros(b, n, N, device=x.device, dtype=torch.bfloat16)
@@ -357,20 +391,22 @@ class _QKVProject16(torch.autograd.Function):
                                                                 capi.fptr(_c(dkl) if dkl is not None else zero), b, n, l, heads, d,
                                                                 capi.stream()), "segment_mean_bwd_add_b16")
         dx = dw = None
-        M = b * n
         if ctx.needs_input_grad[0]:
             wt = wb.t().contiguous()
             dx = torch.empty_like(x)
-            gemm_b16(dqkv, wt, dx, M=M, N=K, K=N, lda=N, ldb=N, ldc=K)
+            gemm_b16(dqkv, wt, dx, M=n0, N=K, K=N, lda=N, ldb=N, ldc=K, nb=b, sa=n * N, sc=n0 * K, a_off=pad * N)
         if ctx.needs_input_grad[1]:
             dw = _ZEROS.zeros((N, K), x.device)
-            gemm_b16(dqkv, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=_splitk_b16(N, K, M))
-        return dx, dw, None, None
+            gemm_b16(dqkv, x, dw, M=N, N=K, K=n0, lda=N, ldb=K, ldc=K, trans=True, splitk=max(1, _splitk_b16(N, K, b * n0) // b), nb=b,
+                     sa=n * N, sb=n0 * K, sc=0, a_off=pad * N)
+        return dx, dw, None, None, None
 
 
-def qkv_project16(x, weight, heads: int, l: int):
-    """x bf16 [b, n, K] -> (qkv bf16 [b, n, 3 h d] = x W^T, ql, kl fp32 [b, h, n / l, d] = means of q / k over l consecutive tokens)"""
-    return _QKVProject16.apply(x, weight, heads, l)
+def qkv_project16(x, weight, heads: int, l: int, pad: int = 0):
+    """x bf16 [b, n0, K] -> (qkv bf16 [b, n, 3 h d], n = pad + n0: `pad` zero rows in front of every bag (NystromAttention.py:82), then x W^T;
+    ql, kl fp32 [b, h, n / l, d] = means of q / k over l consecutive tokens).  The padded bag is never materialised: the GEMMs address
+    a bag's real rows in place."""
+    return _QKVProject16.apply(x, weight, heads, l, pad)
 
 
 class _Attention16KeysLong(torch.autograd.Function):

@@ -221,10 +221,7 @@ class NystromAttention(nn.Module):
         wo, bo = self.to_out[0].weight, self.to_out[0].bias
         if not fp16 and B16_STORAGE and (not self.residual or self.res_conv.weight.shape[2] == 33):
             # bf16 storage end to end (functional.py, "bf16-storage pipeline"): q / k / v live in the projection's token-major bf16 buffer
-            x = x.to(torch.bfloat16)
-            if pad:
-                x = F.pad(x, (0, 0, pad, 0), value=0)
-            qkv, ql, kl = Fh.qkv_project16(x, self.to_qkv.weight, h, l)
+            qkv, ql, kl = Fh.qkv_project16(x.to(torch.bfloat16), self.to_qkv.weight, h, l, pad)   # the front padding (:82) lives in the row map
             a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                         # [b, h, m, m], exact fp32
             fork = _PinvFork(a2)                                                                # beside attn3 v and the residual convolution
             z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale, reduced=True), a2)
@@ -235,8 +232,7 @@ class NystromAttention(nn.Module):
             fork.join(z)
             w = Fh.matmul4(z, right)                                                            # z (attn3 v)          [b, h, m, d]
             out = Fh.attention16_queries_long(qkv, kl, w, res, heads=h, scale=sc)               # softmax(q kl^T) w + res, bf16
-            out = Fh.linear_b16(out, wo, bo, out_bf16=False)
-            return self.to_out[1](out)[:, -n:]
+            return self.to_out[1](Fh.linear_b16(out, wo, bo, out_bf16=False, skip=pad))         # [b, n, dim]: the padded rows are not projected
         b16 = not fp16 and B16_PROJECTIONS                      # bf16 mode: the projections read and write bf16 (csrc/gemm_b16.hip)
         if b16:
             x = x.to(torch.bfloat16)

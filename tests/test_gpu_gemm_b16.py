@@ -81,3 +81,23 @@ def test_linear_b16_forward_backward(cuda, out_bf16):
     _check(xd.grad, xr.grad, True, "dx")
     _check(wd.grad, wr.grad, False, "dw")
     _check(bd.grad, br.grad, False, "db")
+
+
+def test_gemm_b16_batched_row_maps(cuda):
+    """Batch items addressed in place (the bags of a padded buffer): NT with offset / strided outputs, TN whose batches add up in one output."""
+    b, n0, pad, K, N = 3, 200, 56, 64, 136
+    n = n0 + pad
+    x = _rand((b, n0, K), 11); w = _rand((N, K), 12)
+    y = torch.full((b, n, N), float("nan"), device=cuda, dtype=torch.bfloat16)
+    Fh.gemm_b16(x.to(cuda), w.to(cuda), y, M=n0, N=N, K=K, lda=K, ldb=K, ldc=N, nb=b, sa=n0 * K, sc=n * N, c_off=pad * N)
+    ref = x.double() @ w.double().t()
+    _check(y[:, pad:], ref, True, "batched nt")
+    assert torch.isnan(y[:, :pad].float()).all()                      # rows in front of a bag are not touched
+    g = _rand((b, n, N), 13)
+    dw = torch.zeros(N, K, device=cuda)
+    Fh.gemm_b16(g.to(cuda), x.to(cuda), dw, M=N, N=K, K=n0, lda=N, ldb=K, ldc=K, trans=True, splitk=2, nb=b, sa=n * N, sb=n0 * K, sc=0,
+                a_off=pad * N)
+    refw = torch.einsum("bnm,bnk->mk", g[:, pad:].double(), x.double())
+    _check(dw, refw, False, "batched tn")
+    with pytest.raises(RuntimeError):                                  # batches that add up need an fp32 output
+        Fh.gemm_b16(g.to(cuda), x.to(cuda), dw.to(torch.bfloat16), M=N, N=K, K=n0, lda=N, ldb=K, ldc=K, trans=True, nb=b, sa=n * N, sb=n0 * K, sc=0)
