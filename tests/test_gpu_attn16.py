@@ -144,12 +144,13 @@ def test_nystrom_16bit_mode_follows_the_bag_dtype(cuda):
         assert torch.equal(mod(x.to(torch.bfloat16)), mod(x.to(torch.bfloat16).float()))
 
 
-@pytest.mark.parametrize("cfg", [dict(residual=False), dict(num_landmarks=64), dict(heads=4, dim=256), dict(x_fp32=True), dict(B=3, n=513)])
+@pytest.mark.parametrize("cfg", [dict(residual=False), dict(num_landmarks=64), dict(heads=4, dim=256), dict(x_fp32=True), dict(B=3, n=513),
+                                 dict(num_landmarks=96, heads=2, dim=128, n=500), dict(B=1, n=40, num_landmarks=48, heads=1, dim=64)])
 def test_nystrom_bf16_storage_configurations(cuda, cfg):
     """The bf16-storage pipeline (functional.py: qkv_project16 -> attention16_keys_long -> resconv16 -> attention16_queries_long) in the
     configurations the main comparison does not visit: no residual convolution (attention16_keys_long then WRITES dv), 64 landmarks (the
     pseudo-inverse chain through the generic GEMM, 64 keys on the queries-long side), 4 heads, an fp32 bag with compute_dtype='bf16' (the
-    input gradient comes back as fp32), three bags of a length that needs padding - each against the fp64 oracle, and each checked to have
+    input gradient comes back as fp32), three bags of a length that needs padding, landmark counts that leave ragged key tiles (96, 48), one head, a bag shorter than the landmark count - each against the fp64 oracle, and each checked to have
     taken the bf16-storage branch."""
     import importlib
     cfg = dict(cfg)
