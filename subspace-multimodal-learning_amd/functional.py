@@ -99,7 +99,11 @@ class _ZeroPool:
         n = 1
         for d in shape:
             n *= d
-        if n == 0 or n > self.LIMIT or torch.device(device).type != "cuda" or not self.enabled:
+        # Under hipGraph capture a pooled slice would be zero only in the capture run: the slab's fill is not part of the graph, so a
+        # replay would accumulate onto the previous replay's sums.  torch.zeros inside a capture allocates from the graph's private pool
+        # and its fill IS a node of the graph - re-zeroed by every replay.
+        if (n == 0 or n > self.LIMIT or torch.device(device).type != "cuda" or not self.enabled
+                or torch.cuda.is_current_stream_capturing()):
             return torch.zeros(shape, device=device, dtype=torch.float32)
         key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
         buf, used = self.slabs.get(key, (None, self.SLAB))

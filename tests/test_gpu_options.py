@@ -229,3 +229,39 @@ def test_dropout_masks_of_graph_replays_are_uncorrelated(cuda):
                 lo, hi = max(0, shift), min(n, n + shift)
                 agree = float((masks[a][lo - shift:hi - shift] == masks[b][lo:hi]).float().mean())
                 assert abs(agree - 0.5) < 0.01, f"offsets {a},{b} shift {shift}: masks agree on {agree:.3f} of the elements"
+
+
+def test_accumulated_gradients_under_graph_replay(cuda):
+    """Weight / bias gradients are accumulated with atomics into zero-initialised buffers; the buffers of small tensors come from a pre-zeroed
+    pool (functional._ZeroPool).  Inside a hipGraph capture the pool must not be used - a pooled slice is zero only once - so every replay of a
+    captured forward + backward has to return the same gradients as an eager call, not a running sum."""
+    import torch
+    Fh = smml.functional
+    gen = torch.Generator().manual_seed(21)
+    x = (torch.randn(4, 300, 128, generator=gen) * 0.5).to(cuda)
+    w = (torch.randn(64, 128, generator=gen) * 0.1).to(cuda).requires_grad_()
+    bias = (torch.randn(64, generator=gen) * 0.1).to(cuda).requires_grad_()
+    gam = torch.ones(64, device=cuda, requires_grad=True); bet = torch.zeros(64, device=cuda, requires_grad=True)
+    outs = [torch.zeros_like(t) for t in (w, bias, gam, bet)]
+
+    def step():
+        for t in (w, bias, gam, bet):
+            t.grad = None
+        y = Fh.layer_norm(Fh.linear(x, w, bias), gam, bet)
+        (y * y).sum().backward()
+        for o, t in zip(outs, (w, bias, gam, bet)):
+            o.copy_(t.grad)
+
+    step(); torch.cuda.synchronize()
+    ref = [o.clone() for o in outs]
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    for r in range(3):
+        g.replay(); torch.cuda.synchronize()
+        for name, o, e in zip(("dW", "dbias", "dgamma", "dbeta"), outs, ref):
+            assert_close(f"{name} of graph replay {r} vs eager", o, e, 1e-5)
