@@ -68,11 +68,14 @@ void smml_gemm_set_small_tile(int v);
  *   trans = 0   C[M, N] = A[M, K] B[N, K]^T   (row strides lda / ldb >= K, in elements; K % 8 == 0)
  *   trans = 1   C[M, N] = A[K, M]^T B[K, N]   (row strides lda >= M, ldb >= N; M % 8 == 0, N % 8 == 0)
  * bias (fp32 [N] or NULL) is added once.  splitk > 1 (fp32 output only): the K range is cut into slices whose partial products are
- * ADDED to C atomically - the caller zeroes C.  Operands 16-byte aligned, lda / ldb multiples of 8.
+ * ADDED to C atomically - the caller zeroes C; splitk = 0: chosen by the library (one round of workgroups; C must then be zeroed too).  Operands 16-byte aligned, lda / ldb multiples of 8.
  * The projections of the Nystrom block's bf16 compute mode (models/NystromAttention.py:88 to_qkv, :147 to_out) and their backward
  * products with bf16 bags (BASELINE configs 2 / 4): activations stay bf16 end to end. */
 int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                   long long ldc, int trans, int out_bf16, int splitk, void* stream);
+/* tile selection of the bf16-storage GEMM: 0 automatic (the 256-row, eight-wave tile where its grid still covers the chip), 1 the
+ * 128 x 128 tile only, 2 the 256-row tile wherever M >= 256 and N >= 128 (test / measurement switch; SMML_B16_TILE presets it). */
+void smml_gemm_b16_set_tile(int mode);
 /* nb problems of that shape at element strides sa / sb / sc (multiples of 8) between them; sc = 0 (fp32 output only): the problems' products
  * are ADDED into the one zeroed output, like split-K slices.  A bag's n real rows are addressed in place as one batch item (the zero rows
  * the reference pads in front of a bag, NystromAttention.py:82, are never multiplied). */

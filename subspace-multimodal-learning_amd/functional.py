@@ -253,12 +253,6 @@ def gemm_b16(A, B, C, *, M, N, K, lda, ldb, ldc, trans=False, bias=None, splitk=
                                                 int(C.dtype == torch.bfloat16), splitk, nb, sa, sb, sc, capi.stream()), "gemm_b16")
 
 
-def _splitk_b16(out_rows: int, out_cols: int, k: int) -> int:
-    # three 256-thread workgroups fit a CU: aim at one full round of 768 (1008 of them ran as one round and a third)
-    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    return int(max(1, min(768 // max(tiles, 1), (k + 511) // 512)))
-
-
 class _LinearB16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, out_bf16, skip):
@@ -307,7 +301,7 @@ class _LinearB16(torch.autograd.Function):
                 gemm_b16(dyb, wt, dx, M=n, N=K, K=N, lda=N, ldb=N, ldc=K, nb=b, sa=n * N, sc=rows * K, c_off=skip * K)
             if ctx.needs_input_grad[1]:
                 dw = _ZEROS.zeros((N, K), x.device)
-                gemm_b16(dyb, x, dw, M=N, N=K, K=n, lda=N, ldb=K, ldc=K, trans=True, splitk=max(1, _splitk_b16(N, K, b * n) // b), nb=b,
+                gemm_b16(dyb, x, dw, M=N, N=K, K=n, lda=N, ldb=K, ldc=K, trans=True, splitk=0, nb=b,
                          sa=n * N, sb=rows * K, sc=0, b_off=skip * K)
             return dx, dw, db, None, None
         M = x.numel() // K
@@ -317,7 +311,7 @@ class _LinearB16(torch.autograd.Function):
             gemm_b16(dyb, wt, dx, M=M, N=K, K=N, lda=N, ldb=N, ldc=K)
         if ctx.needs_input_grad[1]:
             dw = _ZEROS.zeros((N, K), x.device)
-            gemm_b16(dyb, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=_splitk_b16(N, K, M))
+            gemm_b16(dyb, x, dw, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, trans=True, splitk=0)
         return dx, dw, db, None, None
 
 
@@ -401,7 +395,7 @@ class _QKVProject16(torch.autograd.Function):
             gemm_b16(dqkv, wt, dx, M=n0, N=K, K=N, lda=N, ldb=N, ldc=K, nb=b, sa=n * N, sc=n0 * K, a_off=pad * N)
         if ctx.needs_input_grad[1]:
             dw = _ZEROS.zeros((N, K), x.device)
-            gemm_b16(dqkv, x, dw, M=N, N=K, K=n0, lda=N, ldb=K, ldc=K, trans=True, splitk=max(1, _splitk_b16(N, K, b * n0) // b), nb=b,
+            gemm_b16(dqkv, x, dw, M=N, N=K, K=n0, lda=N, ldb=K, ldc=K, trans=True, splitk=0, nb=b,
                      sa=n * N, sb=n0 * K, sc=0, a_off=pad * N)
         return dx, dw, None, None, None
 

@@ -22,13 +22,16 @@ def timeit(fn, n=20):
 def rnd(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 
 
-for name, M, N, K, trans, obf, sk in [("qkv fwd  NT", R, 1536, 512, False, True, 1), ("out fwd  NT", R, 512, 512, False, False, 1),
-                                      ("dx qkv   NT", R, 512, 1536, False, True, 1), ("dx out   NT", R, 512, 512, False, True, 1),
-                                      ("dW qkv   TN", 1536, 512, R, True, False, 21), ("dW out   TN", 512, 512, R, True, False, 64),
-                                      ("4096^3   NT", 4096, 4096, 4096, False, True, 1)]:
-    if trans: a, b = rnd(K, M), rnd(K, N)
-    else: a, b = rnd(M, K), rnd(N, K)
-    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16 if obf else torch.float32)
-    us = timeit(lambda: Fh.gemm_b16(a, b, c, M=M, N=N, K=K, lda=a.shape[1], ldb=b.shape[1], ldc=N, trans=trans, splitk=sk))
-    byts = (a.numel() + b.numel()) * 2 + c.numel() * c.element_size()
-    print(f"{name}  M={M} N={N} K={K} splitk={sk}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  {byts / us / 1e6:6.2f} TB/s")
+for tile in (1, 0):
+  smml.lib().smml_gemm_b16_set_tile(tile)
+  print("tile mode", tile, "(1: 128 x 128 only, 0: automatic); splitk = 0: chosen by the library")
+  for name, M, N, K, trans, obf, sk in [("qkv fwd  NT", R, 1536, 512, False, True, 1), ("out fwd  NT", R, 512, 512, False, False, 1),
+                                        ("dx qkv   NT", R, 512, 1536, False, True, 1), ("dx out   NT", R, 512, 512, False, True, 1),
+                                        ("dW qkv   TN", 1536, 512, R, True, False, 0), ("dW out   TN", 512, 512, R, True, False, 0),
+                                        ("4096^3   NT", 4096, 4096, 4096, False, True, 1)]:
+      if trans: a, b = rnd(K, M), rnd(K, N)
+      else: a, b = rnd(M, K), rnd(N, K)
+      c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16 if obf else torch.float32)
+      us = timeit(lambda: Fh.gemm_b16(a, b, c, M=M, N=N, K=K, lda=a.shape[1], ldb=b.shape[1], ldc=N, trans=trans, splitk=sk))
+      byts = (a.numel() + b.numel()) * 2 + c.numel() * c.element_size()
+      print(f"{name}  M={M} N={N} K={K} splitk={sk}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  {byts / us / 1e6:6.2f} TB/s")

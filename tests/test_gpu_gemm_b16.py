@@ -21,9 +21,18 @@ def _check(got, ref, out_bf16, what):
     assert err <= tol, (what, err, tol)
 
 
+@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+def tile(request):
+    """both kernels: 1 = the 128 x 128 tile only, 2 = the 256-row eight-wave tile wherever M >= 256 and N >= 128"""
+    L = smml.lib()
+    L.smml_gemm_b16_set_tile(request.param)
+    yield request.param
+    L.smml_gemm_b16_set_tile(-1)
+
+
 @pytest.mark.parametrize("out_bf16", [False, True])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1, 8, 8), (1024, 1536, 512), (257, 136, 1000), (4096, 512, 1536)])
-def test_gemm_b16_nt(cuda, M, N, K, out_bf16):
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (1, 8, 8), (1024, 1536, 512), (257, 136, 1000), (4096, 512, 1536), (700, 520, 136)])
+def test_gemm_b16_nt(cuda, tile, M, N, K, out_bf16):
     a, b = _rand((M, K), M + K), _rand((N, K), N + 7 * K)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
     ref = a.double() @ b.double().t() + bias.double()
@@ -37,15 +46,15 @@ def test_gemm_b16_nt(cuda, M, N, K, out_bf16):
         assert torch.equal(c.float().cpu(), b.float().t())
 
 
-@pytest.mark.parametrize("splitk", [1, 3, 16])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (264, 136, 1000), (8, 8, 1), (512, 1536, 5000), (512, 512, 4096)])
-def test_gemm_b16_tn(cuda, M, N, K, splitk):
+@pytest.mark.parametrize("splitk", [0, 1, 3, 16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (264, 136, 1000), (8, 8, 1), (512, 1536, 5000), (512, 512, 4096), (776, 264, 333)])
+def test_gemm_b16_tn(cuda, tile, M, N, K, splitk):
     a, b = _rand((K, M), M + K), _rand((K, N), N + 7 * K)
     ref = a.double().t() @ b.double()
     c = torch.zeros(M, N, device=cuda)
     Fh.gemm_b16(a.to(cuda), b.to(cuda), c, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans=True, splitk=splitk)
     _check(c, ref, False, ("tn", M, N, K, splitk))
-    if splitk == 1:
+    if splitk == 1:                         # (0 = the library's choice: needs the zeroed fp32 output like any split)
         cb = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
         Fh.gemm_b16(a.to(cuda), b.to(cuda), cb, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans=True)
         _check(cb, ref, True, ("tn bf16", M, N, K))
@@ -83,9 +92,9 @@ def test_linear_b16_forward_backward(cuda, out_bf16):
     _check(bd.grad, br.grad, False, "db")
 
 
-def test_gemm_b16_batched_row_maps(cuda):
+def test_gemm_b16_batched_row_maps(cuda, tile):
     """Batch items addressed in place (the bags of a padded buffer): NT with offset / strided outputs, TN whose batches add up in one output."""
-    b, n0, pad, K, N = 3, 200, 56, 64, 136
+    b, n0, pad, K, N = 3, 300, 56, 64, 136
     n = n0 + pad
     x = _rand((b, n0, K), 11); w = _rand((N, K), 12)
     y = torch.full((b, n, N), float("nan"), device=cuda, dtype=torch.bfloat16)
