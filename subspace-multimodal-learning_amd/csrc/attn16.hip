@@ -154,6 +154,36 @@ __device__ __forceinline__ void store_row(T* rowp, const floatx16& o0, const flo
   }
 }
 
+// A wave's 32 query rows of 64 sixteen-bit values (128 bytes each) moved in FULL LINES: lane l takes the 16-byte chunk l & 7 of rows
+// (l >> 3) + 8 i, i = 0..3 - eight lanes per row, eight whole rows per instruction - where the fragment-shaped access (each lane its own
+// row, 16-32 bytes of it per instruction) touches 32 lines per instruction, 128 per tensor and wave.  The rows pass through a per-wave LDS
+// image [32][RLD] to change between the two shapes.
+template <typename T>
+__device__ __forceinline__ void rows_load(const T* base, long long rs, int row0, int nrows, uint4v (&r)[4], int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4v*>(base + (size_t)min(row0 + (lane >> 3) + 8 * i, nrows - 1) * rs + (lane & 7) * 8);
+}
+template <typename T>
+__device__ __forceinline__ void rows_store(T* base, long long rs, int row0, int nrows, const uint4v (&r)[4], int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + (lane >> 3) + 8 * i;
+    if (row < nrows) *reinterpret_cast<uint4v*>(base + (size_t)row * rs + (lane & 7) * 8) = r[i];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void rows_to_lds(T* img, const uint4v (&r)[4], int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4v*>(&img[((lane >> 3) + 8 * i) * RLD + (lane & 7) * 8]) = r[i];
+}
+template <typename T>
+__device__ __forceinline__ void rows_from_lds(const T* img, uint4v (&r)[4], int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4v*>(&img[((lane >> 3) + 8 * i) * RLD + (lane & 7) * 8]);
+}
+template <typename A, typename B> struct same_type { static constexpr bool value = false; };
+template <typename A> struct same_type<A, A> { static constexpr bool value = true; };
+
 // One 32-row x 64 tile of a staged operand held by 256 threads between its global load and its LDS store.
 //   fp32 storage: rows (tid >> 4) and (tid >> 4) + 16, 4 consecutive d each (two float4), converted when stored (8-byte LDS stores)
 //   16-bit storage: row tid >> 3, 8 consecutive d (one 16-byte load, one 16-byte LDS store per image)
@@ -220,24 +250,37 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict
   const TK* Vb = V + obase(kl, bh) + (size_t)kbeg * kl.rs;
   Lk = kend - kbeg;                                   // from here on: keys of this chunk only
 
+  constexpr bool QROWS = same_type<TQ, T>::value;        // 16-bit query-side storage: rows move in full lines through a per-wave image
+  __shared__ __attribute__((aligned(16))) T Wr[QROWS ? AW * AQ * RLD : 8];
+  T* wr = Wr + (QROWS ? wave * AQ * RLD : 0);
   x8 qf[4];
-  {
-    const TQ* qrow = Q + obase(ql, bh) + (size_t)qi * ql.rs;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = row_frag<T>(qrow, s, hf);
-  }
-  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  TileRegs<T, TK> kreg, vreg;
-  kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
-  // the residual row is requested now (one batch of loads, consumed after the key loop): at the end it would be an exposed HBM round trip
   const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
   float4 ra[4], rb[4];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
-  if (RES && !Opart) {
+  uint4v rraw[4];                                       // the residual rows in line shape (QROWS), requested before the key loop
+  if constexpr (QROWS) {
+    uint4v qraw[4];
+    rows_load(reinterpret_cast<const T*>(Q) + obase(ql, bh), ql.rs, q0, Lq, qraw, lane);
+    if (RES) rows_load(reinterpret_cast<const T*>(RES) + obase(ol, bh), ol.rs, q0, Lq, rraw, lane);
+    rows_to_lds(wr, qraw, lane);
+    wave_lds_fence();
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(RES + oo + 8 * rg + 4 * hf); rb[rg] = load4f(RES + oo + 32 + 8 * rg + 4 * hf); }
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const x8*>(&wr[c * RLD + 16 * s + 8 * hf]);
+    wave_lds_fence();
+  } else {
+    const TQ* qrow = Q + obase(ql, bh) + (size_t)qi * ql.rs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = row_frag<T>(qrow, s, hf);
+    // the residual row is requested now (one batch of loads, consumed after the key loop): at the end it would be an exposed round trip
+    if (RES && !Opart) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(RES + oo + 8 * rg + 4 * hf); rb[rg] = load4f(RES + oo + 32 + 8 * rg + 4 * hf); }
+    }
   }
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  TileRegs<T, TK> kreg, vreg;
+  kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
   floatx16 o0 = {0}, o1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
   const int ntiles = (Lk + AK - 1) / AK;
@@ -305,12 +348,31 @@ __global__ __launch_bounds__(256, 2) void attn16_fwd_kernel(const TQ* __restrict
     }
     return;
   }
-  {
-    // every lane takes part in the store (the 16-bit form exchanges pieces between the halves of a lane pair, whose rows are the same);
-    // rows past Lq are clamped to the last row and skipped
+  if constexpr (QROWS) {
+    T* wq = wr;
+    if (RES) {                                          // line shape -> this lane's pieces of its own row
+      rows_to_lds(wq, rraw, lane);
+      wave_lds_fence();
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(&wq[c * RLD + 8 * rg + 4 * hf]); rb[rg] = load4f(&wq[c * RLD + 32 + 8 * rg + 4 * hf]); }
+      wave_lds_fence();
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      store4f(&wq[c * RLD + 8 * rg + 4 * hf], make_float4(fmaf(o0[4 * rg], inv, ra[rg].x), fmaf(o0[4 * rg + 1], inv, ra[rg].y),
+                                                          fmaf(o0[4 * rg + 2], inv, ra[rg].z), fmaf(o0[4 * rg + 3], inv, ra[rg].w)));
+      store4f(&wq[c * RLD + 32 + 8 * rg + 4 * hf], make_float4(fmaf(o1[4 * rg], inv, rb[rg].x), fmaf(o1[4 * rg + 1], inv, rb[rg].y),
+                                                               fmaf(o1[4 * rg + 2], inv, rb[rg].z), fmaf(o1[4 * rg + 3], inv, rb[rg].w)));
+    }
+    wave_lds_fence();
+    uint4v oraw[4];
+    rows_from_lds(wq, oraw, lane);
+    rows_store(reinterpret_cast<T*>(O) + obase(ol, bh), ol.rs, q0, Lq, oraw, lane);
+    if (qvalid && hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+  } else {
     if (qvalid) {
       store_row(O + oo, o0, o1, inv, ra, rb, hf);
-      if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);     // v_log_f32 is log2
+      if (hf == 0) LSE2[(size_t)bh * Lq + qi] = m_run + __builtin_amdgcn_logf(l_run);
     }
   }
 }
@@ -515,9 +577,46 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const TQ* __restr
   const TK* Kb = K + obase(kl, bh) + (size_t)kbeg * kl.rs;
   const TK* Vb = V + obase(kl, bh) + (size_t)kbeg * kl.rs;
   Lk = kend - kbeg;
+  constexpr bool QROWS = same_type<TQ, T>::value;        // 16-bit query-side storage: rows move in full lines through a per-wave image
+  __shared__ __attribute__((aligned(16))) T Wr[QROWS ? AW * AQ * RLD : 8];
+  __shared__ float Wd[QROWS ? AW * AQ : 1];
+  T* wr = Wr + (QROWS ? wave * AQ * RLD : 0);
   x8 qf[4], dof[4];
   float delta = 0.f;
-  {
+  if constexpr (QROWS) {
+    uint4v qraw[4], graw[4], oraw[4], rraw[4];
+    rows_load(reinterpret_cast<const T*>(Q) + obase(ql, bh), ql.rs, q0, Lq, qraw, lane);
+    rows_load(reinterpret_cast<const T*>(dO) + obase(ol, bh), ol.rs, q0, Lq, graw, lane);
+    rows_load(reinterpret_cast<const T*>(O) + obase(ol, bh), ol.rs, q0, Lq, oraw, lane);
+    if (R) rows_load(reinterpret_cast<const T*>(R) + obase(ol, bh), ol.rs, q0, Lq, rraw, lane);
+    // delta = rowsum(dO . (O - R)) in line shape: eight lanes hold one row, three exchanges add them up
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const x8 gv = __builtin_bit_cast(x8, graw[i]), ov = __builtin_bit_cast(x8, oraw[i]);
+      float d = 0.f;
+      if (R) {
+        const x8 rv = __builtin_bit_cast(x8, rraw[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf((float)gv[e], (float)ov[e] - (float)rv[e], d);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf((float)gv[e], (float)ov[e], d);
+      }
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      if ((lane & 7) == 0) Wd[wave * AQ + (lane >> 3) + 8 * i] = d;
+    }
+    rows_to_lds(wr, qraw, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const x8*>(&wr[c * RLD + 16 * s + 8 * hf]);
+    delta = Wd[wave * AQ + c];
+    wave_lds_fence();
+    rows_to_lds(wr, graw, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dof[s] = *reinterpret_cast<const x8*>(&wr[c * RLD + 16 * s + 8 * hf]);
+    wave_lds_fence();
+  } else {
     const TQ* qrow = Q + obase(ql, bh) + (size_t)qi * ql.rs;
     const size_t oo = obase(ol, bh) + (size_t)qi * ol.rs;
 #pragma unroll
@@ -536,8 +635,8 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const TQ* __restr
 #pragma unroll
       for (int i = 0; i < 8; ++i) delta = fmaf(t[i], u[i], delta);
     }
+    delta = xhalf_sum(delta);
   }
-  delta = xhalf_sum(delta);
   const float lse2 = LSE2[(size_t)bh * Lq + qi];
   if (qvalid && hf == 0 && blockIdx.z == 0) DELTA[(size_t)bh * Lq + qi] = delta;
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -587,10 +686,25 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dq_kernel(const TQ* __restr
         *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale, dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
       }
     } else {
-      float4 z4[4];
+      if constexpr (!QROWS) {
+        float4 z4[4];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) z4[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
-      store_row(dQ + obase(dql, bh) + (size_t)qi * dql.rs, dq0, dq1, scale, z4, z4, hf);
+        for (int rg = 0; rg < 4; ++rg) z4[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
+        store_row(dQ + obase(dql, bh) + (size_t)qi * dql.rs, dq0, dq1, scale, z4, z4, hf);
+      }
+    }
+  }
+  if constexpr (QROWS) {
+    if (!dQslab) {                                       // every lane takes part: pieces -> image -> full lines
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        store4f(&wr[c * RLD + 8 * rg + 4 * hf], make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale, dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale));
+        store4f(&wr[c * RLD + 32 + 8 * rg + 4 * hf], make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale, dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale));
+      }
+      wave_lds_fence();
+      uint4v oraw[4];
+      rows_from_lds(wr, oraw, lane);
+      rows_store(reinterpret_cast<T*>(dQ) + obase(dql, bh), dql.rs, q0, Lq, oraw, lane);
     }
   }
 }
@@ -620,8 +734,27 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
   const bool kvalid = (j0 + c) < Lk;
   const int key = min(j0 + c, Lk - 1);
   const bool wave_has_keys = j0 < Lk;
+  constexpr bool KROWS = same_type<TK, T>::value;        // 16-bit key-side storage: this wave's 32 key rows move in full lines
+  __shared__ __attribute__((aligned(16))) T Wr[KROWS ? AW * AK * RLD : 8];
+  T* wr = Wr + (KROWS ? wave * AK * RLD : 0);
   x8 kf[4], vf[4];
-  {
+  uint4v dvraw[4];                                      // the running dV rows in line shape (KROWS && dv_accumulate)
+  if constexpr (KROWS) {
+    uint4v kraw[4], vraw[4];
+    rows_load(reinterpret_cast<const T*>(K) + obase(kl, bh), kl.rs, j0, Lk, kraw, lane);
+    rows_load(reinterpret_cast<const T*>(V) + obase(kl, bh), kl.rs, j0, Lk, vraw, lane);
+    if (dv_accumulate) rows_load(reinterpret_cast<const T*>(dVp) + obase(dkl, bh), dkl.rs, j0, Lk, dvraw, lane);
+    rows_to_lds(wr, kraw, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const x8*>(&wr[c * RLD + 16 * s + 8 * hf]);
+    wave_lds_fence();
+    rows_to_lds(wr, vraw, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf[s] = *reinterpret_cast<const x8*>(&wr[c * RLD + 16 * s + 8 * hf]);
+    wave_lds_fence();
+  } else {
     const size_t off = obase(kl, bh) + (size_t)key * kl.rs;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { kf[s] = row_frag<T>(K + off, s, hf); vf[s] = row_frag<T>(V + off, s, hf); }
@@ -647,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
   float4 va[4], vb[4];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) { va[rg] = make_float4(0.f, 0.f, 0.f, 0.f); vb[rg] = va[rg]; }
-  if (dv_accumulate) {
+  if (!KROWS && dv_accumulate) {
     const TK* vp0 = dVp + (size_t)part * part_stride + obase(dkl, bh) + (size_t)key * dkl.rs;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) { va[rg] = load4f(vp0 + 8 * rg + 4 * hf); vb[rg] = load4f(vp0 + 32 + 8 * rg + 4 * hf); }
@@ -699,7 +832,33 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_dkv_kernel(const TQ* __rest
       }
     }
   }
-  if (kvalid) {
+  if constexpr (KROWS) {                                 // every lane takes part: pieces -> image -> full lines (no query slices on this form)
+    if (dv_accumulate) {
+      rows_to_lds(wr, dvraw, lane);
+      wave_lds_fence();
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { va[rg] = load4f(&wr[c * RLD + 8 * rg + 4 * hf]); vb[rg] = load4f(&wr[c * RLD + 32 + 8 * rg + 4 * hf]); }
+      wave_lds_fence();
+    }
+    uint4v oraw[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      store4f(&wr[c * RLD + 8 * rg + 4 * hf], make_float4(dk0[4 * rg] * scale, dk0[4 * rg + 1] * scale, dk0[4 * rg + 2] * scale, dk0[4 * rg + 3] * scale));
+      store4f(&wr[c * RLD + 32 + 8 * rg + 4 * hf], make_float4(dk1[4 * rg] * scale, dk1[4 * rg + 1] * scale, dk1[4 * rg + 2] * scale, dk1[4 * rg + 3] * scale));
+    }
+    wave_lds_fence();
+    rows_from_lds(wr, oraw, lane);
+    rows_store(reinterpret_cast<T*>(dKp) + obase(dkl, bh), dkl.rs, j0, Lk, oraw, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      store4f(&wr[c * RLD + 8 * rg + 4 * hf], make_float4(dv0[4 * rg] + va[rg].x, dv0[4 * rg + 1] + va[rg].y, dv0[4 * rg + 2] + va[rg].z, dv0[4 * rg + 3] + va[rg].w));
+      store4f(&wr[c * RLD + 32 + 8 * rg + 4 * hf], make_float4(dv1[4 * rg] + vb[rg].x, dv1[4 * rg + 1] + vb[rg].y, dv1[4 * rg + 2] + vb[rg].z, dv1[4 * rg + 3] + vb[rg].w));
+    }
+    wave_lds_fence();
+    rows_from_lds(wr, oraw, lane);
+    rows_store(reinterpret_cast<T*>(dVp) + obase(dkl, bh), dkl.rs, j0, Lk, oraw, lane);
+  } else if (kvalid) {
     const size_t off = (size_t)part * part_stride + obase(dkl, bh) + (size_t)(j0 + c) * dkl.rs;
     TK* kp = dKp + off;
     TK* vp = dVp + off;
