@@ -185,3 +185,29 @@ def test_nystrom_bf16_storage_configurations(cuda, cfg):
     assert_close(tag + " dx", xd.grad, xr.grad, tol)
     for k, p in mod.named_parameters():
         assert_close(tag + " d" + k, p.grad, pr[k].grad, 2 * tol)
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_attention16_large_score_range(cuda, fp16):
+    """Scores spanning hundreds of log2 units with the row maximum in a LATE key tile: the lazy softmax reference (moved only when a tile
+    maximum exceeds it by 2^8) must rescale then, stay finite, and agree with fp64 - forward and backward - incl. rows whose maximum grows
+    tile after tile."""
+    gen = torch.Generator().manual_seed(9)
+    B, H, Lq, Lk = 1, 2, 96, 200
+    q = torch.randn(B, H, Lq, 64, generator=gen) * 3.0
+    k = torch.randn(B, H, Lk, 64, generator=gen) * 3.0
+    k[:, :, :, :] *= torch.linspace(0.2, 2.5, Lk).view(1, 1, Lk, 1)          # later keys carry larger scores
+    v = torch.randn(B, H, Lk, 64, generator=gen)
+    wo = torch.randn(B, H, Lq, 64, generator=gen)
+    ref = [t.clone().double().requires_grad_() for t in (q, k, v)]
+    o64 = _ref_attention(*ref, 0.125)
+    (o64 * wo.double()).sum().backward()
+    dev = [t.clone().to(cuda).requires_grad_() for t in (q, k, v)]
+    o = Fh.attention16(*dev, scale=0.125, fp16=fp16)
+    (o * wo.to(cuda)).sum().backward()
+    assert torch.isfinite(o).all() and all(torch.isfinite(t.grad).all() for t in dev)
+    # operand rounding moves a near-one-hot row's winner only rarely; the gate is the mode's, on the tensor's scale
+    tol = 4 * TOL[fp16]
+    assert_close(f"large range out fp16={fp16}", o, o64, tol)
+    for t, r, n in zip(dev, ref, "qkv"):
+        assert_close(f"large range d{n} fp16={fp16}", t.grad, r.grad, tol)
