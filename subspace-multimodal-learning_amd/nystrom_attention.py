@@ -261,11 +261,14 @@ class NystromAttention(nn.Module):
 
 
 class TransLayer(nn.Module):
-    def __init__(self, norm_layer=nn.LayerNorm, dim=512):
+    """models/mil.py:168-178 (dup cmta_utils.py).  compute_dtype (extension, default None = follow the input's dtype, i.e. exact fp32 behind
+    the fp32 LayerNorm): 'bf16' / 'fp16' runs the block's contractions in its 16-bit compute mode (NystromAttention docstring)."""
+
+    def __init__(self, norm_layer=nn.LayerNorm, dim=512, compute_dtype=None):
         super().__init__()
         self.norm = norm_layer(dim)
         self.attn = NystromAttention(dim=dim, dim_head=dim // 8, heads=8, num_landmarks=dim // 2, pinv_iterations=6,
-                                     residual=True, dropout=0.1)
+                                     residual=True, dropout=0.1, compute_dtype=compute_dtype)
 
     def forward(self, x):
         return x + self.attn(Fh.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps))
@@ -302,8 +305,9 @@ class TransMIL(nn.Module):
         self._fc1 = nn.Sequential(nn.Linear(int(getattr(args, "input_path_dim", 1024) or 1024), 512), nn.ReLU())
         self.cls_token = nn.Parameter(torch.randn(1, 1, 512))
         self.n_classes = self.args.label_dim
-        self.layer1 = TransLayer(dim=512)
-        self.layer2 = TransLayer(dim=512)
+        cd = getattr(args, "nystrom_compute_dtype", None)            # extension key: None (exact fp32, the reference's arithmetic) | 'bf16' | 'fp16'
+        self.layer1 = TransLayer(dim=512, compute_dtype=cd)
+        self.layer2 = TransLayer(dim=512, compute_dtype=cd)
         self.norm = nn.LayerNorm(512)
         self._fc2 = nn.Linear(512, self.n_classes)
         self.multimodal_projection = nn.Linear(512, self.args.path_dim)

@@ -127,6 +127,27 @@ def test_transmil_vs_oracle(cuda):
         _calibrated("d" + k, p.grad, r32[2][k].grad, r64[2][k].grad)
 
 
+def test_transmil_bf16_compute_mode_vs_oracle(cuda):
+    """TransMIL with args.nystrom_compute_dtype = 'bf16' (both TransLayers in the block's bf16 compute mode, everything else exact): against
+    the fp64 oracle at twice the block's own bf16 gate (two blocks in series), 500 instances -> 23 x 23 grid + cls, 530 tokens padded to 768."""
+    args = argparse.Namespace(label_dim=4, path_dim=128, input_path_dim=1024, nystrom_compute_dtype="bf16")
+    net = smml.TransMIL(args)
+    params = params_for(net, 10, "transmil16")
+    net = _load(net, params, cuda)
+    x = synth.bag(2, 500, 1024, 10, "transmil16:bag")
+    pref = {k: v.clone().double().requires_grad_() for k, v in params.items()}
+    enc64, log64 = trans_mil(x.double(), pref)
+    (enc64.sum() + log64.pow(2).sum()).backward()
+    enc, logits, _ = net(x.to(cuda))
+    (enc.sum() + logits.pow(2).sum()).backward()
+    tol = 3e-2
+    assert_close("transmil bf16 mode encoded", enc, enc64, tol)
+    assert_close("transmil bf16 mode logits", logits, log64, tol)
+    for k, p in net.named_parameters():
+        if pref[k].grad is not None:
+            assert_close("transmil bf16 mode d" + k, p.grad, pref[k].grad, 2 * tol)
+
+
 def test_nystrom_long_bag_self_consistency(cuda):
     """n = 10 000 x 512, m = 256 (front padding to 10 240, l = 40): rows of a1 z a3 sum to ~1 is NOT guaranteed by
     the approximation, but linearity in v is: out(v-weights scaled) relation via to_qkv's v block; and bag independence
