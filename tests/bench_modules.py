@@ -52,6 +52,8 @@ def f3():
     enc, logits, _ = tm(xb)
     (enc.sum() + logits.pow(2).sum()).backward()
 timeit("TransMIL fwd+bwd, 4 x 4096 x 1024", f3, steps=5, warm=2)
+tm = smml.TransMIL(argparse.Namespace(label_dim=4, path_dim=128, input_path_dim=1024, nystrom_compute_dtype="bf16")).to(dev).train()
+timeit("TransMIL fwd+bwd, 4 x 4096 x 1024, Nystrom blocks in bf16 compute mode", f3, steps=5, warm=2)
 
 mha = smml.MultiheadAttention(embed_dim=256, num_heads=1).to(dev)
 qo = torch.randn(200, 4, 256, device=dev, requires_grad=True); kp = torch.randn(4096, 4, 256, device=dev, requires_grad=True)
