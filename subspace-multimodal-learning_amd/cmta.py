@@ -23,13 +23,13 @@ from .nystrom_attention import PPEG, TransLayer
 
 
 class Transformer_P(nn.Module):
-    def __init__(self, feature_dim=512):
+    def __init__(self, feature_dim=512, compute_dtype=None):
         super().__init__()
         self.pos_layer = PPEG(dim=feature_dim)
         self.cls_token = nn.Parameter(torch.randn(1, 1, feature_dim))
         nn.init.normal_(self.cls_token, std=1e-6)
-        self.layer1 = TransLayer(dim=feature_dim)
-        self.layer2 = TransLayer(dim=feature_dim)
+        self.layer1 = TransLayer(dim=feature_dim, compute_dtype=compute_dtype)      # compute_dtype: extension, see nystrom_attention.TransLayer
+        self.layer2 = TransLayer(dim=feature_dim, compute_dtype=compute_dtype)
         self.norm = nn.LayerNorm(feature_dim)
 
     def forward(self, features):
@@ -47,12 +47,12 @@ class Transformer_P(nn.Module):
 
 
 class Transformer_G(nn.Module):
-    def __init__(self, feature_dim=512):
+    def __init__(self, feature_dim=512, compute_dtype=None):
         super().__init__()
         self.cls_token = nn.Parameter(torch.randn(1, 1, feature_dim))
         nn.init.normal_(self.cls_token, std=1e-6)
-        self.layer1 = TransLayer(dim=feature_dim)
-        self.layer2 = TransLayer(dim=feature_dim)
+        self.layer1 = TransLayer(dim=feature_dim, compute_dtype=compute_dtype)      # compute_dtype: extension, see nystrom_attention.TransLayer
+        self.layer2 = TransLayer(dim=feature_dim, compute_dtype=compute_dtype)
         self.norm = nn.LayerNorm(feature_dim)
 
     def forward(self, features):
@@ -93,12 +93,13 @@ class CMTA(nn.Module):
                 fc_omic.append(SNN_Block(dim1=hidden[i], dim2=hidden[i + 1], dropout=0.25))
             sig_networks.append(nn.Sequential(*fc_omic))
         self.sig_networks = nn.ModuleList(sig_networks)
-        self.pathomics_encoder = Transformer_P(feature_dim=hidden[-1])
-        self.pathomics_decoder = Transformer_P(feature_dim=hidden[-1])
+        cd = getattr(args, "nystrom_compute_dtype", None)          # extension key: None (exact fp32) | 'bf16' | 'fp16' for the Nystrom blocks
+        self.pathomics_encoder = Transformer_P(feature_dim=hidden[-1], compute_dtype=cd)
+        self.pathomics_decoder = Transformer_P(feature_dim=hidden[-1], compute_dtype=cd)
         self.P_in_G_Att = MultiheadAttention(embed_dim=256, num_heads=1)
         self.G_in_P_Att = MultiheadAttention(embed_dim=256, num_heads=1)
-        self.genomics_encoder = Transformer_G(feature_dim=hidden[-1])
-        self.genomics_decoder = Transformer_G(feature_dim=hidden[-1])
+        self.genomics_encoder = Transformer_G(feature_dim=hidden[-1], compute_dtype=cd)
+        self.genomics_decoder = Transformer_G(feature_dim=hidden[-1], compute_dtype=cd)
         if self.fusion == 'concat':
             self.mm = nn.Sequential(nn.Linear(256 * 2, size[2]), nn.ReLU(), nn.Linear(size[2], size[2]), nn.ReLU())
         elif self.fusion == 'bilinear':

@@ -213,6 +213,25 @@ def test_cmta_golden(cuda):
         g.check("grad:" + k, p.grad, what="d" + k)
 
 
+def test_cmta_bf16_compute_mode_close_to_exact(cuda):
+    """CMTA with args.nystrom_compute_dtype = 'bf16' (the eight Nystrom blocks of its four transformers in bf16 compute mode) against the same
+    model on the exact path, same parameters and inputs: logits and hazards within 3e-2 of their scale, every parameter that gets a gradient
+    on the exact path gets one in bf16 mode."""
+    from test_oracle_golden import cmta_inputs, cmta_params
+    x_path, x_omic, w = cmta_inputs()
+    outs = {}
+    for cd in (None, "bf16"):
+        net = smml.CMTA(argparse.Namespace(label_dim=4, nystrom_compute_dtype=cd))
+        net = _load(net, cmta_params(net), cuda)
+        out = net(x_path=x_path.to(cuda), x_omic=x_omic.to(cuda))
+        (out[0] * w[0].to(cuda)).sum().backward()
+        outs[cd] = ([o.detach() for o in out], {k for k, p in net.named_parameters() if p.grad is not None})
+    for a, b in zip(outs["bf16"][0], outs[None][0]):
+        if torch.is_tensor(a) and a.is_floating_point():
+            assert_close("cmta bf16 mode vs exact", a, b.double().cpu(), 3e-2)
+    assert outs["bf16"][1] == outs[None][1]
+
+
 def test_cmta_reference_bag_size_train_mode(cuda):
     """CMTA on the reference's bag size (8 bags of 2500 x 1024, config_mine.yaml:2,38) in train() mode (Dropout 0.25 on the
     wsi features, AlphaDropout in the SNN blocks, Nystrom output dropout 0.1): runs, finite, every parameter gets a gradient."""
