@@ -120,7 +120,8 @@ def test_cfg4_full_fusion_10000x512(cuda, B, S):
     with cpb_probe() as probe:
         # three evaluations of the oracle: fp32 on the host (the reference's arithmetic), fp32 on the GPU's ATen kernels (the back end the
         # reference trains on: its fp32 noise is what the HIP path may reasonably be held to, helpers.assert_calibrated) and fp64 (truth)
-        for key, dt, dev in (("cpu32", torch.float32, "cpu"), ("gpu32", torch.float32, cuda), ("cpu64", torch.float64, "cpu")):
+        # (the fp64 run of the full-size case uses the GPU's fp64 ATen kernels: the same truth to ~1e-13, and two minutes less of host time)
+        for key, dt, dev in (("cpu32", torch.float32, "cpu"), ("gpu32", torch.float32, cuda), ("cpu64", torch.float64, cuda if S >= 100 else "cpu")):
             p = {k: (v.clone().to(dev, dt).requires_grad_() if v.dtype.is_floating_point else v.to(dev)) for k, v in params.items()}
             odeform.DECISIONS = tap.decisions()
             o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024)
