@@ -76,6 +76,9 @@ int smml_gemm_b16(const void* A, const void* B, void* C, const float* bias, int 
 /* tile selection of the bf16-storage GEMM: 0 automatic (the 256-row, eight-wave tile where its grid still covers the chip), 1 the
  * 128 x 128 tile only, 2 the 256-row tile wherever M >= 256 and N >= 128 (test / measurement switch; SMML_B16_TILE presets it). */
 void smml_gemm_b16_set_tile(int mode);
+/* measurement switch: 1 (default) places the tiles of one slice of a split reduction on one XCD (they share the slice's operands through one
+ * L2), 0 spreads them over the XCDs like any other launch. */
+void smml_gemm_b16_set_slice_major(int on);
 /* nb problems of that shape at element strides sa / sb / sc (multiples of 8) between them; sc = 0 (fp32 output only): the problems' products
  * are ADDED into the one zeroed output, like split-K slices.  A bag's n real rows are addressed in place as one batch item (the zero rows
  * the reference pads in front of a bag, NystromAttention.py:82, are never multiplied). */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "smml_gemm_set_small_tile": (None, [_i]),
     "smml_gemm_b16": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _i, _i, _i, _f]),
     "smml_gemm_b16_set_tile": (None, [_i]),
+    "smml_gemm_b16_set_slice_major": (None, [_i]),
     "smml_gemm_b16_batched": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _ll, _ll, _i, _i, _i, _i, _ll, _ll, _ll, _f]),
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),

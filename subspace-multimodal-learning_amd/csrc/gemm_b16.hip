@@ -33,6 +33,7 @@ struct B16Args {
   long long lda, ldb, ldc;
   int splitk, tiles_m, tiles_n;
   int atomic;                    // add the result into C (split-K slices, batches that share one output)
+  int slice_major, nb;           // 1-D grid in which the tiles of one (batch item, K slice) sit on ONE XCD (see the kernel)
   long long sa, sb, sc;          // batch strides in elements (gridDim.z problems; sc = 0 with split-K: the batches add up in one output)
 };
 
@@ -49,15 +50,28 @@ __global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Ar
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: hardware hands consecutive workgroup ids to the 8 XCDs in turn; id -> (xcd, position) -> a contiguous tile range
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int id = blockIdx.x;
-  const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r = ntiles & 7;
-  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  int tile, ks, bz;
+  if (g.slice_major) {
+    // Long reductions cut into slices (dW = dy^T x over 40 960 tokens): the ntiles workgroups of one slice walk the same K range in step,
+    // so their working set is one K tile of each operand - if they share an L2.  Measured with the tiles of a slice spread over the 8
+    // XCDs: 426 MB from HBM for 168 MB of operands (every XCD fetched every panel).  Here slice s lives on XCD s % 8: consecutive
+    // workgroup ids go to the XCDs in turn, so id = 8 j + xcd runs tile j % ntiles of slice 8 (j / ntiles) + xcd.
+    const int S = g.splitk * g.nb, id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int sl = (j / ntiles) * 8 + xcd;
+    if (sl >= S) return;                                   // padding of the last group of eight slices (whole workgroup)
+    tile = j - (j / ntiles) * ntiles;
+    bz = sl / g.splitk; ks = sl - bz * g.splitk;
+  } else {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, pos = id >> 3, q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    ks = blockIdx.y; bz = blockIdx.z;
+  }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * GM, n0 = tn * GN;
-  const int ks = blockIdx.y;
-  g.A += (long long)blockIdx.z * g.sa;
-  g.B += (long long)blockIdx.z * g.sb;
-  g.C = OUT_BF16 ? (void*)(reinterpret_cast<__bf16*>(g.C) + (long long)blockIdx.z * g.sc) : (void*)(reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sc);
+  g.A += (long long)bz * g.sa;
+  g.B += (long long)bz * g.sb;
+  g.C = OUT_BF16 ? (void*)(reinterpret_cast<__bf16*>(g.C) + (long long)bz * g.sc) : (void*)(reinterpret_cast<float*>(g.C) + (long long)bz * g.sc);
   const int ktiles = (g.K + GK - 1) / GK;
   const int tps = (ktiles + g.splitk - 1) / g.splitk;
   const int kt0 = ks * tps, kt1 = min(ktiles, kt0 + tps);
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256, SMML_B16_MINBLOCKS) void gemm_b16_kernel(B16Ar
       const int n = n0 + wn * 64 + ni * 32 + c;
       const int mb = m0 + wm * 64 + mi * 32;
       if (!interior && n >= g.N) continue;
-      const float bv = (g.bias && ks == 0 && (g.sc != 0 || blockIdx.z == 0)) ? g.bias[n] : 0.f;
+      const float bv = (g.bias && ks == 0 && (g.sc != 0 || bz == 0)) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + acc_row(r, hf);
@@ -383,11 +397,13 @@ __global__ __launch_bounds__(512, 1) void gemm_b16_big_kernel(B16Args g) {
     }
 }
 
+static int g_b16_slice_major = 1;   // measurement switch (smml_gemm_b16_set_slice_major): 0 = slices of a split reduction spread over the XCDs
 static int g_b16_tile = -1;      // -1: read SMML_B16_TILE; 0: automatic; 1: the 128 x 128 kernel only; 2: the 256-row kernel wherever it applies
 
 }  // namespace
 
 extern "C" void smml_gemm_b16_set_tile(int mode) { g_b16_tile = mode; }
+extern "C" void smml_gemm_b16_set_slice_major(int on) { g_b16_slice_major = on; }
 
 // C = A B^T (trans = 0: A [M, K], B [N, K], leading dimensions lda / ldb in elements) or C = A^T B (trans = 1: A [K, M], B [K, N]);
 // A, B bf16; C bf16 (out_bf16 = 1, ldc in bf16 elements) or fp32; bias (fp32 [N], may be null) is added once.  splitk > 1: fp32 output only,
@@ -450,7 +466,7 @@ extern "C" int smml_gemm_b16_batched(const void* A, const void* B, void* C, cons
     SMML_REQUIRE(tmb * tnb < (1LL << 31), "smml_gemm_b16: grid too large");
     const int atomic_b = (nb > 1 && sc == 0) ? 1 : 0;
     B16Args gb{reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(B), C, bias, M, N, K, lda, ldb, ldc, splitk, (int)tmb, (int)tnb,
-               (splitk > 1 || atomic_b) ? 1 : 0, sa, sb, sc};
+               (splitk > 1 || atomic_b) ? 1 : 0, 0, nb, sa, sb, sc};
     dim3 gridb((unsigned)(tmb * tnb), (unsigned)splitk, (unsigned)nb), blockb(512);
     hipStream_t stb = (hipStream_t)stream;
 #define SMML_BIG(TNV, OB)                                                                                        \
@@ -468,9 +484,14 @@ extern "C" int smml_gemm_b16_batched(const void* A, const void* B, void* C, cons
   SMML_REQUIRE(tm * tn < (1LL << 31), "smml_gemm_b16: grid too large");
   // batches that add into one output take the atomic path like split-K slices: the kernel's "splitk > 1" test covers both
   const int atomic_batches = (nb > 1 && sc == 0) ? 1 : 0;
+  // slices of a long reduction that add up in one output: one XCD per slice (see the kernel)
+  const long long nslices = (long long)splitk * nb;
+  const int slice_major = (g_b16_slice_major != 0 && !out_bf16 && (splitk > 1 || atomic_batches) && nslices >= 8 &&
+                           ((nslices + 7) / 8) * 8 * tm * tn < (1LL << 31)) ? 1 : 0;
   B16Args g{reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(B), C, bias, M, N, K, lda, ldb, ldc, splitk, (int)tm, (int)tn,
-            (splitk > 1 || atomic_batches) ? 1 : 0, sa, sb, sc};
+            (splitk > 1 || atomic_batches) ? 1 : 0, slice_major, nb, sa, sb, sc};
   dim3 grid((unsigned)(tm * tn), (unsigned)splitk, (unsigned)nb), block(256);
+  if (slice_major) grid = dim3((unsigned)(((nslices + 7) / 8) * 8 * tm * tn), 1, 1);
   hipStream_t st = (hipStream_t)stream;
   if (trans) {
     if (out_bf16) hipLaunchKernelGGL((gemm_b16_kernel<true, true>), grid, block, 0, st, g);

@@ -35,3 +35,14 @@ for tile in (1, 0):
       us = timeit(lambda: Fh.gemm_b16(a, b, c, M=M, N=N, K=K, lda=a.shape[1], ldb=b.shape[1], ldc=N, trans=trans, splitk=sk))
       byts = (a.numel() + b.numel()) * 2 + c.numel() * c.element_size()
       print(f"{name}  M={M} N={N} K={K} splitk={sk}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  {byts / us / 1e6:6.2f} TB/s")
+
+print("slices of a split reduction: spread over the XCDs (0) / one XCD per slice (1)")
+smml.lib().smml_gemm_b16_set_tile(-1)
+for sm in (0, 1, 0, 1):
+    smml.lib().smml_gemm_b16_set_slice_major(sm)
+    for name, M, N, K in [("dW qkv   TN", 1536, 512, R), ("dW out   TN", 512, 512, R)]:
+        a, b = rnd(K, M), rnd(K, N)
+        c = torch.zeros(M, N, device=dev)
+        us = timeit(lambda: Fh.gemm_b16(a, b, c, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans=True, splitk=0))
+        print(f"slice_major={sm} {name}  M={M} N={N} K={K}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s")
+smml.lib().smml_gemm_b16_set_slice_major(1)
