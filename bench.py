@@ -117,8 +117,8 @@ def nystrom_flop(n, D=512, h=8, d=64, m=256, iters=6, k=33):
     return total, qkav
 
 
-def mil_args(in_dim):
-    return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim)
+def mil_args(in_dim, deform_dtype=None):
+    return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim, deform_compute_dtype=deform_dtype)
 
 
 def algorithmic_flop_per_bag(N, J, in_dim, C=128, H=8):
@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
+    ap.add_argument("--deform-dtype", default=None, choices=[None, "bf16", "fp16"],
+                    help="measurement switch: run the HEADLINE step itself with the fused attention core in its 16-bit compute mode (the "
+                         "default line stays fp32-grade; the default run reports the 16-bit step in the extra key `deform16`)")
     ap.add_argument("--graph", action="store_true", help="one GPU only: capture the step in a hipGraph and time replays (the per-kernel "
                     "HIP-event times of `roofline` then come from the eager warm-up steps)")
     a = ap.parse_args()
@@ -238,7 +241,7 @@ def main():
     J = pkg.lib().smml_offsets_out_len(S, 6, 4) ** 2
 
     torch.manual_seed(42)
-    mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, a.deform_dtype))
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
     mil = mil.to(dev).train()              # train mode: attention dropout 0.1 (DeformCrossTransMIL.py:49) is active
     model = pkg.BagDataParallel(mil) if world > 1 else mil
@@ -302,6 +305,8 @@ def main():
     dt = float(tmax.item())
 
     kt = Fh.TIMER.collect()
+    if a.deform_dtype:                      # measurement switch: the 16-bit kernels report under the same two roofline keys
+        kt = {{"deform16_fwd": "deform_attn_fwd", "cpb16_bwd": "cpb_bwd"}.get(k, k): v for k, v in kt.items()}
     dp_info = None
     if world > 1:
         # self-check of a multi-GPU run: the world size the collective backend reports, every rank's device, and the data-parallel

@@ -176,6 +176,29 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                              void* ev_start, void* ev_stop, void* stream);
+/* 16-bit compute mode of the same fused core (csrc/deform_attn16.hip; BASELINE config 4 names bf16, config 5 fp16): the op sequence of
+ * smml_deform_attn_fwd_f32 / _bwd_f32 (models/DeformableAttention2D.py:120-157,284-312; DeformableAttention1D.py:60-102,205-232) with
+ * single-term 16-bit operands on the matrix pipe - dtype 0 = bf16, 1 = fp16 for forward-range operands (q, k, v, probabilities, the
+ * hidden layer and W2 of the position-bias MLP); gradient-range operands are always bf16 - and 16-bit score storage:
+ *   logits16  [B, H, nst / 32, J, 32] of dtype (the pre-softmax scores incl. bias; in training the forward's own softmax runs on the
+ *             rounded values, and with dropout the keep decision rides in the lowest mantissa bit)
+ *   dlogits16 [B, H, nst / 32, J, 32] bf16 (scratch of the backward: d scores = d bias)
+ * q / k / v / out and every gradient stay fp32 in memory; layer 1 of the position-bias MLP, the softmax statistics and all
+ * accumulators are fp32; relu_masks, the workspace (smml_deform_attn_bwd_workspace_bytes) and the decision export
+ * (smml_deform_attn_relu1_masks) are shared with the fp32 path.  ev_start / ev_stop as in the fp32 entry points. */
+int smml_deform_attn16_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, float* out,
+                           float* lse, unsigned short* logits16, unsigned short* relu_masks, int B, int N, int J, int H, int G,
+                           int posdim, float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start,
+                           void* ev_stop, void* stream);
+int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const float* out,
+                           const float* dout, const float* lse, const unsigned short* logits16, const unsigned short* relu_masks,
+                           unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1,
+                           float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
+                           int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
+                           int dtype, void* ev_start, void* ev_stop, void* stream);
+
 /* hipGraph support for attention dropout.  `dropout_seed` is a host value and is baked into a captured launch; to give every
  * replay its own mask, point the calling thread at a device-resident 64-bit offset first: the forward / backward / mask
  * launches issued by this thread afterwards add *device_offset to dropout_seed when they RUN (the pointer is never dereferenced

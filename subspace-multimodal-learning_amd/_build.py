@@ -20,7 +20,8 @@ FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # -fno-slp-vectorize: packed fp32 forms are no faster than two plain fp32 instructions on gfx950 except for FMA, and the
 # SLP vectoriser turns modifier forms (x + |x|) into packed ones that need extra instructions; the kernels write float2
 # arithmetic explicitly where it pays (tests/microbench/valu_mix_probe.hip)
-EXTRA_FLAGS = {"deform_attn.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]}
+_DEFORM_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]
+EXTRA_FLAGS = {"deform_attn.hip": _DEFORM_FLAGS, "deform_attn16.hip": _DEFORM_FLAGS}
 
 
 def sources():

@@ -1,0 +1,956 @@
+// 16-bit compute mode of the fused deformable cross-attention core (BASELINE config 4 names bf16; config 5 fp16): the same op
+// sequence as deform_attn.hip -
+//   models/DeformableAttention2D.py:284-312 (sim, rel_pos_bias, softmax, dropout, attn @ v) and :120-157 (CPB)
+//   models/DeformableAttention1D.py:205-232 and :60-102
+// with SINGLE-TERM 16-bit operands on the matrix pipe and 16-bit score / d-score storage, where deform_attn.hip spends two to six
+// MFMAs per contraction block (and the vector instructions that split fp32 values into hi / mid / lo terms) on fp32-grade results.
+//
+// What is 16 bit (T = bf16 or fp16 for everything of forward range; gradient-range operands are always bf16 - fp32's exponents):
+//   forward   q, k, v, the softmax'd probabilities and the hidden layer h1 of the position-bias MLP are rounded to T when they
+//             become MFMA operands; W2 is one T term; the pre-softmax scores (incl. bias) are stored as T [B, H, nst / 32, J, 32]
+//             and - in training - the forward's own softmax runs on the ROUNDED scores, so forward and backward see one set of
+//             probabilities.  With dropout the keep decision rides in the stored score's lowest mantissa bit (as in the fp32 path).
+//   backward  K, V, Q, dO, P, dS as single bf16 terms; d scores stored as bf16; chain 2 of the position-bias backward with the
+//             constant (W2 w3)^T as one fp16 term against the exact 0 / 1 mask operand; g = h1 . d bias as one bf16 term.
+// What stays fp32: layer 1 of the position-bias MLP (the three-term bf16 product of deform_common.h - the SAME device function as
+// the fp32 path, so the layer-1 ReLU decisions and their export are shared), every accumulator, the softmax statistics (running
+// max, normaliser, log-sum-exp), delta = rowsum(dO . O), all parameter-gradient sums, q / k / v / out and their gradients in memory.
+// Per (key, 32 queries) that is 3 + 8/32 MFMAs forward (7 + 24/32 in the fp32-grade path) and 8 backward (12).
+#include "deform_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+
+// ---- element-type plumbing: T = _Float16 or __bf16 ----
+template <typename T> struct Vec8;
+template <> struct Vec8<_Float16> { typedef half8 type; };
+template <> struct Vec8<__bf16> { typedef bf16x8 type; };
+__device__ __forceinline__ floatx16 mma(half8 a, half8 b, floatx16 c) { return mfma16(a, b, c); }
+__device__ __forceinline__ floatx16 mma(bf16x8 a, bf16x8 b, floatx16 c) { return mfma16b(a, b, c); }
+// two fp32 -> one 32-bit word of two T (round to nearest even; element 0 in the low half)
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<_Float16>(float a, float b) {
+  const float2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2v));
+}
+template <> __device__ __forceinline__ unsigned pack2<__bf16>(float a, float b) {
+  const float2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type cvt8(const float (&x)[8]) {
+  const uint4v w = {pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]), pack2<T>(x[4], x[5]), pack2<T>(x[6], x[7])};
+  return __builtin_bit_cast(typename Vec8<T>::type, w);
+}
+template <typename T> __device__ __forceinline__ uint2v pack4(const float4 v) {
+  return (uint2v){pack2<T>(v.x, v.y), pack2<T>(v.z, v.w)};
+}
+// 16-bit pattern -> fp32
+template <typename T> __device__ __forceinline__ float tof(unsigned u16bits);
+template <> __device__ __forceinline__ float tof<__bf16>(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+template <> __device__ __forceinline__ float tof<_Float16>(unsigned u) { return (float)__builtin_bit_cast(_Float16, (u16)u); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+// MFMA fragment of an operand stored k-major in LDS (two hardware-transposed reads, smml_common.h lds_frag_tr), any 16-bit type
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type frag_tr(const T* p0, const T* p1) {
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) short4v lds_s4;
+  const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p0);
+  const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p1);
+  const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  return __builtin_bit_cast(typename Vec8<T>::type, r);
+}
+// the dropout keep decision in the lowest mantissa bit of a stored 16-bit score (deform_common.h stash_keep, on 16-bit patterns:
+// at most one ulp, direction from the second-lowest bit, never across +-0)
+__device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) {
+  const unsigned flip = (u ^ (keep ? 1u : 0u)) & 1u;
+  const int dir = (u & 0x7FFEu) ? (int)(u & 2u) - 1 : 1;
+  return (u + (unsigned)(flip ? dir : 0)) & 0xFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward.  One wave = 32 queries on the lane axis (deform_attn.hip's mapping); K / V tiles are converted to T when staged
+// (double-buffered: one barrier per tile, the next tile's loads in flight during the key loop), the wave's scaled Q tile lives in
+// registers as four B fragments.
+// ------------------------------------------------------------------------------------------------
+template <int PD, bool SAVE, typename T>
+__global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
+    const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O, float* __restrict__ LSE, u16* __restrict__ LT,
+    u16* __restrict__ MK, int N, int J, int H, int G, int NST, float scale, DropCfg dc_in) {
+  typedef typename Vec8<T>::type vec8;
+  const DropCfg dc = drop_resolve(dc_in);
+  __shared__ __attribute__((aligned(16))) T Kp[2][KT * FRLD];          // K tile, row image (A operand of S^T)
+  __shared__ __attribute__((aligned(16))) T Vp[2][KT * FTLD];          // V tile, read transposed (A operand of O^T)
+  __shared__ float vsl[2][KT][2];                                      // sample positions of the tile's keys
+  __shared__ float biasT[WAVES][KT][QT];                               // per-wave bias tile [key][query]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const int HD = H * DH;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  // scaled Q of this lane's query as the B operand of S^T = K . Q^T: k-step st holds d = 16 st + 8 hf + j
+  vec8 qf[4];
+  {
+    const float* qp = Q + ((size_t)b * N + qi) * HD + h * DH + hf * 8;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * st), t1 = *reinterpret_cast<const float4*>(qp + 16 * st + 4);
+      const float x8[8] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale, t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
+      qf[st] = cvt8<T>(x8);
+    }
+  }
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // transposed-read lane map
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // position-bias constants (layout notes: deform_attn.hip forward).  The chain runs on 2 h1 (relu2), so it delivers
+  // 2 (W2 h1 + b2), and relu2 of that is 4 relu(.): b2 rides in doubled, w3 carries 1/4.
+  float w3v[16];
+  floatx16 b2acc, b1acc;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int oc = acc_row(s, hf);
+    b2acc[s] = 2.f * cp.b2[oc];
+    w3v[s] = 0.25f * cp.w3[oi * CH + oc];
+    b1acc[s] = cp.b1[oc];
+  }
+  const bf16x8 a1 = cpb_l1_weights_q(cp.w1[c * PD], (PD == 2) ? cp.w1[c * PD + 1] : 0.f, hf);
+  vec8 w2t[2];                       // W2 as ONE T term: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
+    w2t[kb] = cvt8<T>(wv);
+  }
+  const float b3h = (hf == 0) ? cp.b3[oi] : 0.f;
+
+  floatx16 oacc0 = {0}, oacc1 = {0};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* Kb = K + (size_t)b * J * HD + h * DH;
+  const float* Vb = V + (size_t)b * J * HD + h * DH;
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  u16* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;              // this wave's [J][32] block of 16-bit scores
+  u16* MKb = MK ? MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32 : nullptr;   // [J][2][32] mask block, this lane half
+  float big;                                                  // 2^100 in an SGPR (v_mul_f32 ... clamp takes no literal)
+  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
+
+  // staging map: thread -> keys (tid >> 4) and (tid >> 4) + 16, 4 consecutive d
+  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  float4 kreg[2], vreg[2];
+  float vsr0 = 0.f, vsr1 = 0.f;
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = j0 + skey + 16 * i;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
+      if (key < J) {
+        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * HD + sd4);
+        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * HD + sd4);
+      }
+    }
+    if (tid < KT) {
+      const int key = j0 + tid;
+      vsr0 = (key < J) ? VSb[(size_t)key * PD] : 0.f;
+      vsr1 = (PD == 2 && key < J) ? VSb[(size_t)key * PD + 1] : 0.f;
+    }
+  };
+  fetch(0);
+
+  const int ntiles = (J + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT, buf = kt & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = skey + 16 * i;
+      *reinterpret_cast<uint2v*>(&Kp[buf][key * FRLD + sd4]) = pack4<T>(kreg[i]);
+      *reinterpret_cast<uint2v*>(&Vp[buf][key * FTLD + sd4]) = pack4<T>(vreg[i]);
+    }
+    if (tid < KT) { vsl[buf][tid][0] = vsr0; vsl[buf][tid][1] = vsr1; }
+    __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2, which every wave left before the previous barrier
+    if (kt + 1 < ntiles) fetch(j0 + KT);
+
+    // S^T[key, query] = K . (scale Q)^T
+    floatx16 s = {0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      s = mma(*reinterpret_cast<const vec8*>(&Kp[buf][c * FRLD + 16 * st + 8 * hf]), qf[st], s);
+
+    // continuous position bias: layer 1 (fp32-grade, deform_common.h) + one T-term layer 2 per key
+    const int nk = min(KT, J - j0);
+    for (int jj = 0; jj < nk; ++jj) {
+      const float p0 = slog1p(gq0 - vsl[buf][jj][0]);
+      const float p1 = (PD == 2) ? slog1p(gq1 - vsl[buf][jj][1]) : 0.f;
+      floatx16 d = b2acc;
+      const floatx16 xacc = cpb_layer1_q(a1, cpb_split_pos(p0, p1), hf, b1acc);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = relu2(xacc[8 * kb + j]);
+        d = mma(w2t[kb], cvt8<T>(hv), d);
+      }
+      // layer 3: two packed-fp32 FMA chains; b3 rides in half 0's sum.  Mask bits as in the fp32 path (same bit layout).
+      float2v ta = {b3h, 0.f}, tb = {0.f, 0.f};
+      float mb0 = 0.f, mb1 = 0.f, mb2 = 0.f, mb3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        const float2v ra = {relu2(d[r]), relu2(d[r + 1])}, rb = {relu2(d[r + 2]), relu2(d[r + 3])};
+        ta = __builtin_elementwise_fma(ra, (float2v){w3v[r], w3v[r + 1]}, ta);
+        tb = __builtin_elementwise_fma(rb, (float2v){w3v[r + 2], w3v[r + 3]}, tb);
+        if (SAVE) {
+          mb0 = fmaf(fminf(fmaxf(ra[0] * big, 0.f), 1.f), (float)(1u << ((13 + r) & 15)), mb0);
+          mb1 = fmaf(fminf(fmaxf(ra[1] * big, 0.f), 1.f), (float)(1u << ((14 + r) & 15)), mb1);
+          mb2 = fmaf(fminf(fmaxf(rb[0] * big, 0.f), 1.f), (float)(1u << ((15 + r) & 15)), mb2);
+          mb3 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb3);
+        }
+      }
+      if (SAVE) MKb[(size_t)(j0 + jj) * 64 + c] = (u16)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded tiles: no bounds check
+      ta += tb;
+      biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);
+    }
+    wave_lds_fence();
+
+    // bias add, key mask
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, hf);
+      s[r] = (key < nk) ? s[r] + biasT[wave][key][c] : -INFINITY;
+    }
+    unsigned keepbits = 0xFFFFu;
+    if (dc.thresh) {
+      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
+      keepbits = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keepbits |= (drop_hash(dc.seed, base + acc_row(r, hf)) >= dc.thresh) ? (1u << r) : 0u;
+    }
+    if (SAVE) {
+      // the scores are rounded to T for storage and the forward's own softmax continues on the rounded (and, with dropout, stashed)
+      // values: forward and backward agree on the probabilities.  Lanes past N write padding of their own tile.
+      if (nk == KT) {                            // full tile (uniform): no per-key bounds
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const unsigned w = pack2<T>(s[r], s[r + 1]);
+          unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          if (dc.thresh) { lo = stash_keep16(lo, (keepbits >> r) & 1u); hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u); }
+          LTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = (u16)lo;
+          LTb[(size_t)(j0 + acc_row(r + 1, hf)) * 32 + c] = (u16)hi;
+          s[r] = tof<T>(lo); s[r + 1] = tof<T>(hi);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const unsigned w = pack2<T>(s[r], s[r + 1]);
+          unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          const int k0 = acc_row(r, hf), k1 = acc_row(r + 1, hf);
+          if (dc.thresh) {
+            if (k0 < nk) lo = stash_keep16(lo, (keepbits >> r) & 1u);
+            if (k1 < nk) hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u);
+          }
+          if (k0 < nk) { LTb[(size_t)(j0 + k0) * 32 + c] = (u16)lo; s[r] = tof<T>(lo); }
+          if (k1 < nk) { LTb[(size_t)(j0 + k1) * 32 + c] = (u16)hi; s[r + 1] = tof<T>(hi); }
+        }
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    tmax = xhalf_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = sexp(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = sexp(s[r] - m_new);
+      psum += p;                                  // the normaliser sums the un-dropped probabilities
+      s[r] = p;
+    }
+    if (dc.thresh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= ((keepbits >> r) & 1u) ? dc.keep_scale : 0.f;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc0[r] *= alpha; oacc1[r] *= alpha; }
+
+    // O^T[d, query] += V^T . P^T: accumulator registers 8 kb .. 8 kb + 7 of P^T are the B fragment of k-step kb
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float p8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p8[j] = s[8 * kb + j];
+      const vec8 pt = cvt8<T>(p8);
+      const int ro = (16 * kb + 4 * hf + trq) * FTLD + trc;
+      oacc0 = mma(frag_tr<T>(&Vp[buf][ro], &Vp[buf][ro + 8 * FTLD]), pt, oacc0);
+      oacc1 = mma(frag_tr<T>(&Vp[buf][ro + 32], &Vp[buf][ro + 32 + 8 * FTLD]), pt, oacc1);
+    }
+  }
+
+  l_run = xhalf_sum(l_run);
+  const float inv = 1.f / l_run;
+  if (qvalid) {
+    float* op = O + ((size_t)b * N + qi) * HD + h * DH;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(op + d) = make_float4(oacc0[4 * rg] * inv, oacc0[4 * rg + 1] * inv,
+                                                       oacc0[4 * rg + 2] * inv, oacc0[4 * rg + 3] * inv);
+      *reinterpret_cast<float4*>(op + 32 + d) = make_float4(oacc1[4 * rg] * inv, oacc1[4 * rg + 1] * inv,
+                                                            oacc1[4 * rg + 2] * inv, oacc1[4 * rg + 3] * inv);
+    }
+    if (hf == 0) LSE[(size_t)(b * H + h) * N + qi] = m_run + logf(l_run);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1 (query owners): dS^T = P^T (dP^T - delta) -> bf16 d scores, dQ = scale * dS K.  Single bf16 terms.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
+    const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O, const float* __restrict__ dO,
+    const float* __restrict__ LSE, const u16* __restrict__ LT, u16* __restrict__ dLT, float* __restrict__ dQ, int N, int J,
+    int H, int NST, float scale, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
+  __shared__ __attribute__((aligned(16))) __bf16 Vp[2][KT * VBLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Kp[2][KT * KBLD];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int HD = H * DH;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  // dO of this lane's query as the B operand of dP^T = V . dO^T: K-block kb holds d = 16 kb + 8 hf + j
+  bf16x8 dob[4];
+  float delta = 0.f;
+  {
+    const size_t off = ((size_t)b * N + qi) * HD + h * DH + hf * 8;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 t0 = *reinterpret_cast<const float4*>(dO + off + 16 * kb), t1 = *reinterpret_cast<const float4*>(dO + off + 16 * kb + 4);
+      const float4 u0 = *reinterpret_cast<const float4*>(O + off + 16 * kb), u1 = *reinterpret_cast<const float4*>(O + off + 16 * kb + 4);
+      delta += t0.x * u0.x + t0.y * u0.y + t0.z * u0.z + t0.w * u0.w + t1.x * u1.x + t1.y * u1.y + t1.z * u1.z + t1.w * u1.w;
+      const float x8[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      dob[kb] = cvt8<__bf16>(x8);
+    }
+  }
+  delta = xhalf_sum(delta);
+  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
+
+  floatx16 dq0 = {0}, dq1 = {0};
+  const float* Kb = K + (size_t)b * J * HD + h * DH;
+  const float* Vb = V + (size_t)b * J * HD + h * DH;
+  const u16* LTb = LT + ((size_t)(b * H + h) * NST + q0) * J;
+  u16* dLTb = dLT + ((size_t)(b * H + h) * NST + q0) * J;
+
+  const int skey = tid >> 4, sd4 = (tid & 15) * 4;
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 kreg[2], vreg[2];
+  unsigned lt[16];
+  auto fetch = [&](int j0, float4 (&kr)[2], float4 (&vr)[2], unsigned (&l)[16]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = j0 + skey + 16 * i;
+      kr[i] = make_float4(0.f, 0.f, 0.f, 0.f); vr[i] = kr[i];
+      if (key < J) {
+        kr[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * HD + sd4);
+        vr[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * HD + sd4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(j0 + acc_row(r, hf), J - 1);     // clamped: always in bounds, masked at use
+      l[r] = LTb[(size_t)key * 32 + c];
+    }
+  };
+  fetch(0, kreg, vreg, lt);
+
+  const int ntiles = (J + KT - 1) / KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT, buf = kt & 1;
+    const int nk = min(KT, J - j0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = skey + 16 * i;
+      *reinterpret_cast<uint2v*>(&Vp[buf][key * VBLD + sd4]) = pack4<__bf16>(vreg[i]);
+      *reinterpret_cast<uint2v*>(&Kp[buf][key * KBLD + sd4]) = pack4<__bf16>(kreg[i]);
+    }
+    __syncthreads();        // one barrier per tile (double buffer)
+    unsigned ltc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ltc[r] = lt[r];
+    if (kt + 1 < ntiles) fetch(j0 + KT, kreg, vreg, lt);
+
+    // dP^T[key, query] = V . dO^T
+    floatx16 dp = {0};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      dp = mfma16b(*reinterpret_cast<const bf16x8*>(&Vp[buf][c * VBLD + 16 * kb + 8 * hf]), dob[kb], dp);
+
+    float ds[16];
+    const bool interior = (nk == KT && q0 + QT <= N);      // uniform
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      float v2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int key = acc_row(r + e, hf);
+        float v = 0.f;
+        if (interior || (key < nk && qvalid)) {
+          const float p = prob_of(tof<T>(ltc[r + e]), nl);
+          float dpr = dp[r + e];
+          if (dc.thresh) dpr *= (ltc[r + e] & 1u) ? dc.keep_scale : 0.f;     // the forward's decision rides in the score's lowest bit
+          v = p * (dpr - delta);
+        }
+        v2[e] = v;
+        ds[r + e] = v;
+      }
+      const unsigned w = pack2<__bf16>(v2[0], v2[1]);
+      const int k0 = acc_row(r, hf), k1 = acc_row(r + 1, hf);
+      if (interior || (k0 < nk && qvalid)) dLTb[(size_t)(j0 + k0) * 32 + c] = (u16)(w & 0xFFFFu);
+      if (interior || (k1 < nk && qvalid)) dLTb[(size_t)(j0 + k1) * 32 + c] = (u16)(w >> 16);
+    }
+    // dQ^T[d, query] += K^T . dS^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float x8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) x8[jx] = ds[8 * kb + jx];
+      const bf16x8 sb = cvt8<__bf16>(x8);
+      const int ro = (16 * kb + 4 * hf + trq) * KBLD + trc;
+      dq0 = mfma16b(lds_frag_tr(&Kp[buf][ro], &Kp[buf][ro + 8 * KBLD]), sb, dq0);
+      dq1 = mfma16b(lds_frag_tr(&Kp[buf][ro + 32], &Kp[buf][ro + 32 + 8 * KBLD]), sb, dq1);
+    }
+  }
+  if (qvalid) {
+    float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(qp + d) = make_float4(dq0[4 * rg] * scale, dq0[4 * rg + 1] * scale,
+                                                       dq0[4 * rg + 2] * scale, dq0[4 * rg + 3] * scale);
+      *reinterpret_cast<float4*>(qp + 32 + d) = make_float4(dq1[4 * rg] * scale, dq1[4 * rg + 1] * scale,
+                                                            dq1[4 * rg + 2] * scale, dq1[4 * rg + 3] * scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2 (key owners): dV = P_dropped^T dO, dK = scale * dS^T Q (deform_attn.hip's mapping; single bf16 terms, the
+// 16-bit scores / d scores are read as 8-byte runs of four consecutive queries).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
+    const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE, const u16* __restrict__ LT,
+    const u16* __restrict__ dLT, float* __restrict__ dKp, float* __restrict__ dVp, int N, int J, int H, int NST, int nkg,
+    int tiles_per_part, int nparts, int Bn, DropCfg dc_in) {
+  const DropCfg dc = drop_resolve(dc_in);
+  __shared__ __attribute__((aligned(16))) __bf16 Qp[2][QT * QBLD];
+  __shared__ __attribute__((aligned(16))) __bf16 dOp[2][QT * QBLD];
+  __shared__ __attribute__((aligned(16))) float nls[2][QT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  // XCD-aware block order (deform_attn.hip): the key groups of one (query slice, head, bag) get ids that differ by multiples of 8
+  const int nslices = nparts * H * Bn;
+  const int chunk = blockIdx.x / (8 * nkg), rem = blockIdx.x - chunk * (8 * nkg);
+  const int kg = rem >> 3, slice = chunk * 8 + (rem & 7);
+  if (slice >= nslices) return;                         // padding of the last chunk (whole workgroup, before any barrier)
+  const int part = slice % nparts, h = (slice / nparts) % H, b = slice / (nparts * H);
+  const int j0 = kg * DKV_KEYS + wave * KT;
+  const int HD = H * DH;
+  const int nk = min(KT, J - j0);                       // <= 0: this wave has no keys (it still stages tiles)
+  const bool kvalid = c < nk;
+  const int key = min(j0 + c, J - 1);
+  const u16* LTk = LT + (size_t)(b * H + h) * NST * J + (size_t)key * 32;
+  const u16* dLTk = dLT + (size_t)(b * H + h) * NST * J + (size_t)key * 32;
+  const float* LSEb = LSE + (size_t)(b * H + h) * N;
+
+  const int nqt = (N + QT - 1) / QT;
+  const int qt_begin = part * tiles_per_part, qt_end = min(qt_begin + tiles_per_part, nqt);
+  const int srow = tid >> 4, sd4 = (tid & 15) * 4;
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 qreg[2], doreg[2];
+  uint2v ltr[4], dlr[4];
+  float lsereg = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ltr[i] = (uint2v){0u, 0u}; dlr[i] = ltr[i]; }
+  qreg[0] = qreg[1] = doreg[0] = doreg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qrow = min(q0 + srow + 16 * i, N - 1);
+      const size_t off = ((size_t)b * N + qrow) * HD + h * DH + sd4;
+      qreg[i] = *reinterpret_cast<const float4*>(Q + off);
+      doreg[i] = *reinterpret_cast<const float4*>(dO + off);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const size_t qq = (size_t)q0 * J + 8 * rg + 4 * hf;   // 4 consecutive queries of the tile: 8 bytes
+      ltr[rg] = *reinterpret_cast<const uint2v*>(LTk + qq);
+      dlr[rg] = *reinterpret_cast<const uint2v*>(dLTk + qq);
+    }
+    if (tid < QT) lsereg = LSEb[min(q0 + tid, N - 1)];
+  };
+
+  floatx16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  if (qt_begin < qt_end) fetch(qt_begin * QT);
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int q0 = qt * QT, buf = (qt - qt_begin) & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (srow + 16 * i) * QBLD + sd4;
+      *reinterpret_cast<uint2v*>(&Qp[buf][o]) = pack4<__bf16>(qreg[i]);
+      *reinterpret_cast<uint2v*>(&dOp[buf][o]) = pack4<__bf16>(doreg[i]);
+    }
+    if (tid < QT) nls[buf][tid] = prob_bias(lsereg);
+    __syncthreads();
+    unsigned lv[16];
+    float dsv[16], ls[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      lv[4 * rg + 0] = ltr[rg][0] & 0xFFFFu; lv[4 * rg + 1] = ltr[rg][0] >> 16;
+      lv[4 * rg + 2] = ltr[rg][1] & 0xFFFFu; lv[4 * rg + 3] = ltr[rg][1] >> 16;
+      dsv[4 * rg + 0] = bf_lo(dlr[rg][0]); dsv[4 * rg + 1] = bf_hi(dlr[rg][0]);
+      dsv[4 * rg + 2] = bf_lo(dlr[rg][1]); dsv[4 * rg + 3] = bf_hi(dlr[rg][1]);
+      const float4 t = *reinterpret_cast<const float4*>(&nls[buf][8 * rg + 4 * hf]);     // broadcast read
+      ls[4 * rg + 0] = t.x; ls[4 * rg + 1] = t.y; ls[4 * rg + 2] = t.z; ls[4 * rg + 3] = t.w;
+    }
+    if (qt + 1 < qt_end) fetch(q0 + QT);
+    if (nk > 0) {                                          // wave-uniform
+      float p[16], ds[16];
+      const bool interior = (nk == KT && q0 + QT <= N);    // uniform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = interior || (kvalid && q0 + acc_row(r, hf) < N);
+        float pv = ok ? prob_of(tof<T>(lv[r]), ls[r]) : 0.f;
+        if (dc.thresh) pv *= (lv[r] & 1u) ? dc.keep_scale : 0.f;
+        p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
+        ds[r] = ok ? dsv[r] : 0.f;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float x8[8], y8[8];
+#pragma unroll
+        for (int jx = 0; jx < 8; ++jx) { x8[jx] = p[8 * kb + jx]; y8[jx] = ds[8 * kb + jx]; }
+        const bf16x8 pb = cvt8<__bf16>(x8), sb = cvt8<__bf16>(y8);
+        const int ro = (16 * kb + 4 * hf + trq) * QBLD + trc;
+        dv0 = mfma16b(lds_frag_tr(&dOp[buf][ro], &dOp[buf][ro + 8 * QBLD]), pb, dv0);
+        dk0 = mfma16b(lds_frag_tr(&Qp[buf][ro], &Qp[buf][ro + 8 * QBLD]), sb, dk0);
+        dv1 = mfma16b(lds_frag_tr(&dOp[buf][ro + 32], &dOp[buf][ro + 32 + 8 * QBLD]), pb, dv1);
+        dk1 = mfma16b(lds_frag_tr(&Qp[buf][ro + 32], &Qp[buf][ro + 32 + 8 * QBLD]), sb, dk1);
+      }
+    }
+  }
+  if (kvalid) {
+    const size_t off = (((size_t)part * Bn + b) * J + (j0 + c)) * HD + h * DH;
+    float* kp = dKp + off;
+    float* vp = dVp + off;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = 8 * rg + 4 * hf;
+      *reinterpret_cast<float4*>(kp + d) = make_float4(dk0[4 * rg], dk0[4 * rg + 1], dk0[4 * rg + 2], dk0[4 * rg + 3]);
+      *reinterpret_cast<float4*>(kp + 32 + d) = make_float4(dk1[4 * rg], dk1[4 * rg + 1], dk1[4 * rg + 2], dk1[4 * rg + 3]);
+      *reinterpret_cast<float4*>(vp + d) = make_float4(dv0[4 * rg], dv0[4 * rg + 1], dv0[4 * rg + 2], dv0[4 * rg + 3]);
+      *reinterpret_cast<float4*>(vp + 32 + d) = make_float4(dv1[4 * rg], dv1[4 * rg + 1], dv1[4 * rg + 2], dv1[4 * rg + 3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of the continuous position bias, 16-bit mode: deform_attn.hip's cpb_bwd_kernel (both MFMA layouts, the forward's saved
+// layer-2 ReLU bits rotated straight into an fp16 operand, per-workgroup slabs added in a fixed order) with d bias read from the
+// bf16 d scores, chain 2 against ONE fp16 term of (W2 w3)^T and g = h1 . d bias as ONE bf16 term: 8 MFMAs per key
+// (1 + 1 layer 1, 2 mask transposition, 2 chain 2, 2 dW2) instead of 12, and none of the residual arithmetic of the splits.
+// ------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(256, 2) void cpb16_bwd_kernel(
+    const u16* __restrict__ dLT, const u16* __restrict__ MK, const float* __restrict__ VS, const float* __restrict__ GQ,
+    CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  const bool qvalid = (q0 + c) < N;
+  const int qi = qvalid ? (q0 + c) : (N - 1);
+
+  float* tab = smem;
+  float* wbase = smem + CPB2_TAB;
+  float* xq = wbase + wave * CPB2_WAVE_LDS;                 // [2][32]
+  float2* stg = reinterpret_cast<float2*>(xq + CPB_XQ);     // [16 keys][65]
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float2* dvs_row = reinterpret_cast<float2*>(dvs_slab) + (size_t)(wg * WAVES + wave) * J;
+  if (tid < 32) {                                           // tid = 16 half + r
+    const int ch = acc_row(tid & 15, tid >> 4);
+    tab[(tid >> 4) * 32 + (tid & 15)] = cp.w1[ch * PD];
+    tab[(tid >> 4) * 32 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+  }
+  const float* tabh = tab + hf * 32;
+  const float gq0 = GQ[(size_t)qi * PD];
+  const float gq1 = (PD == 2) ? GQ[(size_t)qi * PD + 1] : 0.f;
+
+  // layer 1 in both layouts (operand layouts: deform_attn.hip cpb_bwd_kernel)
+  bf16x8 a1q, a1t;
+  floatx16 b1acc;
+  {
+    const float wx = cp.w1[c * PD], wy = (PD == 2) ? cp.w1[c * PD + 1] : 0.f, bb = cp.b1[c];
+    const __bf16 xh = (__bf16)wx; const float xr = wx - (float)xh; const __bf16 xm = (__bf16)xr;
+    const __bf16 xl = (__bf16)(xr - (float)xm);
+    const __bf16 yh = (__bf16)wy; const float yr = wy - (float)yh; const __bf16 ym = (__bf16)yr;
+    const __bf16 yl = (__bf16)(yr - (float)ym);
+    const __bf16 bh_ = (__bf16)bb; const float br = bb - (float)bh_; const __bf16 bm = (__bf16)br;
+    const __bf16 bl_ = (__bf16)(br - (float)bm);
+    const __bf16 z = (__bf16)0.f;
+    a1q = cpb_l1_weights_q(wx, wy, hf);
+    if (hf == 0) a1t = (bf16x8){xh, yh, xh, yh, xh, yh, bh_, bm};
+    else a1t = (bf16x8){xm, ym, xm, ym, xl, yl, bl_, z};
+#pragma unroll
+    for (int s16 = 0; s16 < 16; ++s16) b1acc[s16] = cp.b1[acc_row(s16, hf)];
+  }
+  const float b2c = cp.b2[c];
+  const float w3c = cp.w3[oi * CH + c];
+
+  half8 w2t[2];                        // W2[out = ch(8 kb + j)][in = c] * w3[out] * slot scale * lift: A operand of chain 2, one fp16 term
+  half8 idb[2];                        // scaled identity: mask . I = mask^T as exact 0.0 / 1.0
+  float unlift2;
+  {
+    float amax = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { const int ch = acc_row(s, hf); amax = fmaxf(amax, fabsf(cp.w2[ch * CH + c] * cp.w3[oi * CH + ch])); }
+    const float lift2 = pow2_lift(wave_max_all(amax), 256.f, -8.f, 24.f);
+    unlift2 = 1.f / lift2;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = acc_row(8 * kb + j, hf);
+        const float sc = (j & 1) ? 0.5f : 128.f;
+        w2t[kb][j] = (_Float16)(cp.w2[ch * CH + c] * cp.w3[oi * CH + ch] * sc * lift2);
+        idb[kb][j] = (ch == c) ? (_Float16)sc : (_Float16)0.0f;
+      }
+    }
+  }
+
+  float big;
+  asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
+  floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
+  float2v aw1x[8], aw1y[8], ab1[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { aw1x[p] = (float2v){0.f, 0.f}; aw1y[p] = aw1x[p]; ab1[p] = aw1x[p]; }
+  float ab3 = 0.f;
+  float2v s2 = {0.f, 0.f};
+
+  const float* VSb = VS + (size_t)(b * G + g) * J * PD;
+  const u16* dLTb = dLT + ((size_t)(b * H + h) * NST + q0) * J;
+  __syncthreads();
+  float vx_n = VSb[0];
+  float vy_n = (PD == 2) ? VSb[1] : 0.f;
+  unsigned db_n = dLTb[c];
+  const u16* MKb = MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
+  unsigned m16_n = MKb[c];
+
+  for (int j = 0; j < J; ++j) {
+    const float vx = vx_n, vy = vy_n, dbias = qvalid ? tof<__bf16>(db_n) : 0.f;
+    const unsigned m16 = m16_n;
+    {
+      const int jn = min(j + 1, J - 1);
+      vx_n = VSb[(size_t)jn * PD];
+      if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
+      db_n = dLTb[(size_t)jn * 32 + c];
+      m16_n = MKb[(size_t)jn * 64 + c];
+    }
+    float* xb = xq + (j & 1) * 32;
+    xb[c] = dbias;
+    const float d0 = gq0 - vx, d1 = gq1 - vy;
+    const float p0 = slog1p(d0);
+    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
+
+    floatx16 xacc, ht;
+    {
+      const PosTerms pt = cpb_split_pos(p0, p1);
+      xacc = cpb_layer1_q(a1q, pt, hf, b1acc);
+      const uint4v tw = {pt.hw, pt.mw, hf ? pt.hw : pt.lw, hf ? 0x00003F80u : 0x3F803F80u};
+      ht = mfma16b(__builtin_bit_cast(bf16x8, tw), a1t, (floatx16){0});
+    }
+    bool on1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) on1[r] = xacc[r] > 0.f;
+
+    half8 mk[2];
+    {
+      const unsigned mm2 = m16 | (m16 << 16);
+      uint4v w0, w1;
+      w0[0] = mm2 & 0x40002000u;
+      w0[1] = __builtin_amdgcn_alignbit(mm2, mm2, 2) & 0x40002000u;
+      w0[2] = __builtin_amdgcn_alignbit(mm2, mm2, 4) & 0x40002000u;
+      w0[3] = __builtin_amdgcn_alignbit(mm2, mm2, 6) & 0x40002000u;
+      w1[0] = __builtin_amdgcn_alignbit(mm2, mm2, 8) & 0x40002000u;
+      w1[1] = __builtin_amdgcn_alignbit(mm2, mm2, 10) & 0x40002000u;
+      w1[2] = __builtin_amdgcn_alignbit(mm2, mm2, 12) & 0x40002000u;
+      w1[3] = __builtin_amdgcn_alignbit(mm2, mm2, 14) & 0x40002000u;
+      mk[0] = __builtin_bit_cast(half8, w0);
+      mk[1] = __builtin_bit_cast(half8, w1);
+    }
+    floatx16 mtt = mfma16(mk[0], idb[0], (floatx16){0});
+    mtt = mfma16(mk[1], idb[1], mtt);
+
+    float dbq[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 t = *reinterpret_cast<const float4*>(xb + 8 * rg + 4 * hf);          // broadcast reads
+      dbq[4 * rg] = t.x; dbq[4 * rg + 1] = t.y; dbq[4 * rg + 2] = t.z; dbq[4 * rg + 3] = t.w;
+    }
+    bf16x8 am[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4v amw;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = 8 * t + 2 * p;
+        s2[0] = fmaf(mtt[r], dbq[r], s2[0]);
+        s2[1] = fmaf(mtt[r + 1], dbq[r + 1], s2[1]);
+        amw[p] = pack2<__bf16>(mtt[r], mtt[r + 1]);
+      }
+      am[t] = __builtin_bit_cast(bf16x8, amw);
+    }
+    // chain 2: dh1[in = ch(r)][query = c] = (W2 w3)^T mask, one fp16 term of the constant against the exact mask operand
+    floatx16 dh = {0};
+    dh = mfma16(w2t[0], mk[0], dh);
+    dh = mfma16(w2t[1], mk[1], dh);
+    ab3 += (hf == 0) ? dbias : 0.f;
+
+    // dW2 += mask^T g, g = 2 h1^T . d bias as one bf16 term
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float g8[8];
+#pragma unroll
+      for (int jx = 0; jx < 8; ++jx) g8[jx] = relu2(ht[8 * t + jx]) * dbq[8 * t + jx];
+      e = mfma16b(am[t], cvt8<__bf16>(g8), e);
+    }
+
+    // layer-1 backward, d vs (fp32 on the vector unit, as in the fp32 path)
+    {
+      float2v dp0v = {0.f, 0.f}, dp1v = {0.f, 0.f};
+      const float dbl = dbias * unlift2;
+      const float p0i = p0 * dbl, p1i = p1 * dbl;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        float2v g1;
+        g1[0] = on1[2 * p] ? dh[2 * p] : 0.f;
+        g1[1] = on1[2 * p + 1] ? dh[2 * p + 1] : 0.f;
+        const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);
+        ab1[p] = g1 * (float2v){dbl, dbl} + ab1[p];
+        aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
+        dp0v = g1 * (float2v){wx.x, wx.y} + dp0v;
+        if (PD == 2) {
+          const float2 wy = *reinterpret_cast<const float2*>(tabh + 16 + 2 * p);
+          aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
+          dp1v = g1 * (float2v){wy.x, wy.y} + dp1v;
+        }
+      }
+      float2 v;
+      v.x = -(dp0v[0] + dp0v[1]) * dbl * (srcp(fabsf(d0) + 1.f) * fminf(fmaxf(fabsf(d0) * big, 0.f), 1.f));
+      v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbl * (srcp(fabsf(d1) + 1.f) * fminf(fmaxf(fabsf(d1) * big, 0.f), 1.f)) : 0.f;
+      stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
+    }
+    if ((j & (CPB2_STG_KEYS - 1)) == CPB2_STG_KEYS - 1 || j == J - 1) {   // uniform: flush the staging tile
+      asm volatile("" ::: "memory");
+      const int kk = lane & 31, nrow = (j & (CPB2_STG_KEYS - 1)) + 1;
+      float sx = 0.f, sy = 0.f;
+      if (kk < nrow) {
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const float2 t = stg[kk * 65 + 32 * hf + i];
+          sx += t.x; sy += t.y;
+        }
+      }
+      sx = xhalf_sum(sx); sy = xhalf_sum(sy);
+      if (hf == 0 && kk < nrow) dvs_row[(j & ~(CPB2_STG_KEYS - 1)) + kk] = make_float2(sx, (PD == 2) ? sy : 0.f);
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // workgroup reduction of the per-lane partials -> slab[wg] (fixed order, no atomics; layout: deform_common.h CPB_SLAB)
+  __syncthreads();
+  float* red = wbase + WAVES * CPB2_WAVE_LDS + wave * CPB_SLAB;
+  for (int i = lane; i < CPB_SLAB; i += 64) red[i] = 0.f;
+  {
+    const float s2s = xhalf_sum(s2[0] + s2[1]);
+    if (hf == 0) {
+      red[1024 + 64 + 32 + c] = w3c * s2s;
+      red[1024 + 64 + 32 + 32 + c] = b2c * s2s;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, hf);
+    red[row * CH + c] = 0.5f * e[r] * cp.w3[oi * CH + row];
+    float v;
+    v = 0.5f * e[r] * cp.w2[row * CH + c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) red[1024 + 64 + 32 + 32 + row] += v;
+    v = ab1[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) red[1024 + 64 + row] = v;
+    v = aw1x[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) red[1024 + row * 2] = v;
+    v = aw1y[r >> 1][r & 1];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (c == 0) red[1024 + row * 2 + 1] = v;
+  }
+  {
+    float v = wave_sum(ab3);
+    if (lane == 0) red[1024 + 64 + 32 + 32 + 32] = v;
+  }
+  __syncthreads();
+  float* sl = slab + (size_t)wg * CPB_SLAB;
+  const float* r0 = wbase + WAVES * CPB2_WAVE_LDS;
+  for (int i = tid; i < CPB_SLAB; i += 256)
+    sl[i] = (r0[i] + r0[CPB_SLAB + i]) + (r0[2 * CPB_SLAB + i] + r0[3 * CPB_SLAB + i]);
+}
+
+int check16(const char* fn, int B, int N, int J, int H, int G, int posdim, int dtype) {
+  SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0 && G > 0, "%s: non-positive dimension", fn);
+  SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
+  SMML_REQUIRE(H / G <= 2, "%s: at most 2 heads per offset group are supported (got %d)", fn, H / G);
+  SMML_REQUIRE(posdim == 1 || posdim == 2, "%s: posdim must be 1 or 2 (got %d)", fn, posdim);
+  SMML_REQUIRE(B <= 65535 && H <= 65535, "%s: batch/heads exceed the grid limits", fn);
+  SMML_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype must be 0 (bf16) or 1 (fp16), got %d", fn, dtype);
+  return SMML_OK;
+}
+
+template <typename T>
+void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float* q, const float* k, const float* v, const float* vs,
+                  const float* gq, CpbParams cp, float* out, float* lse, u16* lt, u16* mk, int N, int J, int H, int G, int nst,
+                  float scale, DropCfg dc) {
+  dim3 block(256);
+  if (posdim == 2 && save)
+    hipLaunchKernelGGL((deform16_fwd_kernel<2, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+  else if (posdim == 2)
+    hipLaunchKernelGGL((deform16_fwd_kernel<2, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+  else if (save)
+    hipLaunchKernelGGL((deform16_fwd_kernel<1, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+  else
+    hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI (include/smml.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int smml_deform_attn_nst(int N);
+size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
+
+int smml_deform_attn16_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, float* out,
+                           float* lse, unsigned short* logits16, unsigned short* relu_masks, int B, int N, int J, int H, int G,
+                           int posdim, float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start,
+                           void* ev_stop, void* stream) {
+  int rc = check16("smml_deform_attn16_fwd", B, N, J, H, G, posdim, dtype);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_fwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && lse, "smml_deform_attn16_fwd: null pointer");
+  SMML_REQUIRE((logits16 == nullptr) == (relu_masks == nullptr),
+               "smml_deform_attn16_fwd: logits16 and relu_masks are saved together (training) or not at all");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B);
+  const int nst = smml_deform_attn_nst(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (dtype == 1) launch_fwd16<_Float16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc);
+  else launch_fwd16<__bf16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK("smml_deform_attn16_fwd");
+  return SMML_OK;
+}
+
+int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const float* out,
+                           const float* dout, const float* lse, const unsigned short* logits16, const unsigned short* relu_masks,
+                           unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1,
+                           float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
+                           int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
+                           int dtype, void* ev_start, void* ev_stop, void* stream) {
+  int rc = check16("smml_deform_attn16_bwd", B, N, J, H, G, posdim, dtype);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_bwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits16 && relu_masks &&
+                   dlogits16 && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
+               "smml_deform_attn16_bwd: null pointer");
+  SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, J, H),
+               "smml_deform_attn16_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+               smml_deform_attn_bwd_workspace_bytes(B, N, J, H));
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_deform_attn16_bwd: workspace must be 16-byte aligned");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  hipStream_t st = (hipStream_t)stream;
+  const int nst = smml_deform_attn_nst(N);
+  const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
+  dim3 block(256);
+  const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
+  float* wsf = reinterpret_cast<float*>(workspace);
+  // pass 1: d scores (bf16), dQ
+  if (dtype == 1)
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<_Float16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc);
+  else
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<__bf16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc);
+  SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/dq");
+  // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
+  {
+    const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+    const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
+    const int nslices = parts * H * B;
+    const dim3 gk(((nslices + 7) / 8) * 8 * nkg);
+    if (dtype == 1)
+      hipLaunchKernelGGL(deform16_bwd_dkv_kernel<_Float16>, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    else
+      hipLaunchKernelGGL(deform16_bwd_dkv_kernel<__bf16>, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/dkv");
+    const size_t n4 = (size_t)B * J * H * DH / 4;
+    hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,
+                       reinterpret_cast<const float4*>(wsf + wsl.dkp), reinterpret_cast<const float4*>(wsf + wsl.dvp),
+                       reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts, scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/dkv_reduce");
+  }
+  // pass 3: position-bias MLP backward
+  {
+    float* slab = wsf;
+    const size_t lds = ((size_t)CPB2_TAB + WAVES * CPB2_WAVE_LDS + WAVES * CPB_SLAB) * sizeof(float);
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
+    if (posdim == 2)
+      hipLaunchKernelGGL(cpb16_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
+    else
+      hipLaunchKernelGGL(cpb16_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/cpb");
+    const int nwg = qtiles * H * B;
+    {
+      const long long threads = (long long)B * G * J * 4;
+      hipLaunchKernelGGL(dvs_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                         reinterpret_cast<const float2*>(wsf + wsl.dvs), dvs, B, G, H, qtiles, J, posdim);
+    }
+    const int nchunks = min(CPB_RED_CHUNKS, nwg), chunk = (nwg + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(cpb_partial_kernel, dim3((CPB_SLAB + 63) / 64, nchunks), dim3(256), 0, st, slab, nwg, H / G, qtiles, H, chunk, wsf + wsl.partial);
+    hipLaunchKernelGGL(cpb_final_kernel, dim3((CPB_SLAB + 255) / 256), dim3(256), 0, st, wsf + wsl.partial, nchunks, H / G, dw1, db1, dw2, db2, dw3, db3, posdim);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/reduce");
+  }
+  return SMML_OK;
+}
+
+}  // extern "C"

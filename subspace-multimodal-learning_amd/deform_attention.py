@@ -9,6 +9,8 @@ so `state_dict`s are interchangeable.  The nn.Conv / nn.Linear sub-modules only 
 
 Additive knobs (reference defaults kept): `grid_hw` - the reference hard-wires a 50 x 50 token grid
 (DeformableAttention2D.py:239-240,318); here the grid defaults to the square root of the token count.
+`compute_dtype` (None | 'bf16' | 'fp16', default None): the 16-bit compute mode of the fused attention core
+(csrc/deform_attn16.hip; BASELINE config 4 names bf16) - parameters, inputs, outputs and gradients stay fp32.
 Corrected-semantics switches, OFF by default (bit-parity with the reference needs them off):
   * DeformCrossAttention2D(consistent_grid_norm=True): the reference normalises sample positions with the
     align_corners=True formula 2 v / (t - 1) - 1 (:100-108,265; x divided by rows - 1, y by cols - 1) but samples with
@@ -98,9 +100,11 @@ def _build_grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
 class DeformCrossAttention2D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=4,
                  offset_groups=8, offset_kernel_size=6, group_queries=True, group_key_values=True,
-                 grid_hw: Optional[Tuple[int, int]] = None, consistent_grid_norm: bool = False):
+                 grid_hw: Optional[Tuple[int, int]] = None, consistent_grid_norm: bool = False, compute_dtype=None):
         super().__init__()
         self.consistent_grid_norm = bool(consistent_grid_norm)
+        Fh._dtype16(compute_dtype)             # validates: None | 'bf16' | 'fp16'
+        self.compute_dtype = compute_dtype     # additive: None = the fp32-grade path, else the 16-bit compute mode of the fused core
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -159,7 +163,7 @@ class DeformCrossAttention2D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
-                                **_dropout_args(self, q.device))
+                                compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 
@@ -174,9 +178,11 @@ class DeformCrossAttention2D(nn.Module):
 class DeformCrossAttention1D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None,
                  offset_groups=4, offset_kernel_size=6, cpb_log_distance=True, group_queries=False,
-                 group_key_values=False, true_1d_sampling: bool = False):
+                 group_key_values=False, true_1d_sampling: bool = False, compute_dtype=None):
         super().__init__()
         self.true_1d_sampling = bool(true_1d_sampling)
+        Fh._dtype16(compute_dtype)
+        self.compute_dtype = compute_dtype
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -224,7 +230,7 @@ class DeformCrossAttention1D(nn.Module):
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
-                                scale=self.scale, **_dropout_args(self, q.device))
+                                scale=self.scale, compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
         return (out, vgrid) if return_vgrid else out
 

@@ -32,8 +32,8 @@ class KernelTimer:
             return None, None
         L = capi.lib()
         a, b = L.smml_event_create(), L.smml_event_create()
-        self.pairs[name].append((a, b))
-        self.work[name].append(pairs_count)
+        self.pairs.setdefault(name, []).append((a, b))
+        self.work.setdefault(name, []).append(pairs_count)
         return a, b
 
     def collect(self):
@@ -772,9 +772,24 @@ def bilinear_corners(vs, Hh: int, Ww: int, posdim: int):
 # ------------------------------------------------------------------------------------------------
 # fused attention core with continuous position bias
 # ------------------------------------------------------------------------------------------------
+_DTYPE16 = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
+
+
+def _dtype16(compute_dtype):
+    """None (the fp32-grade path) or the (C-ABI code, torch dtype) of the 16-bit compute mode."""
+    if compute_dtype is None:
+        return None
+    key = {"bfloat16": "bf16", "float16": "fp16", "half": "fp16"}.get(str(compute_dtype).replace("torch.", ""),
+                                                                      str(compute_dtype).replace("torch.", ""))
+    if key not in _DTYPE16:
+        raise ValueError(f"compute_dtype must be None, 'bf16' or 'fp16' (got {compute_dtype!r})")
+    return _DTYPE16[key]
+
+
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None):
+    def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
+                compute_dtype=None):
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
         B, N, HD = q.shape
@@ -785,6 +800,7 @@ class _DeformAttn(torch.autograd.Function):
         if tuple(w2.shape) != (32, 32):
             raise RuntimeError("the position-bias kernels are built for a hidden width of 32 (dim = 128)")
         L = capi.lib()
+        m16 = _dtype16(compute_dtype)
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad)
@@ -792,18 +808,26 @@ class _DeformAttn(torch.autograd.Function):
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
             # score-shaped tensors are stored per 32-query tile (include/smml.h): [B, H, nst / 32, J, 32] (+ the lane-half axis of the masks)
-            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32)
+            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32 if m16 is None else m16[1])
             masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
         _set_seed_offset(L, seed_offset)
-        capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
-                                              capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
-                                              capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
-                                              heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
-                                              *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
-                   "deform_attn_fwd")
+        if m16 is None:
+            capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                                  capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                                  capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
+                                                  heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
+                                                  *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
+                       "deform_attn_fwd")
+        else:
+            capi.check(L.smml_deform_attn16_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                                capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                                capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.ptr(logits), capi.ptr(masks), B, N, J,
+                                                heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed), m16[0],
+                                                *TIMER.events("deform16_fwd", B * heads * N * J), capi.stream()),
+                       "deform_attn16_fwd")
         _set_seed_offset(L, None)
         ctx.seed_offset = seed_offset           # a device int64 [1] owned by this call (hipGraph replays: deform_attention)
-        ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed))
+        ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         if DECISION_TAP is not None:
             DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(), "masks2": masks,
@@ -813,29 +837,39 @@ class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks = ctx.saved_tensors
-        heads, groups, scale, dropout_p, dropout_seed = ctx.cfg
+        heads, groups, scale, dropout_p, dropout_seed, m16 = ctx.cfg
         B, N, _ = q.shape
         J = k.shape[1]
         posdim = vs.shape[-1]
         L = capi.lib()
         dout = _c(dout)
-        dlogits = torch.empty_like(logits)
+        dlogits = torch.empty_like(logits) if m16 is None else torch.empty(logits.shape, device=q.device, dtype=torch.bfloat16)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dvs = torch.empty_like(vs)
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
         _set_seed_offset(L, ctx.seed_offset)
-        capi.check(L.smml_deform_attn_bwd_f32(
-            capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
-            capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
-            capi.fptr(logits), capi.ptr(masks), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
-            capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
-            capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
-            *TIMER.events("cpb_bwd", B * heads * N * J),
-            capi.stream()), "deform_attn_bwd")
+        if m16 is None:
+            capi.check(L.smml_deform_attn_bwd_f32(
+                capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
+                capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
+                capi.fptr(logits), capi.ptr(masks), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+                capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
+                capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
+                *TIMER.events("cpb_bwd", B * heads * N * J),
+                capi.stream()), "deform_attn_bwd")
+        else:
+            capi.check(L.smml_deform_attn16_bwd(
+                capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
+                capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
+                capi.ptr(logits), capi.ptr(masks), capi.ptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+                capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
+                capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed, m16[0],
+                *TIMER.events("cpb16_bwd", B * heads * N * J),
+                capi.stream()), "deform_attn16_bwd")
         _set_seed_offset(L, None)
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None
 
 
 def _set_seed_offset(L, t):
@@ -871,12 +905,14 @@ def graph_seed_offset(device, allocate_only: bool = False):
 
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
-                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None):
+                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
-    (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset)."""
+    (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
+    compute_dtype None: fp32-grade split products (csrc/deform_attn.hip); 'bf16' / 'fp16': the 16-bit compute mode
+    (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32)."""
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
-                             dropout_seed_offset)
+                             dropout_seed_offset, compute_dtype)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):

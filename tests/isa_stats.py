@@ -14,7 +14,7 @@ txt = open(out).read()
 print("asm:", out)
 for m in re.finditer(r"^(_Z\w+):\n(.*?)\n\s*\.end_amdhsa_kernel", txt, re.S | re.M):
     name, body = m.group(1), m.group(2)
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["/usr/bin/c++filt", name], capture_output=True, text=True).stdout.strip()
     lines = [l.strip() for l in body.split("\n")]
     ins = [l for l in lines if l and not l.startswith((";", ".", "/")) and not l.endswith(":")]
     def mix(seq):

@@ -1,0 +1,218 @@
+"""GPU parity of the 16-bit compute mode of the fused deformable attention (csrc/deform_attn16.hip; BASELINE config 4 names bf16,
+config 5 fp16): DeformCrossAttention2D / 1D(compute_dtype='bf16' | 'fp16') and the fused core against the fp64 oracle.
+
+Tolerance of this mode, stated ONCE here (the way tests/test_gpu_attn16.py states the Nystrom block's): every tensor is compared with
+the fp64 evaluation in the max norm relative to the tensor's own scale -
+    forward values                 bf16 1.5e-2    fp16 2e-3     (8 / 11 operand mantissa bits on q, k, v, P, h1, W2 and the stored scores)
+    gradients                      bf16 3e-2      fp16 1.5e-2   (gradient-range operands - dO, dS, g = h1 . d bias - are bf16 in BOTH modes:
+                                                                 fp32's exponent range without a loss scale; sums of ~1e5..1e8 such terms)
+fp32 accumulation everywhere.  The piecewise-linear decisions the kernels took (sampler cells, both ReLU layers of the position-bias MLP)
+are exported and imposed on the oracle exactly as in the fp32-grade tests (tests/helpers.py): layer 1 is the SAME fp32-grade device
+function in both modes (its decisions may differ from fp64 only at rounding level, 2e-6); layer 2 is a single-term 16-bit product here,
+so its decisions may differ where |W2 h1 + b2| is within the 16-bit rounding of the product (asserted below: 2^-7 / 2^-10 of sum |W2||h1|)."""
+import math
+
+import pytest
+import torch
+
+import helpers
+import oracle.deform as odeform
+from helpers import assert_close, decision_tap, params_for, rel_err, smml, synth
+from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d
+from test_gpu_parity import _core_reference, cpb_probe
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+
+FWD_TOL = {"bf16": 1.5e-2, "fp16": 2e-3}
+GRAD_TOL = {"bf16": 3e-2, "fp16": 1.5e-2}
+L2_MARGIN = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # layer-2 decisions: |pre-activation| of a flipped unit <= margin x sum |W2| |h1| (+ |b2|)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_fused_core16_random_shapes(cuda, mode):
+    """The 16-bit fused core (forward + the three backward passes) on random ragged shapes - N, J off the 32 / 128 tiles, one or two
+    heads per offset group, 1-D and 2-D positions, with and without dropout - against plain torch in fp64 with the kernels' own
+    ReLU decisions and dropout mask imposed."""
+    gen = torch.Generator().manual_seed(4321)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    forced = [(1, 1, 65, 8, 1, 0.0), (2, 33, 5, 4, 2, 0.25), (1, 129, 33, 8, 2, 0.0), (1, 300, 1, 8, 2, 0.0)]
+    nrand = 8
+    worst = {}
+    for case in range(nrand + len(forced)):
+        B, N, J = ri(1, 3), ri(1, 300), ri(2, 90)
+        groups = (4, 8)[ri(0, 1)]
+        heads, PD, p_drop = 8, ri(1, 2), (0.0, 0.25)[ri(0, 1)]
+        if case >= nrand:
+            B, N, J, groups, PD, p_drop = forced[case - nrand]
+        rn = lambda *s: torch.randn(*s, generator=gen)
+        t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+                 gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+                 w3=rn(heads // groups, 32) * 0.3, b3=rn(heads // groups) * 0.1)
+        wo = rn(B, N, 512)
+        names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+        dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+        seed = 170 + case
+        smml.functional.DECISION_TAP = tapped = []
+        try:
+            out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=p_drop,
+                                      dropout_seed=seed, compute_dtype=mode)
+        finally:
+            smml.functional.DECISION_TAP = None
+        (out * wo.to(cuda)).sum().backward()
+        keep = Fh.deform_attention_dropout_mask(B, N, J, heads, p_drop, seed, cuda) if p_drop else None
+        a = tapped[0]
+        m1 = helpers.Decisions.decode(Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=groups), 0, N, cuda)
+        m2 = helpers.Decisions.decode(Fh.relu_masks_rows(a["masks2"])[:, ::heads // groups].reshape(B * groups, J, 2, -1), 0, N, cuda)
+        r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+        o = _core_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / (1.0 - p_drop), masks=(m1, m2))
+        (o * wo.to(cuda, torch.float64)).sum().backward()
+        with torch.no_grad():       # the decisions against the exact pre-activations
+            pos = r["gq"][None, :, None, :] - r["vs"].view(B * groups, 1, J, PD)
+            x1 = (torch.sign(pos) * torch.log(pos.abs() + 1)) @ r["w1"].T + r["b1"]
+            h1 = torch.relu(x1)
+            x2 = h1 @ r["w2"].T + r["b2"]
+            bad1 = x1[(x1 > 0) != m1].abs()
+            assert bad1.numel() == 0 or float(bad1.max()) < 2e-6, f"case {case}: layer-1 decision off by {float(bad1.max()):.2e}"
+            mag = h1 @ r["w2"].abs().T + r["b2"].abs()                      # sum |W2| |h1| + |b2| per unit
+            flip = (x2 > 0) != m2
+            if flip.any():
+                ratio = float((x2.abs() / mag.clamp_min(1e-30))[flip].max())
+                worst["l2 flip / magnitude"] = max(worst.get("l2 flip / magnitude", 0.0), ratio)
+                assert ratio < L2_MARGIN[mode], f"case {case}: a layer-2 decision differs from fp64 at {ratio:.2e} of the unit's magnitude"
+        tag = f"{mode} case {case}: B={B} N={N} J={J} G={groups} PD={PD} p={p_drop}"
+        e = rel_err(out, o); worst["out"] = max(worst.get("out", 0.0), e)
+        assert_close(tag + " out", out, o, FWD_TOL[mode])
+        for n in t:
+            if n in ("gq", "b3"):
+                continue
+            g, g64 = dev[n].grad, r[n].grad
+            if float(g64.abs().max()) < 1e-9:               # identically zero in exact arithmetic (one key: dS = 0)
+                assert float(g.abs().max()) < 5e-2, f"{tag} d{n}: expected ~0, got {float(g.abs().max()):.3e}"
+                continue
+            e = rel_err(g, g64); worst["d" + n] = max(worst.get("d" + n, 0.0), e)
+            assert_close(tag + " d" + n, g, g64, GRAD_TOL[mode])
+    print(f"\n[deform16 {mode}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("train", [False, True])
+def test_deform2d_16bit_vs_oracle(cuda, mode, train):
+    """DeformCrossAttention2D(compute_dtype=...) on a 20 x 20 grid, eval and train (dropout 0.1 with the kernel's exported mask): output,
+    vgrid (untouched by the mode: exact), input and parameter gradients against the fp64 oracle with the kernels' decisions imposed."""
+    B, Hh, Ww, C = 2, 20, 20, 128
+    N = Hh * Ww
+    tag = f"d2d16:{mode}:{int(train)}"
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww), compute_dtype=mode)
+    params = params_for(mod, 31, tag)
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).train(train)
+    x1 = synth.normal((B, C, N), 31, tag + ":x1"); x2 = synth.normal((B, C, N), 31, tag + ":x2")
+    w_out = synth.normal((B, C, N), 31, tag + ":wo")
+    torch.manual_seed(99)
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o, vg = mod(ad, bd, return_vgrid=True)
+    (o * w_out.to(cuda)).sum().backward()
+    J = vg.shape[-1] * vg.shape[-2]
+    keep = Fh.deform_attention_dropout_mask(B, N, J, 8, 0.1, mod.last_dropout_seed, cuda).cpu() if train else None
+    dt = torch.float64
+    pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+    a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+    odeform.DECISIONS = tap.decisions()
+    kw = dict(attn_keep=keep, dropout_p=0.1) if train else {}
+    o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), **kw)
+    (o_ref * w_out.to(dt)).sum().backward()
+    assert_close(tag + " vgrid", vg, vg_ref, 1e-5)
+    assert_close(tag + " out", o, o_ref, FWD_TOL[mode])
+    assert_close(tag + " dx1", ad.grad, a.grad, GRAD_TOL[mode])
+    assert_close(tag + " dx2", bd.grad, b.grad, GRAD_TOL[mode])
+    for k, p in mod.named_parameters():
+        if k.endswith("rel_pos_bias.mlp.2.bias"):           # zero in exact arithmetic (softmax shift invariance)
+            continue
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, GRAD_TOL[mode])
+    # the mode changes nothing outside the fused core: same vgrid bits as the fp32-grade module
+    ref_mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww))
+    ref_mod.load_state_dict(params)
+    ref_mod = ref_mod.to(cuda).eval()
+    with torch.no_grad():
+        o32, vg32 = ref_mod(ad.detach(), bd.detach(), return_vgrid=True)
+    assert torch.equal(vg32, vg.detach())
+    if not train:
+        assert_close(tag + " out vs fp32-grade path", o, o32, FWD_TOL[mode])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_deform1d_16bit_vs_oracle(cuda, mode):
+    """DeformCrossAttention1D(compute_dtype=...): two heads per offset group, 1-D positions, n = 129 (front of a ragged tile)."""
+    B, n, C = 2, 129, 128
+    tag = f"d1d16:{mode}"
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, compute_dtype=mode)
+    params = params_for(mod, 33, tag)
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).eval()
+    x1 = synth.normal((B, C, n), 33, tag + ":x1"); x2 = synth.normal((B, C, n), 33, tag + ":x2")
+    w_out = synth.normal((B, C, n), 33, tag + ":wo")
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o = mod(ad, bd)
+    (o * w_out.to(cuda)).sum().backward()
+    dt = torch.float64
+    pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+    a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+    odeform.DECISIONS = tap.decisions()
+    o_ref, _ = deform_cross_attention_1d(a, b, pref, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    (o_ref * w_out.to(dt)).sum().backward()
+    assert_close(tag + " out", o, o_ref, FWD_TOL[mode])
+    assert_close(tag + " dx1", ad.grad, a.grad, GRAD_TOL[mode])
+    assert_close(tag + " dx2", bd.grad, b.grad, GRAD_TOL[mode])
+    for k, p in mod.named_parameters():
+        if k.endswith("rel_pos_bias.mlp.2.bias") or pref[k].grad is None:
+            continue
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, GRAD_TOL[mode])
+
+
+def test_core16_gradients_are_run_to_run_identical(cuda):
+    """Fixed-order reductions in the 16-bit mode too: two runs give the same bits (dropout on)."""
+    gen = torch.Generator().manual_seed(22)
+    B, N, J, heads, groups, PD = 2, 700, 150, 8, 4, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+             w3=rn(heads // groups, 32) * 0.3, b3=rn(heads // groups) * 0.1)
+    wo = rn(B, N, 512).to(cuda)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    runs = []
+    for _ in range(2):
+        dev = {n: x.to(cuda).requires_grad_(n != "gq") for n, x in t.items()}
+        out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=0.1, dropout_seed=5,
+                                  compute_dtype="bf16")
+        (out * wo).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({n: dev[n].grad.clone() for n in names if n != "gq"} | {"out": out.detach().clone()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), f"{n} differs between two runs"
+
+
+def test_core16_dropout_decisions_ride_in_the_saved_scores(cuda):
+    """Train mode: the keep decisions the backward reads from the lowest bit of the saved 16-bit scores are the exported mask's -
+    checked through the gradient: with v = const every dropped pair contributes nothing to dv, so dv[key] = sum_q keep P dO exactly as
+    the exported mask says (fp64 recomputation from the kernel's own saved probabilities is not needed: compare with the oracle core)."""
+    gen = torch.Generator().manual_seed(5)
+    B, N, J, heads, groups, PD, p = 1, 257, 70, 8, 8, 2, 0.3
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.3, k=rn(B, J, 512) * 0.3, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2 - 1,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.5, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.2, b2=rn(32) * 0.2,
+             w3=rn(1, 32) * 0.3, b3=rn(1) * 0.1)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    for mode in ("bf16", "fp16"):
+        dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+        out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=p, dropout_seed=77, compute_dtype=mode)
+        out.sum().backward()
+        keep = Fh.deform_attention_dropout_mask(B, N, J, heads, p, 77, cuda)
+        r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+        o = _core_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / (1.0 - p))
+        o.sum().backward()
+        # a wrong keep bit anywhere moves dv by O(P) of single pairs: far above the mode's rounding
+        assert_close(f"{mode} dv under dropout", dev["v"].grad, r["v"].grad, GRAD_TOL[mode])
+        assert_close(f"{mode} out under dropout", out, o, FWD_TOL[mode] * 2)
