@@ -34,6 +34,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: pe
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA - the pipe every contraction of the dominant kernels issues on
 CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 1 + 1 + 2 + 4 + 4
 CPB_FWD_MFMAS = 7                   # deform_attn_fwd_kernel: 1 (layer 1) + 6 (layer 2, three-term split) 16-bit MFMAs per (key, 32 queries)
+CPB16_BWD_MFMAS = 8                 # cpb16_bwd_kernel (16-bit compute mode): 1 + 1 + 2 + 2 + 2
+CPB16_FWD_MFMAS = 3                 # deform16_fwd_kernel: 1 (layer 1) + 2 (layer 2, one term) + 8/32 for QK^T / PV
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
 TRAFFIC_FILE = "r03_hbm_traffic.json"
@@ -196,6 +198,60 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
             "qkav_share_of_flops": qkav / total}
 
 
+def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3):
+    """The headline training step (same model, parameters, bags, losses, Adam) with the fused attention core in its 16-bit compute
+    mode (csrc/deform_attn16.hip; BASELINE config 4 names bf16): ms per step by wall clock between synchronisations, the two dominant
+    kernels by HIP events on their launch stream, algorithmic flops as for the fp32-grade line.  Not part of `value`."""
+    Fh = pkg.functional
+    N = S * S
+    torch.manual_seed(42)
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, dtype))
+    mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
+    mil = mil.to(dev).train()
+    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True)
+    bloss = pkg.BatchLoss(B, 1)
+    path = pkg.synth.bag(B, N, in_dim, 42, "bench:bag").to(dev)
+    omic = torch.relu(pkg.synth.normal((B, 128), 42, "bench:omicvec")).to(dev)
+    label = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def step():
+        enc, logits, _, omic_t, vgrid = mil(path, omic)
+        loss = torch.nn.functional.cross_entropy(logits, label) + torch.sum(bloss(omic_t, vgrid))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    Fh.TIMER.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    Fh.TIMER.enabled = False
+    kt = Fh.TIMER.collect()
+    out = {"workload": f"the headline step with DeformCrossAttention2D(compute_dtype='{dtype}'): {B} bags of {N} x {in_dim} per step, "
+                       f"fwd + bwd + Adam, CE + BatchLoss; parameters, inputs, outputs and gradients fp32 in memory",
+           "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
+    if "cpb16_bwd" in kt:
+        n, ms, pairs = kt["cpb16_bwd"]
+        flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR
+        out["roofline"] = {"kernel": "cpb16_bwd_kernel<2>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, "avg_ms": ms, "launches": n,
+                           "flop_per_launch": flop, "mfmas_per_key_and_32_queries": CPB16_BWD_MFMAS}
+    if "deform16_fwd" in kt:
+        n, ms, pairs = kt["deform16_fwd"]
+        flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
+        out["roofline_fwd"] = {"kernel": "deform16_fwd_kernel<2, true>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12,
+                               "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                               "avg_ms": ms, "launches": n, "flop_per_launch": flop, "mfmas_per_key_and_32_queries": CPB16_FWD_MFMAS}
+    del mil, opt
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +261,7 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-deform16", action="store_true", help="skip the 16-bit-compute-mode leg of the headline step (extra key `deform16`, not part of `value`)")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
     ap.add_argument("--deform-dtype", default=None, choices=[None, "bf16", "fp16"],
@@ -340,6 +397,10 @@ def main():
             # results), so the algorithmic flops are priced against THAT pipe's dense peak; what actually bounds the kernel is
             # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~265 vector instructions per 12 MFMAs.
             traffic, tsrc = None, "not collected (--no-traffic, or N > 1)"
+            if world == 1 and not a.no_deform16 and not a.deform_dtype:
+                # BASELINE config 4 as stated (bf16 compute): the same step with the fused core in its 16-bit mode, driver-run
+                out["deform16"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3)
+                out["deform16"]["speedup_vs_fp32_line"] = out["deform16"]["bags_per_s"] / out["value"]
             if world == 1 and not a.no_nystrom:
                 # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
                 # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
@@ -347,7 +408,7 @@ def main():
                                   nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
             if world == 1 and not a.no_traffic:
                 traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
-                                                                "--no-traffic", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
+                                                                "--no-traffic", "--no-deform16", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
             if tsrc.startswith(("CHILD_TIMEOUT", "CHILD_SIGNAL")):
                 out["pmc_child_failed"] = tsrc           # a hung / crashed profiler child is surfaced, not folded into a fallback
             if traffic is None and world == 1 and not a.no_traffic and (S, in_dim) == (100, 512):

@@ -57,7 +57,9 @@ int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, c
 void smml_gemm_force_generic(int on);
 /* precision / tuning switch of the tiled kernels: 0 automatic (default: exact fp32 on the f32 MFMA, split-bf16 for large
  * square-ish products), 1 fp32-MFMA kernel only, 2 split-bf16 (three terms, fp32-grade) wherever it applies, 3 single-term bf16
- * (operands rounded to bf16 when staged, fp32 accumulation: the 16-bit compute mode of the Nystrom block). */
+ * (operands rounded to bf16 when staged, fp32 accumulation: the 16-bit compute mode of the Nystrom block), 4 single-term fp16 (operands
+ * rounded to fp16 when staged - 11 mantissa bits, fp16's exponent range: for forward-range operands; the fp16 compute modes issue their
+ * gradient products in mode 3). */
 void smml_gemm_set_mode(int mode);
 int smml_gemm_get_mode(void);
 /* tile-height switch of the tiled kernels: 0 automatic (64-row tiles for launches that the 128-row tiling leaves below two
@@ -180,8 +182,8 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
  * smml_deform_attn_fwd_f32 / _bwd_f32 (models/DeformableAttention2D.py:120-157,284-312; DeformableAttention1D.py:60-102,205-232) with
  * single-term 16-bit operands on the matrix pipe - dtype 0 = bf16, 1 = fp16 for forward-range operands (q, k, v, probabilities, the
  * hidden layer and W2 of the position-bias MLP); gradient-range operands are always bf16 - and 16-bit score storage:
- *   logits16  [B, H, nst / 32, J, 32] of dtype (the pre-softmax scores incl. bias; in training the forward's own softmax runs on the
- *             rounded values, and with dropout the keep decision rides in the lowest mantissa bit)
+ *   logits16  [B, H, nst / 32, J, 32] fp16 in BOTH modes (the pre-softmax scores incl. bias are of forward range; in training the forward's
+ *             own softmax runs on the rounded values, and with dropout the keep decision rides in the lowest mantissa bit)
  *   dlogits16 [B, H, nst / 32, J, 32] bf16 (scratch of the backward: d scores = d bias)
  * q / k / v / out and every gradient stay fp32 in memory; layer 1 of the position-bias MLP, the softmax statistics and all
  * accumulators are fp32; relu_masks, the workspace (smml_deform_attn_bwd_workspace_bytes) and the decision export

@@ -401,6 +401,51 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   fetch(0, kreg, vreg, lt);
 
   const int ntiles = (J + KT - 1) / KT;
+#if SMML_DELTA_EXACT
+  // Measurement variant: delta = sum_k P_k dP_k from the SAME dP products the d scores are made of, in a first sweep
+  // over the keys, instead of rowsum(dO . O).  A systematic relative error of the dP products (the matrix pipe truncates the aligned
+  // products of a block toward zero, tests/microbench/mfma_round_probe.hip) then scales dS as a whole instead of surviving the
+  // cancellation dP - delta, where it is amplified by |dP| / |dP - delta|.
+  {
+    float dsum = 0.f;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int j0 = kt * KT, buf = kt & 1;
+      const int nk = min(KT, J - j0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int key = skey + 16 * i;
+        uint2v hh, mm, ll;
+        split4_bf3(vreg[i], hh, mm, ll);
+        *reinterpret_cast<uint2v*>(&Vp[buf][0][key * VBLD + sd4]) = hh;
+        *reinterpret_cast<uint2v*>(&Vp[buf][1][key * VBLD + sd4]) = mm;
+        *reinterpret_cast<uint2v*>(&Vp[buf][2][key * VBLD + sd4]) = ll;
+      }
+      __syncthreads();
+      float ltc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ltc[r] = lt[r];
+      if (kt + 1 < ntiles) fetch(j0 + KT, kreg, vreg, lt);
+      floatx16 dp = {0};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int o = c * VBLD + 16 * kb + 8 * hf;
+        dp = bwd_prod<3>(*reinterpret_cast<const bf16x8*>(&Vp[buf][0][o]), *reinterpret_cast<const bf16x8*>(&Vp[buf][1][o]),
+                         *reinterpret_cast<const bf16x8*>(&Vp[buf][2][o]), doh[kb], dom[kb], dol[kb], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (acc_row(r, hf) < nk) {
+          float dpr = dp[r];
+          if (dc.thresh) dpr *= stashed_factor(ltc[r], dc.keep_scale);
+          dsum = fmaf(prob_of(ltc[r], nl), dpr, dsum);
+        }
+      }
+    }
+    delta = xhalf_sum(dsum);
+    __syncthreads();
+    fetch(0, kreg, vreg, lt);
+  }
+#endif
   for (int kt = 0; kt < ntiles; ++kt) {
     const int j0 = kt * KT, buf = kt & 1;
     const int nk = min(KT, J - j0);

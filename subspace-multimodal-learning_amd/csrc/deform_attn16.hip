@@ -7,9 +7,10 @@
 //
 // What is 16 bit (T = bf16 or fp16 for everything of forward range; gradient-range operands are always bf16 - fp32's exponents):
 //   forward   q, k, v, the softmax'd probabilities and the hidden layer h1 of the position-bias MLP are rounded to T when they
-//             become MFMA operands; W2 is one T term; the pre-softmax scores (incl. bias) are stored as T [B, H, nst / 32, J, 32]
-//             and - in training - the forward's own softmax runs on the ROUNDED scores, so forward and backward see one set of
-//             probabilities.  With dropout the keep decision rides in the stored score's lowest mantissa bit (as in the fp32 path).
+//             become MFMA operands; W2 is one T term; the pre-softmax scores (incl. bias) are stored as fp16 [B, H, nst / 32, J, 32]
+//             (both modes: forward range, 11 bits) and - in training - the forward's own softmax runs on the ROUNDED scores, so forward
+//             and backward see one set of probabilities.  With dropout the keep decision rides in the stored score's lowest mantissa
+//             bit (as in the fp32 path).
 //   backward  K, V, Q, dO, P, dS as single bf16 terms; d scores stored as bf16; chain 2 of the position-bias backward with the
 //             constant (W2 w3)^T as one fp16 term against the exact 0 / 1 mask operand; g = h1 . d bias as one bf16 term.
 // What stays fp32: layer 1 of the position-bias MLP (the three-term bf16 product of deform_common.h - the SAME device function as
@@ -61,6 +62,12 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type frag_tr(
   const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
   return __builtin_bit_cast(typename Vec8<T>::type, r);
 }
+// Stored scores are fp16 in BOTH modes: they are of forward range (softmax logits; clamped to +-60000 so that nothing rounds to inf)
+// and fp16's 11 significant bits keep exp(score - lse) to 2^-11 |score| - eight times finer than bf16 at the same two bytes.
+__device__ __forceinline__ unsigned pack_score(float a, float b) {
+  return pack2<_Float16>(fminf(fmaxf(a, -60000.f), 60000.f), fminf(fmaxf(b, -60000.f), 60000.f));
+}
+__device__ __forceinline__ float score_of(unsigned u) { return tof<_Float16>(u); }
 // the dropout keep decision in the lowest mantissa bit of a stored 16-bit score (deform_common.h stash_keep, on 16-bit patterns:
 // at most one ulp, direction from the second-lowest bit, never across +-0)
 __device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) {
@@ -236,25 +243,25 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
       if (nk == KT) {                            // full tile (uniform): no per-key bounds
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const unsigned w = pack2<T>(s[r], s[r + 1]);
+          const unsigned w = pack_score(s[r], s[r + 1]);
           unsigned lo = w & 0xFFFFu, hi = w >> 16;
           if (dc.thresh) { lo = stash_keep16(lo, (keepbits >> r) & 1u); hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u); }
           LTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = (u16)lo;
           LTb[(size_t)(j0 + acc_row(r + 1, hf)) * 32 + c] = (u16)hi;
-          s[r] = tof<T>(lo); s[r + 1] = tof<T>(hi);
+          s[r] = score_of(lo); s[r + 1] = score_of(hi);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const unsigned w = pack2<T>(s[r], s[r + 1]);
+          const unsigned w = pack_score(s[r], s[r + 1]);
           unsigned lo = w & 0xFFFFu, hi = w >> 16;
           const int k0 = acc_row(r, hf), k1 = acc_row(r + 1, hf);
           if (dc.thresh) {
             if (k0 < nk) lo = stash_keep16(lo, (keepbits >> r) & 1u);
             if (k1 < nk) hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u);
           }
-          if (k0 < nk) { LTb[(size_t)(j0 + k0) * 32 + c] = (u16)lo; s[r] = tof<T>(lo); }
-          if (k1 < nk) { LTb[(size_t)(j0 + k1) * 32 + c] = (u16)hi; s[r + 1] = tof<T>(hi); }
+          if (k0 < nk) { LTb[(size_t)(j0 + k0) * 32 + c] = (u16)lo; s[r] = score_of(lo); }
+          if (k1 < nk) { LTb[(size_t)(j0 + k1) * 32 + c] = (u16)hi; s[r + 1] = score_of(hi); }
         }
       }
     }
@@ -310,15 +317,17 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 1 (query owners): dS^T = P^T (dP^T - delta) -> bf16 d scores, dQ = scale * dS K.  Single bf16 terms.
+// backward pass 1 (query owners): dS^T = P^T (dP^T - delta) -> bf16 d scores, dQ = scale * dS K.  dP = V dO^T runs in the forward's
+// operand type T (fp16 mode: dO scaled per query by a power of two), dQ = dS K on bf16 terms.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O, const float* __restrict__ dO,
     const float* __restrict__ LSE, const u16* __restrict__ LT, u16* __restrict__ dLT, float* __restrict__ dQ, int N, int J,
     int H, int NST, float scale, DropCfg dc_in) {
+  typedef typename Vec8<T>::type vec8;
   const DropCfg dc = drop_resolve(dc_in);
-  __shared__ __attribute__((aligned(16))) __bf16 Vp[2][KT * VBLD];
+  __shared__ __attribute__((aligned(16))) T Vp[2][KT * VBLD];          // V in the FORWARD's operand type (dP = V dO^T must see the V that made O)
   __shared__ __attribute__((aligned(16))) __bf16 Kp[2][KT * KBLD];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -328,22 +337,48 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
 
-  // dO of this lane's query as the B operand of dP^T = V . dO^T: K-block kb holds d = 16 kb + 8 hf + j
-  bf16x8 dob[4];
+  // dO of this lane's query as the B operand of dP^T = V . dO^T (K-block kb holds d = 16 kb + 8 hf + j), rounded to T; in fp16 mode
+  // the row is first scaled by a power of two 2^-e so that its largest element sits in [0.5, 1) (fp16 has 5 exponent bits: gradients
+  // need a scale; per query it is exact and free - 2^e rides on the probabilities through the exponent bias below).
+  // delta = rowsum(dO . O) is formed from the ROUNDED dO: dS = P (dP - delta) must cancel exactly where it does in exact arithmetic
+  // (one key: dP = dO . V = dO . O), and sum_k dS_k stays at the rounding of the probabilities instead of that of dO (2^-9).
+  vec8 dob[4];
   float delta = 0.f;
+  int e2 = 0;
   {
     const size_t off = ((size_t)b * N + qi) * HD + h * DH + hf * 8;
+    float4 t[8];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      const float4 t0 = *reinterpret_cast<const float4*>(dO + off + 16 * kb), t1 = *reinterpret_cast<const float4*>(dO + off + 16 * kb + 4);
+      t[2 * kb] = *reinterpret_cast<const float4*>(dO + off + 16 * kb); t[2 * kb + 1] = *reinterpret_cast<const float4*>(dO + off + 16 * kb + 4);
+    }
+    float inv = 1.f;
+    if (sizeof(T) == 2 && !__is_same(T, __bf16)) {
+      float amax = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[i].x), fabsf(t[i].y))), fmaxf(fabsf(t[i].z), fabsf(t[i].w)));
+      amax = xhalf_max(amax);
+      const int eb = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);          // biased exponent: amax in [2^(eb-127), 2^(eb-126))
+      e2 = (amax > 0.f) ? min(max(eb - 126, -100), 100) : 0;
+      inv = __builtin_bit_cast(float, (unsigned)(127 - e2) << 23);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 t0 = t[2 * kb], t1 = t[2 * kb + 1];
       const float4 u0 = *reinterpret_cast<const float4*>(O + off + 16 * kb), u1 = *reinterpret_cast<const float4*>(O + off + 16 * kb + 4);
-      delta += t0.x * u0.x + t0.y * u0.y + t0.z * u0.z + t0.w * u0.w + t1.x * u1.x + t1.y * u1.y + t1.z * u1.z + t1.w * u1.w;
-      const float x8[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-      dob[kb] = cvt8<__bf16>(x8);
+      const float x8[8] = {t0.x * inv, t0.y * inv, t0.z * inv, t0.w * inv, t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv};
+      dob[kb] = cvt8<T>(x8);
+      const uint4v w = __builtin_bit_cast(uint4v, dob[kb]);
+      delta += tof<T>(w[0] & 0xFFFFu) * u0.x + tof<T>(w[0] >> 16) * u0.y + tof<T>(w[1] & 0xFFFFu) * u0.z + tof<T>(w[1] >> 16) * u0.w +
+               tof<T>(w[2] & 0xFFFFu) * u1.x + tof<T>(w[2] >> 16) * u1.y + tof<T>(w[3] & 0xFFFFu) * u1.z + tof<T>(w[3] >> 16) * u1.w;
     }
   }
-  delta = xhalf_sum(delta);
-  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
+  delta = xhalf_sum(delta);                             // of the scaled row: dP below is scaled alike
+#if SMML_FAST_MATH
+  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]) + (float)e2;                       // P 2^e = exp2(l log2e - lse log2e + e)
+#else
+  const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]) + (float)e2 * 0.6931471805599453f;
+#endif
 
   floatx16 dq0 = {0}, dq1 = {0};
   const float* Kb = K + (size_t)b * J * HD + h * DH;
@@ -380,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = skey + 16 * i;
-      *reinterpret_cast<uint2v*>(&Vp[buf][key * VBLD + sd4]) = pack4<__bf16>(vreg[i]);
+      *reinterpret_cast<uint2v*>(&Vp[buf][key * VBLD + sd4]) = pack4<T>(vreg[i]);
       *reinterpret_cast<uint2v*>(&Kp[buf][key * KBLD + sd4]) = pack4<__bf16>(kreg[i]);
     }
     __syncthreads();        // one barrier per tile (double buffer)
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
     floatx16 dp = {0};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
-      dp = mfma16b(*reinterpret_cast<const bf16x8*>(&Vp[buf][c * VBLD + 16 * kb + 8 * hf]), dob[kb], dp);
+      dp = mma(*reinterpret_cast<const vec8*>(&Vp[buf][c * VBLD + 16 * kb + 8 * hf]), dob[kb], dp);
 
     float ds[16];
     const bool interior = (nk == KT && q0 + QT <= N);      // uniform
@@ -405,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
         const int key = acc_row(r + e, hf);
         float v = 0.f;
         if (interior || (key < nk && qvalid)) {
-          const float p = prob_of(tof<T>(ltc[r + e]), nl);
+          const float p = prob_of(score_of(ltc[r + e]), nl);
           float dpr = dp[r + e];
           if (dc.thresh) dpr *= (ltc[r + e] & 1u) ? dc.keep_scale : 0.f;     // the forward's decision rides in the score's lowest bit
           v = p * (dpr - delta);
@@ -447,7 +482,6 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
 // backward pass 2 (key owners): dV = P_dropped^T dO, dK = scale * dS^T Q (deform_attn.hip's mapping; single bf16 terms, the
 // 16-bit scores / d scores are read as 8-byte runs of four consecutive queries).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
 __global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ dO, const float* __restrict__ LSE, const u16* __restrict__ LT,
     const u16* __restrict__ dLT, float* __restrict__ dKp, float* __restrict__ dVp, int N, int J, int H, int NST, int nkg,
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool ok = interior || (kvalid && q0 + acc_row(r, hf) < N);
-        float pv = ok ? prob_of(tof<T>(lv[r]), ls[r]) : 0.f;
+        float pv = ok ? prob_of(score_of(lv[r]), ls[r]) : 0.f;
         if (dc.thresh) pv *= (lv[r] & 1u) ? dc.keep_scale : 0.f;
         p[r] = pv;                                         // dV takes the dropped probabilities, dK the dS written by pass 1
         ds[r] = ok ? dsv[r] : 0.f;
@@ -917,10 +951,7 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
     const int nslices = parts * H * B;
     const dim3 gk(((nslices + 7) / 8) * 8 * nkg);
-    if (dtype == 1)
-      hipLaunchKernelGGL(deform16_bwd_dkv_kernel<_Float16>, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
-    else
-      hipLaunchKernelGGL(deform16_bwd_dkv_kernel<__bf16>, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    hipLaunchKernelGGL(deform16_bwd_dkv_kernel, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
     SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/dkv");
     const size_t n4 = (size_t)B * J * H * DH / 4;
     hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,

@@ -28,6 +28,10 @@
                               // dW3 4x and, with every ReLU unit active, dW2 / db 3-4x closer to fp64; everything else
                               // unchanged; costs 0.3-0.45 ms of the 17.5 ms step (one more score read + an exp per pair).
 #endif
+#ifndef SMML_DELTA_EXACT
+#define SMML_DELTA_EXACT 0    // 1: the dq pass forms delta = sum_k P_k dP_k from its own dP products in a first sweep over the keys (measurement
+                              // variant, deform_attn.hip; + ~0.4 ms per 8-bag step).  Default: delta = rowsum(dO . O).
+#endif
 #ifndef SMML_CHAIN2_TERMS
 #define SMML_CHAIN2_TERMS 2   // fp16 terms of the constant (W2 w3)^T in d h1 = (W2 w3)^T mask.  The mask operand is exact, so the
                               // only error is the constant's: 2 terms = 22 bits, a fixed relative perturbation <= 2^-23 of

@@ -331,6 +331,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 helpers of the single-term fp16 form: four fp32 -> four fp16 (RNE), and the f16 MFMA on fragments held as 16-bit blobs
+__device__ __forceinline__ uint2v f16_pack4(const float4 v) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const float2v a = {v.x, v.y}, b = {v.z, v.w};
+  return (uint2v){__builtin_bit_cast(unsigned, __builtin_convertvector(a, h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(b, h2))};
+}
+__device__ __forceinline__ floatx16 mfma16h(bf16x8 a, bf16x8 b, floatx16 c) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
 // Split-bf16 path ("bf3"): the same fp32 product on the 16-bit matrix pipe.  Every operand element is split into three
 // bf16 terms when its tile is staged (x = h + m + l to 2^-24, fp32's exponent range: no scaling, no overflow) and six of
 // the nine cross products are kept (m m, l h, h l, m h, h m, h h; what is dropped is <= 2^-23 |a||b| per product, i.e.
@@ -344,8 +355,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_fast_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 // TERMS = 1 ("bf1"): only the leading bf16 term of each operand and one product - the plain bf16 matrix-pipe GEMM with fp32
 // storage and fp32 accumulation (8 mantissa bits per operand element), used by the 16-bit compute mode of the Nystrom block.
-template <int BN_, bool A_KC, bool B_KC, int TERMS = 3, int FBM = 128>
+// F16 (with TERMS = 1, "f1"): the single term is fp16 instead of bf16 - 11 operand mantissa bits, fp16's exponent range: for
+// forward-range operands only (activations and weights of the fp16 compute modes; their gradient products use bf1).
+template <int BN_, bool A_KC, bool B_KC, int TERMS = 3, int FBM = 128, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
+  static_assert(!F16 || TERMS == 1, "the fp16 form is single-term");
   constexpr int FBK = 32, NI = BN_ / 64, MI = FBM / 64;        // MI x NI 32x32 blocks per wave; FBM = 64: the small-problem tile
   constexpr int A_LD = A_KC ? (FBK + 8) : (FBM + 32);          // halves per row of a plane
   constexpr int B_LD = B_KC ? (FBK + 8) : (BN_ + 32);
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       const int idx = tid + 256 * i;
       const int off = A_KC ? ((idx >> 3) * A_LD + 4 * (idx & 7)) : ((idx / MQ) * A_LD + 4 * (idx % MQ));
       uint2v h, m, l;
-      split4_bf3(ra[i], h, m, l);
+      if (F16) h = f16_pack4(ra[i]); else split4_bf3(ra[i], h, m, l);
       *reinterpret_cast<uint2v*>(&As[off]) = h;
       if (TERMS == 3) {
         *reinterpret_cast<uint2v*>(&As[A_PLANE + off]) = m;
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
       constexpr int NQ = BN_ / 4;
       const int off = B_KC ? ((idx >> 3) * B_LD + 4 * (idx & 7)) : ((idx / NQ) * B_LD + 4 * (idx % NQ));
       uint2v h, m, l;
-      split4_bf3(rb[i], h, m, l);
+      if (F16) h = f16_pack4(rb[i]); else split4_bf3(rb[i], h, m, l);
       *reinterpret_cast<uint2v*>(&Bs[off]) = h;
       if (TERMS == 3) {
         *reinterpret_cast<uint2v*>(&Bs[B_PLANE + off]) = m;
@@ -486,7 +500,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
             d = mfma16b(af[mi][1], bf[ni][0], d);
             d = mfma16b(af[mi][0], bf[ni][1], d);
           }
-          d = mfma16b(af[mi][0], bf[ni][0], d);
+          if (F16) d = mfma16h(af[mi][0], bf[ni][0], d);
+          else d = mfma16b(af[mi][0], bf[ni][0], d);
           acc[mi][ni] = d;
         }
     }
@@ -547,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
 static int g_force_generic = 0;   // test hook: route everything through the generic kernel
 static int g_mode = 0;            // 0: automatic, 1: fp32-MFMA tiled kernel only, 2: split-bf16 kernel wherever it applies,
                                   // 3: single-term bf16 kernel wherever it applies (16-bit compute mode: 8-bit operand mantissas)
+                                  // 4: single-term fp16 kernel (11-bit operand mantissas, fp16's range: forward-range operands only)
 extern "C" void smml_gemm_force_generic(int on) { g_force_generic = on; }
 extern "C" void smml_gemm_set_mode(int mode) { g_mode = mode; }
 extern "C" int smml_gemm_get_mode(void) { return g_mode; }
@@ -605,16 +621,18 @@ extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const flo
     // (SMML_GEMM_MODE=1 vs automatic with that wider rule), the step is not faster (17.2 / 17.5 vs 17.6 / 17.5 ms) and
     // the errors against the oracle grow 2x.  So the automatic choice keeps it for large square-ish products only.
     const bool bf3 = (g_mode == 2) || (g_mode == 0 && K >= 2048 && M >= 1024 && N >= 1024);
-    const bool bf1 = (g_mode == 3);
+    const bool bf1 = (g_mode == 3), f1 = (g_mode == 4);
 #define SMML_FAST(BNV, AK, BK2)                                                                   \
   do {                                                                                            \
-    if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2, 1>), grid, dim3(256), 0, st, g);   \
+    if (f1) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2, 1, 128, true>), grid, dim3(256), 0, st, g); \
+    else if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2, 1>), grid, dim3(256), 0, st, g);   \
     else if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_fast_kernel<BNV, AK, BK2>), grid, dim3(256), 0, st, g);     \
   } while (0)
 #define SMML_SMALL(AK, BK2)                                                                          \
   do {                                                                                               \
-    if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 1, 64>), grid, dim3(256), 0, st, g);   \
+    if (f1) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 1, 64, true>), grid, dim3(256), 0, st, g);   \
+    else if (bf1) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 1, 64>), grid, dim3(256), 0, st, g);   \
     else if (bf3) hipLaunchKernelGGL((gemm_bf3_kernel<64, AK, BK2, 3, 64>), grid, dim3(256), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_fast_kernel<64, AK, BK2, 64>), grid, dim3(256), 0, st, g);     \
   } while (0)

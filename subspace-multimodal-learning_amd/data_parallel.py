@@ -14,7 +14,10 @@ Replaces the reference's ``DDP(model, find_unused_parameters=True, broadcast_buf
     raises (call ``reset_unused()`` after changing what the model computes);
   * the 1 / world factor is folded into the reduction (ReduceOp.AVG on RCCL; pre-scaled sum elsewhere): nothing runs
     between the collective's completion and the return of backward() but the wait itself;
-  * ``.module`` exposes the wrapped model as DDP does.
+  * ``.module`` exposes the wrapped model as DDP does; parameters and buffers are broadcast from rank 0 once, at wrap time;
+  * SyncBatchNorm (main.py:118, only with fusion_type 'pofusion') issues its own all-gather / all-reduce inside forward and backward:
+    they interleave with the bucket all-reduces in the order autograd reaches them, which is the same on every rank
+    (tests/test_gpu_data_parallel.py::test_syncbn_pofusion_two_ranks).
 The payload is ~4.65 MB per step for DeformPathomicNet (1.96 MB for one DeformCrossTransMIL), so the collectives are
 latency-bound: the default bucket is 512 KiB - 4 to 9 buckets, enough for the first ones to be on the wire while the
 position-bias backward (the longest kernel of the step) of the other branch still runs."""
@@ -55,8 +58,13 @@ class BagDataParallel(nn.Module):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         if self.world > 1 and broadcast:
+            # rank 0's state at wrap time, parameters AND buffers - as DDP's constructor does whatever `broadcast_buffers` says (that flag,
+            # False at main.py:119, only stops the per-forward re-broadcast).  Buffers matter with fusion_type 'pofusion': main.py:118
+            # converts BilinearFusion's BatchNorm1d to SyncBatchNorm, whose running statistics must start equal on every rank
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
+            for b in module.buffers():
+                dist.broadcast(b.data, src=0, group=process_group)
         self._buckets: List[_Bucket] = []
         self._where = {}
         cur, cur_bytes = [], 0

@@ -164,7 +164,8 @@ class DeformCrossAttention2D(nn.Module):
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
                                 compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
-        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
+        # the output projection follows the core's compute mode (single-term 16-bit operands, fp32 accumulation and storage)
+        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out
 
     def forward(self, x1, x2, return_vgrid=False):
@@ -231,7 +232,7 @@ class DeformCrossAttention1D(nn.Module):
         seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
                                 scale=self.scale, compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
-        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual)
+        out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out
 
     def forward(self, x1, x2, return_vgrid=False):

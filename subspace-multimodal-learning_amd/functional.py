@@ -175,7 +175,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, rows_per_bias, residual, prec=0):
         x = _c(x); weight = _c(weight)
-        ctx.prec = prec
+        ctx.prec = 3 if prec == 4 else prec          # fp16 operands are for forward-range values: the gradient products of mode 4 run in bf16
         K = x.shape[-1]
         M = x.numel() // K
         N = weight.shape[0]
@@ -227,7 +227,8 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, residual=None, prec: int = 0):
     """act(x W^T + bias) (+ residual).  prec: GEMM precision mode of the forward and backward products (0 automatic / exact
-    fp32, 2 three-term split bf16, 3 single-term bf16 operands - the 16-bit compute mode)."""
+    fp32, 2 three-term split bf16, 3 single-term bf16 operands - the 16-bit compute mode, 4 single-term fp16 operands in the forward
+    product and bf16 ones in the two gradient products - the fp16 compute modes)."""
     return _Linear.apply(x, weight, bias, act, rows_per_bias, residual, prec)
 
 
@@ -775,6 +776,12 @@ def bilinear_corners(vs, Hh: int, Ww: int, posdim: int):
 _DTYPE16 = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
 
 
+def prec16(compute_dtype) -> int:
+    """GEMM precision mode (`linear(..., prec=)`) that goes with a 16-bit compute mode: None -> 0 (exact), 'bf16' -> 3, 'fp16' -> 4."""
+    m = _dtype16(compute_dtype)
+    return 0 if m is None else (4 if m[0] == 1 else 3)
+
+
 def _dtype16(compute_dtype):
     """None (the fp32-grade path) or the (C-ABI code, torch dtype) of the 16-bit compute mode."""
     if compute_dtype is None:
@@ -808,7 +815,7 @@ class _DeformAttn(torch.autograd.Function):
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
             # score-shaped tensors are stored per 32-query tile (include/smml.h): [B, H, nst / 32, J, 32] (+ the lane-half axis of the masks)
-            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32 if m16 is None else m16[1])
+            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32 if m16 is None else torch.float16)   # 16-bit mode: fp16 scores in both sub-modes
             masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
         _set_seed_offset(L, seed_offset)
         if m16 is None:

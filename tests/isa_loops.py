@@ -30,7 +30,15 @@ for n, (i0, name) in enumerate(starts):
             if nm:
                 loops.append((len(seq), nm, m.group(1), seq))
     print("\n" + dem[:120])
+    shown = 0
     for n_, nm, lab, seq in sorted(loops):
+        # nested loops contain their inner loops' instructions: list the innermost ones only (loops whose label range holds no other
+        # listed loop), at most four per kernel
+        if any(o[0] < n_ and all(x in seq for x in o[3][:3]) and labels[o[2]] > labels[lab] for o in loops if o[2] != lab):
+            continue
+        shown += 1
+        if shown > 4:
+            break
         c = collections.Counter(x.split()[0] for x in seq)
         valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
         print(f"  loop {lab}: {n_} instrs, mfma {nm}, valu {valu}, salu {sum(v for k, v in c.items() if k.startswith('s_'))}, "

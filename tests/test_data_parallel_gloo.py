@@ -182,3 +182,56 @@ def test_default_buckets_split_the_mil_model():
     assert dp.stats["buckets"] >= 3
     sizes = [b.numel * 4 for b in dp._buckets]
     assert max(sizes) < (1 << 20) + (512 << 10)
+
+
+class _FakeWork:
+    waited = 0
+
+    def wait(self):
+        _FakeWork.waited += 1
+        return True
+
+
+def test_rccl_branch_of_the_reducer_with_a_fake_backend(monkeypatch):
+    """the `nccl` (RCCL) branch of BagDataParallel - ReduceOp.AVG, no pre-scaling - has only ever been skipped on a
+    one-GPU box.  Walked here in ONE process against stand-ins for torch.distributed (world 2, backend 'nccl', all_reduce that records
+    its arguments and averages with a pretend second rank holding 3 x this rank's gradient): the first RCCL run is then not also the
+    first execution of that branch."""
+    calls = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls.append({"op": op, "async": async_op, "numel": t.numel(), "dtype": t.dtype, "pre": t.clone()})
+        if op == dist.ReduceOp.AVG:
+            t.mul_(2.0)                       # (g + 3 g) / 2
+        elif op == dist.ReduceOp.MAX:
+            pass                              # the used / unused bitmask exchange: both ranks agree
+        else:
+            raise AssertionError(f"unexpected reduce op {op} on the RCCL branch")
+        return _FakeWork() if async_op else None
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "broadcast", lambda t, src=0, group=None: None)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    _FakeWork.waited = 0
+    net = _Toy()
+    dp = smml.BagDataParallel(net, bucket_bytes=32)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(11))
+    ref = _Toy()
+    ref(x).pow(2).sum().backward()
+    for step in range(2):
+        calls.clear()
+        net.zero_grad(set_to_none=True)
+        dp(x).pow(2).sum().backward()
+        red = [c for c in calls if c["op"] == dist.ReduceOp.AVG]
+        assert len(red) == dp.stats["buckets"] - (dp.stats["skipped"] if step else 0)
+        assert all(c["async"] and c["dtype"] == torch.float32 for c in red)
+        # AVG carries the 1 / world factor: the payload is the raw gradient, not a pre-scaled one
+        assert torch.allclose(net.a.weight.grad, 2.0 * ref.a.weight.grad, rtol=1e-6)
+        assert torch.allclose(net.b.bias.grad, 2.0 * ref.b.bias.grad, rtol=1e-6)
+        assert net.unused.weight.grad is None
+    assert dp.stats["skipped"] >= 1 and dp.stats["launched_in_backward"] == dp.stats["buckets"] - dp.stats["skipped"]
+    assert _FakeWork.waited >= 2 * (dp.stats["buckets"] - dp.stats["skipped"])
+    raw = [c for c in calls if c["op"] == dist.ReduceOp.AVG and c["numel"] >= net.a.weight.numel()]
+    assert raw, "a bucket holding a.weight was reduced"

@@ -126,3 +126,114 @@ def test_two_ranks_over_rccl(cuda, smml):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run_two_ranks(smml, "nccl")
+
+
+# ------------------------------------------------------------------------------------------------
+# SyncBatchNorm + BagDataParallel (reference: main.py:118-119 converts BN to SyncBN, then wraps) - only reached with
+# fusion_type 'pofusion' (BilinearFusion's two BatchNorm1d, models/fusion.py:44-45)
+# ------------------------------------------------------------------------------------------------
+def _pofusion_net(smml, S, in_dim):
+    from test_oracle_golden import pathomic_args
+    args = pathomic_args(fusion_type="pofusion", skip=1, input_path_dim=in_dim, grid_hw=(S, S), batch_size=2, mmhid=128)
+    net = smml.DeformPathomicNet(args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(smml.synth.fill_params(shapes, 9, "dp:po"))
+    return net
+
+
+def _po_mode(net):
+    """dropout off everywhere, BatchNorm on batch statistics: the only train-mode behaviour whose two-rank result has a single-process twin"""
+    net.eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.train()
+    return net
+
+
+def _po_data(smml, rank, B, S, in_dim):
+    path = smml.synth.bag(B, S * S, in_dim, 80 + rank, "dp:po:bag").cuda()
+    xt = smml.synth.normal((B, 59), 80 + rank, "dp:po:t").cuda()
+    xi = smml.synth.normal((B, 361), 80 + rank, "dp:po:i").cuda()
+    label = torch.tensor([(rank + 2 * i) % 4 for i in range(B)]).cuda()
+    return path, xt, xi, label
+
+
+def _worker_syncbn(rank, world, port, q):
+    import importlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    smml = importlib.import_module("subspace-multimodal-learning_amd")
+    B, S, in_dim = 2, 12, 64
+    net = _pofusion_net(smml, S, in_dim).cuda()
+    if rank == 1:                                  # desynchronise rank 1's BN buffers on purpose: the wrap must bring rank 0's over
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.add_(3.0); m.running_var.mul_(5.0)
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)          # main.py:118
+    n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
+    dp = smml.BagDataParallel(_po_mode(net), bucket_bytes=1 << 18)    # main.py:119
+    path, xt, xi, label = _po_data(smml, rank, B, S, in_dim)
+    for step in range(2):
+        net.zero_grad(set_to_none=True)
+        out = dp(x_path=path, x_omic=None, x_omic_tumor=xt, x_omic_immune=xi)
+        loss = torch.nn.functional.cross_entropy(out[3][2], label)
+        loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters() if p.grad is not None}
+    bufs = {k: b.detach().cpu().numpy() for k, b in net.named_buffers() if "running" in k}
+    q.put((rank, float(loss.item()), grads, bufs, n_sync, dict(dp.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_pofusion_two_ranks(cuda, smml):
+    """fusion_type 'pofusion' -> SyncBatchNorm.convert_sync_batchnorm -> BagDataParallel on two ranks (gloo, both on
+    cuda:0): SyncBN's own collectives inside forward / backward interleave with the bucket all-reduces; buffers are broadcast at wrap
+    time.  Gradients and running statistics equal a single-process BatchNorm1d run over the concatenated batch."""
+    import helpers
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, l, g, bufs, n_sync, st = q.get(timeout=300)
+        res[r] = (l, g, bufs)
+        assert n_sync == 2, "BilinearFusion's two BatchNorm1d must have been converted"
+        assert st["launched_in_backward"] == st["buckets"] - st["skipped"] >= 2, st
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B, S, in_dim = 2, 12, 64
+    net = _po_mode(_pofusion_net(smml, S, in_dim).cuda())
+    data = [_po_data(smml, r, B, S, in_dim) for r in range(world)]
+    path, xt, xi, label = (torch.cat([d[i] for d in data]) for i in range(4))
+    for step in range(2):                          # two steps: the running statistics take two momentum updates on both sides
+        net.zero_grad(set_to_none=True)
+        out = net(x_path=path, x_omic=None, x_omic_tumor=xt, x_omic_immune=xi)
+        ce = [torch.nn.functional.cross_entropy(out[3][2][r * B:(r + 1) * B], label[r * B:(r + 1) * B]) for r in range(world)]
+        (sum(ce) / world).backward()
+    for r in range(world):
+        assert abs(res[r][0] - float(ce[r].item())) <= 1e-4 * abs(res[r][0]), "per-rank loss"
+    ref = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert set(ref) == set(res[0][1]) == set(res[1][1])
+    assert any("fusion.encoder1.1" in k for k in ref), "the SyncBN affine parameters carry gradients"
+    worst = []
+    for k, v in ref.items():
+        g0, g1 = torch.from_numpy(res[0][1][k]), torch.from_numpy(res[1][1][k])
+        assert torch.equal(g0, g1), f"ranks disagree on {k}"
+        if k.endswith("rel_pos_bias.mlp.2.bias"):
+            continue
+        err = float((g0 - v).abs().max() / v.abs().max().clamp_min(1e-30))
+        helpers.record(f"syncbn dp2 d{k}", err, None, 2e-4, "max vs single process")
+        if err > 2e-4:
+            worst.append(f"{k}: {err:.2e}")
+    assert not worst, "two-rank SyncBN gradients differ from the single-process BatchNorm run:\n  " + "\n  ".join(worst)
+    refb = {k: b.detach().cpu() for k, b in net.named_buffers() if "running" in k}
+    for k, v in refb.items():
+        b0, b1 = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
+        assert torch.equal(b0, b1), f"running statistics differ between ranks: {k}"
+        assert torch.allclose(b0, v, rtol=1e-4, atol=1e-6), f"{k}: running statistics differ from the single-process run"

@@ -3,9 +3,10 @@ config 5 fp16): DeformCrossAttention2D / 1D(compute_dtype='bf16' | 'fp16') and t
 
 Tolerance of this mode, stated ONCE here (the way tests/test_gpu_attn16.py states the Nystrom block's): every tensor is compared with
 the fp64 evaluation in the max norm relative to the tensor's own scale -
-    forward values                 bf16 1.5e-2    fp16 2e-3     (8 / 11 operand mantissa bits on q, k, v, P, h1, W2 and the stored scores)
-    gradients                      bf16 3e-2      fp16 1.5e-2   (gradient-range operands - dO, dS, g = h1 . d bias - are bf16 in BOTH modes:
-                                                                 fp32's exponent range without a loss scale; sums of ~1e5..1e8 such terms)
+    forward values                 bf16 1.5e-2    fp16 4e-3     (8 / 11 operand mantissa bits on q, k, v, P, h1, W2; the stored scores are fp16 in both)
+    gradients                      bf16 3e-2      fp16 3e-2     (gradient-range operands - dS, g = h1 . d bias, the dK / dV / dQ products - are bf16 in
+                                                                 BOTH modes: fp32's exponent range without a loss scale; measured worst over the fuzz
+                                                                 cases 2.3e-2 on dW2 / dW3 of the position-bias MLP, <= 1e-2 elsewhere)
 fp32 accumulation everywhere.  The piecewise-linear decisions the kernels took (sampler cells, both ReLU layers of the position-bias MLP)
 are exported and imposed on the oracle exactly as in the fp32-grade tests (tests/helpers.py): layer 1 is the SAME fp32-grade device
 function in both modes (its decisions may differ from fp64 only at rounding level, 2e-6); layer 2 is a single-term 16-bit product here,
@@ -24,8 +25,8 @@ from test_gpu_parity import _core_reference, cpb_probe
 pytestmark = pytest.mark.gpu
 Fh = smml.functional
 
-FWD_TOL = {"bf16": 1.5e-2, "fp16": 2e-3}
-GRAD_TOL = {"bf16": 3e-2, "fp16": 1.5e-2}
+FWD_TOL = {"bf16": 1.5e-2, "fp16": 4e-3}
+GRAD_TOL = {"bf16": 3e-2, "fp16": 3e-2}
 L2_MARGIN = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # layer-2 decisions: |pre-activation| of a flipped unit <= margin x sum |W2| |h1| (+ |b2|)
 
 
@@ -216,3 +217,65 @@ def test_core16_dropout_decisions_ride_in_the_saved_scores(cuda):
         # a wrong keep bit anywhere moves dv by O(P) of single pairs: far above the mode's rounding
         assert_close(f"{mode} dv under dropout", dev["v"].grad, r["v"].grad, GRAD_TOL[mode])
         assert_close(f"{mode} out under dropout", out, o, FWD_TOL[mode] * 2)
+
+
+# Full-model bounds of the mode (BASELINE config 4 as stated: bf16 compute of the deformable path - fused core, its output projection, _fc1 and
+# the fusion layer).  Forward values and the losses: FWD_TOL.  Every parameter gradient: CFG4_GRAD_TOL of its own scale - measured at the
+# full size (1 x 100 x 100, bf16) 7.0e-3 on tumor to_offsets.2.weight, <= 4e-3 on all others; fp16 on the 24 x 24 grid <= 6e-4.
+CFG4_GRAD_TOL = {"bf16": 2e-2, "fp16": 1e-2}
+
+
+@pytest.mark.parametrize("B,S,mode", [(2, 24, "bf16"), (1, 100, "bf16"), (2, 24, "fp16")])
+def test_cfg4_full_fusion_16bit(cuda, B, S, mode):
+    """BASELINE config 4 as it is stated - full two-branch DeformPathomicNet on bags of 10 000 x 512 with the deformable attention computing
+    in bf16 (args.deform_compute_dtype; fp32 master parameters, fp32 inputs / outputs / gradients) + cross-entropy + both BatchLosses + an
+    OrthogonalLoss term: forward and every parameter gradient against the fp64 oracle with the kernels' decisions imposed (one oracle
+    run, on the GPU's fp64 ATen kernels at the full size).  The two-bag case (BatchLosses contribute) runs on a 24 x 24 grid."""
+    from oracle.losses import batch_loss, orthogonal_loss
+    from oracle.mil import deform_pathomic_net
+    from test_oracle_golden import ZERO_GRADS, pathomic_args
+    args = pathomic_args(input_path_dim=512, batch_size=B, deform_compute_dtype=mode)
+    net = smml.DeformPathomicNet(args)
+    params = params_for(net, 17, "cfg4")
+    net.load_state_dict(params)
+    net = net.to(cuda).eval()
+    assert net.pathomic_net_tumor.layer3.attn2d.compute_dtype == mode
+    x_path = synth.bag(B, S * S, 512, 17, "cfg4:bag")
+    x_t = synth.normal((B, 59), 17, "cfg4:tumor"); x_i = synth.normal((B, 361), 17, "cfg4:immune")
+    label = torch.tensor([2, 0])[:B]
+
+    def total(feats, vt, vi, lg, bl, ol):
+        l_t, l_i = bl(lg[3], lg[4]), bl(lg[5], lg[6])
+        return (torch.nn.functional.cross_entropy(lg[2], label.to(lg[2].device)) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
+                + 0.1 * ol(vt, vi, vi, vt).sum()), l_t, l_i
+
+    with decision_tap() as tap:
+        feats, vt, vi, lg, _, _, _ = net(x_path=x_path.to(cuda), x_omic=None, x_omic_tumor=x_t.to(cuda), x_omic_immune=x_i.to(cuda))
+    loss, l_t, l_i = total(feats, vt, vi, lg, smml.BatchLoss(B, 1), smml.OrthogonalLoss())
+    loss.backward()
+    dev = cuda if S >= 100 else "cpu"
+    dt = torch.float64
+    p = {k: (v.clone().to(dev, dt).requires_grad_() if v.dtype.is_floating_point else v.to(dev)) for k, v in params.items()}
+    odeform.DECISIONS = tap.decisions()
+    o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024)
+    assert not odeform.DECISIONS
+    o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
+    o_loss.backward()
+    tag = f"cfg4/{mode} {B}x{S}x{S}"
+    for name, got, ref in (("features", feats, o_feats), ("haz", lg[2], o_lg[2]), ("vgrid_t", lg[4], o_lg[4]), ("vgrid_i", lg[6], o_lg[6]),
+                           ("loss", loss, o_loss)):
+        assert_close(f"{tag} {name}", got, ref, FWD_TOL[mode])
+    if B > 1:
+        assert_close(f"{tag} batchloss_t", l_t, o_lt, FWD_TOL[mode]); assert_close(f"{tag} batchloss_i", l_i, o_li, FWD_TOL[mode])
+    with_grad = {k for k, q in net.named_parameters() if q.grad is not None}
+    assert with_grad == {k for k, v in p.items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
+    bad = []
+    for k, q in net.named_parameters():
+        if q.grad is None or k.endswith(ZERO_GRADS) or k.endswith("cls_token"):
+            continue
+        tol = CFG4_GRAD_TOL[mode]
+        e = rel_err(q.grad, p[k].grad)
+        helpers.record(f"{tag} d{k}", e, None, tol, "max vs fp64")
+        if not e <= tol:
+            bad.append(f"{k}: {e:.2e} > {tol:.1e}")
+    assert not bad, f"{len(bad)} parameter gradients out of tolerance:\n  " + "\n  ".join(bad)
