@@ -198,6 +198,12 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
             "qkav_share_of_flops": qkav / total}
 
 
+def nystrom_legs(pkg, dev):
+    """BASELINE config 2 (8 x 4096 bf16), the N = 10 000 bag in bf16 / fp32, and config 5 (one 50 000-instance fp16 bag)."""
+    return [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
+            nystrom_leg(pkg, dev, 4, 10000, torch.float32), nystrom_leg(pkg, dev, 1, 50000, torch.float16)]
+
+
 def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3):
     """The headline training step (same model, parameters, bags, losses, Adam) with the fused attention core in its 16-bit compute
     mode (csrc/deform_attn16.hip; BASELINE config 4 names bf16): ms per step by wall clock between synchronisations, the two dominant
@@ -404,8 +410,7 @@ def main():
             if world == 1 and not a.no_nystrom:
                 # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
                 # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
-                out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
-                                  nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
+                out["nystrom"] = nystrom_legs(pkg, dev)
             if world == 1 and not a.no_traffic:
                 traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
                                                                 "--no-traffic", "--no-deform16", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
@@ -434,8 +439,7 @@ def main():
                                    "note": f"2496 algorithmic flop per pair (position-bias MLP 2240 + QK^T / PV 256) against the dense 16-bit "
                                            f"MFMA peak; {CPB_FWD_MFMAS} + 24/32 16-bit MFMAs + ~170 vector instructions per (key, 32 queries)"}
         if world == 1 and not a.no_nystrom and "nystrom" not in out:
-            out["nystrom"] = [nystrom_leg(pkg, dev, 8, 4096, torch.bfloat16), nystrom_leg(pkg, dev, 4, 10000, torch.bfloat16),
-                              nystrom_leg(pkg, dev, 4, 10000, torch.float32)]
+            out["nystrom"] = nystrom_legs(pkg, dev)
         if world > 1:
             out["data_parallel"] = dp_info               # what the collective backend saw + per-rank overlap counters: a SCALE run checks itself
         if world == 1 and not a.no_cpu_baseline:

@@ -315,6 +315,10 @@ int smml_attn16_fwd_f32(const float* q, const float* k, const float* v, float* o
  * kernel with all keys resident in LDS wherever its 256-query workgroups fill the chip, 2 = wherever Lk <= 256.  The two-pass kernel
  * halves the vector instructions per MFMA but the launch is HBM-bound with fp32 storage (csrc/attn16.hip). */
 void smml_attn16_set_fewkeys(int mode);
+/* queries-long bf16-storage forward (smml_attn16_fwd_b16, long_side 1): 0 = one 32-query block per wave, 1 (default) = two blocks per wave
+ * (the K / V fragments of a tile feed two accumulator sets: half the LDS fragment reads, barriers and K / V staging per MFMA) wherever the
+ * 256-query workgroups still cover the chip twice over, 2 = always (test / measurement switch). */
+void smml_attn16_set_query_blocks(int mode);
 /* bf16-STORAGE forms of the two attention-shaped products (bf16 compute mode with bf16 bags): the LONG side (long_side 0: keys / values -
  * softmax(ql k^T) v; 1: queries - softmax(q kl^T) w) is bf16 in memory at element strides (s_bs, s_hs, s_rs) per (bag, head, row) - q / k / v
  * are read in the token-major [b, n', 3, h, 64] buffer the projection wrote - the short (landmark) side is fp32 [B H, L, 64].

@@ -35,6 +35,7 @@ SIGNATURES = {
     "smml_attn16_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "smml_attn16_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _i, _i, _f]),
     "smml_attn16_set_fewkeys": (None, [_i]),
+    "smml_attn16_set_query_blocks": (None, [_i]),
     "smml_attn16_fwd_b16": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _fl, _i, _ll, _ll, _ll, _ll, _ll, _ll, _f]),
     "smml_attn16_bwd_b16": (_i, [_f] * 11 + [_sz, _i, _i, _i, _i, _fl, _i] + [_ll] * 9 + [_i, _f]),
     "smml_attn16_bwd_workspace_bytes": (_sz, [_i, _i, _i]),

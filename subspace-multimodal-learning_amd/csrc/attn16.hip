@@ -226,6 +226,141 @@ template <typename T> struct TileRegs<T, T> {
 };
 
 // ------------------------------------------------------------------------------------------------
+// forward, queries-long form with 16-bit query-side storage, TWO 32-query blocks per wave: the [n', m] side of the
+// Nystrom block has only m / 32 = 8 key tiles per wave, so what a wave pays once - its q / residual / output rows, the launch ramp - and what it
+// pays per tile and wave - the K / V fragment reads from LDS, the barrier - weighs as much as the MFMAs.  With two query blocks a wave issues
+// the same K and V fragments into two independent accumulator sets: LDS fragment reads, barriers and the staging of K / V per MFMA halve.
+//   Q, O, RES: T at layouts ql / ol;  K, V: fp32 head-major [BH, Lk, 64] (the landmark side);  grid (ceil(Lq / 256), BH)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn16_fwd_q2_kernel(const T* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                               T* O, const T* RES, float* __restrict__ LSE2, int Lq, int Lk, float qscale,
+                                                               OLayout ql, OLayout kl, OLayout ol) {
+  typedef typename Pipe<T>::x8 x8;
+  constexpr int NB = 2;                                  // query blocks per wave
+  __shared__ __attribute__((aligned(16))) T Kr[2][AK * RLD];
+  __shared__ __attribute__((aligned(16))) T Vt[2][AK * TLD];
+  __shared__ __attribute__((aligned(16))) T Wr[AW * NB * AQ * RLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.y;
+  const int q0 = blockIdx.x * (AQ * AW * NB) + wave * (AQ * NB);
+  T* wr = Wr + wave * (NB * AQ * RLD);
+  const float* Kb = K + obase(kl, bh);
+  const float* Vb = V + obase(kl, bh);
+  x8 qf[NB][4];
+  {
+    uint4v qraw[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rows_load(Q + obase(ql, bh), ql.rs, q0 + AQ * nb, Lq, qraw[nb], lane);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rows_to_lds(wr + nb * AQ * RLD, qraw[nb], lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[nb][s] = *reinterpret_cast<const x8*>(&wr[(nb * AQ + c) * RLD + 16 * s + 8 * hf]);
+    wave_lds_fence();
+  }
+  const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  TileRegs<T, float> kreg, vreg;
+  kreg.load(Kb, kl.rs, 0, Lk, tid); vreg.load(Vb, kl.rs, 0, Lk, tid);
+  floatx16 o0[NB], o1[NB];
+  float m_run[NB], l_run[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { o0[nb] = floatx16{0}; o1[nb] = floatx16{0}; m_run[nb] = -INFINITY; l_run[nb] = 0.f; }
+  const int ntiles = (Lk + AK - 1) / AK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * AK, buf = kt & 1;
+    const int nk = min(AK, Lk - j0);
+    kreg.store(Kr[buf], RLD, tid); vreg.store(Vt[buf], TLD, tid);
+    __syncthreads();        // buffer (kt & 1) was last read in iteration kt - 2: one barrier per tile is enough
+    if (kt + 1 < ntiles) { kreg.load(Kb, kl.rs, j0 + AK, Lk, tid); vreg.load(Vb, kl.rs, j0 + AK, Lk, tid); }
+    floatx16 s[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) s[nb] = floatx16{0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const x8 kf = *reinterpret_cast<const x8*>(&Kr[buf][c * RLD + 16 * st + 8 * hf]);          // one fragment read, two products
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) s[nb] = Pipe<T>::mfma(kf, qf[nb][st], s[nb]);
+    }
+    constexpr float LAZY = 8.f;                          // lazy reference point (attn16_fwd_kernel)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (nk < AK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (acc_row(r, hf) >= nk) s[nb][r] = -INFINITY;
+      }
+      float tmax = s[nb][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[nb][r]);
+      tmax = xhalf_max(tmax) * qscale;
+      if (__builtin_amdgcn_ballot_w64(tmax > m_run[nb] + LAZY)) {      // wave-uniform
+        const float m_new = fmaxf(m_run[nb], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
+        l_run[nb] *= alpha;
+        m_run[nb] = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[nb][r] *= alpha; o1[nb][r] *= alpha; }
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[nb][r] = __builtin_amdgcn_exp2f(fmaf(s[nb][r], qscale, -m_run[nb])); psum += s[nb][r]; }
+      l_run[nb] += psum;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      x8 pb[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float p8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p8[j] = s[nb][8 * kb + j];
+        pb[nb] = pack8<T>(p8);
+      }
+      const int ro = (16 * kb + 4 * hf + trq) * TLD + trc;
+      const x8 v0 = frag_tr<T>(&Vt[buf][ro], &Vt[buf][ro + 8 * TLD]);
+      const x8 v1 = frag_tr<T>(&Vt[buf][ro + 32], &Vt[buf][ro + 32 + 8 * TLD]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { o0[nb] = Pipe<T>::mfma(v0, pb[nb], o0[nb]); o1[nb] = Pipe<T>::mfma(v1, pb[nb], o1[nb]); }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int qb = q0 + AQ * nb;
+    if (qb >= Lq) continue;                              // wave-uniform: nothing of this block is inside the bag
+    T* wq = wr + nb * AQ * RLD;
+    const float l = xhalf_sum(l_run[nb]);
+    const float inv = 1.f / l;
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { ra[rg] = make_float4(0.f, 0.f, 0.f, 0.f); rb[rg] = ra[rg]; }
+    if (RES) {                                          // the residual rows: full lines -> this lane's pieces of its own row
+      uint4v rraw[4];
+      rows_load(RES + obase(ol, bh), ol.rs, qb, Lq, rraw, lane);
+      rows_to_lds(wq, rraw, lane);
+      wave_lds_fence();
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { ra[rg] = load4f(&wq[c * RLD + 8 * rg + 4 * hf]); rb[rg] = load4f(&wq[c * RLD + 32 + 8 * rg + 4 * hf]); }
+      wave_lds_fence();
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      store4f(&wq[c * RLD + 8 * rg + 4 * hf], make_float4(fmaf(o0[nb][4 * rg], inv, ra[rg].x), fmaf(o0[nb][4 * rg + 1], inv, ra[rg].y),
+                                                          fmaf(o0[nb][4 * rg + 2], inv, ra[rg].z), fmaf(o0[nb][4 * rg + 3], inv, ra[rg].w)));
+      store4f(&wq[c * RLD + 32 + 8 * rg + 4 * hf], make_float4(fmaf(o1[nb][4 * rg], inv, rb[rg].x), fmaf(o1[nb][4 * rg + 1], inv, rb[rg].y),
+                                                               fmaf(o1[nb][4 * rg + 2], inv, rb[rg].z), fmaf(o1[nb][4 * rg + 3], inv, rb[rg].w)));
+    }
+    wave_lds_fence();
+    uint4v oraw[4];
+    rows_from_lds(wq, oraw, lane);
+    rows_store(O + obase(ol, bh), ol.rs, qb, Lq, oraw, lane);
+    if (qb + c < Lq && hf == 0) LSE2[(size_t)bh * Lq + qb + c] = m_run[nb] + __builtin_amdgcn_logf(l);     // v_log_f32 is log2
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward: O = softmax(scale Q K^T) V (+ RES), LSE2 = log2-sum-exp2 of the scaled scores per query (base 2: what the backward needs)
 //   Q, O, RES: storage TQ at layouts ql / ol;  K, V: storage TK at layout kl;  LSE2 [BH, Lq]     grid (ceil(Lq / 128), BH, key chunks)
 //   RES may be O itself (the fp32 path accumulates into an output that already holds the residual)
@@ -926,10 +1061,13 @@ static int attn16_parts(int BH, int Lq, int Lk) {
 // us): with fp32 storage this launch moves 252 MB (q in, residual in, out out) - 4.7 TB/s at 54 us - i.e. the [n', m] side of the Nystrom
 // block is HBM-bound, not issue-bound, and one 8-wave workgroup per CU (86 KB of LDS) keeps fewer bytes in flight than two 4-wave ones.
 static int g_fewkeys = -1;
+static int g_q2 = 1;              // queries-long bf16-storage forward: 0 one query block per wave, 1 (default) two blocks per wave where the
+                                  // 256-query workgroups still cover the chip twice over, 2 always (smml_attn16_set_query_blocks)
 
 extern "C" {
 
 void smml_attn16_set_fewkeys(int mode) { g_fewkeys = mode; }
+void smml_attn16_set_query_blocks(int mode) { g_q2 = mode; }
 
 // scratch of smml_attn16_fwd_f32: the partial outputs + log-sum-exps of a key-split launch (0 when the launch is not split)
 size_t smml_attn16_fwd_workspace_bytes(int BH, int Lq, int Lk) {
@@ -1116,6 +1254,16 @@ int smml_attn16_fwd_b16(const void* q, const void* k, const void* v, void* out, 
   SMML_REQUIRE((o_bs % 8) == 0 && (o_hs % 8) == 0 && (o_rs % 8) == 0 && al16p(q) && al16p(out) && al16p(residual),
                "smml_attn16_fwd_b16: bf16 operands must be 16-byte aligned with strides that are multiples of 8");
   const OLayout ol{o_bs, o_hs, o_rs, H}, kl = head_major(Lk);
+  // two query blocks per wave (attn16_fwd_q2_kernel) wherever its 256-query workgroups still cover the chip twice over; g_q2 = 0 / 2: never / always
+  const long long wg2 = (long long)((Lq + 2 * AQ * AW - 1) / (2 * AQ * AW)) * BH;
+  if (g_q2 == 2 || (g_q2 == 1 && wg2 >= 1024)) {
+    dim3 grid2((Lq + 2 * AQ * AW - 1) / (2 * AQ * AW), BH, 1);
+    hipLaunchKernelGGL(attn16_fwd_q2_kernel<__bf16>, grid2, block, 0, st, reinterpret_cast<const __bf16*>(q), reinterpret_cast<const float*>(k),
+                       reinterpret_cast<const float*>(v), reinterpret_cast<__bf16*>(out), reinterpret_cast<const __bf16*>(residual), lse2, Lq, Lk,
+                       qscale, sl, kl, ol);
+    SMML_LAUNCH_CHECK("smml_attn16_fwd_b16/queries2");
+    return SMML_OK;
+  }
   dim3 grid((Lq + AQ * AW - 1) / (AQ * AW), BH, 1);
   hipLaunchKernelGGL((attn16_fwd_kernel<__bf16, __bf16, float>), grid, block, 0, st, reinterpret_cast<const __bf16*>(q),
                      reinterpret_cast<const float*>(k), reinterpret_cast<const float*>(v), reinterpret_cast<__bf16*>(out),

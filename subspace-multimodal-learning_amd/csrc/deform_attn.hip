@@ -244,10 +244,10 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     }
     unsigned keepbits = 0xFFFFu;              // dropout decisions of this lane's 16 keys (bit r)
     if (dc.thresh) {
-      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
+      const unsigned long long base2 = ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1) + (j0 >> 1);
       keepbits = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) keepbits |= (drop_hash(dc.seed, base + acc_row(r, hf)) >= dc.thresh) ? (1u << r) : 0u;
+      for (int r = 0; r < 16; r += 2) keepbits |= drop_keep2(dc, base2 + (acc_row(r, hf) >> 1)) << r;     // registers r, r + 1: keys 2 jp, 2 jp + 1
     }
     if (SAVE) {                               // rows are padded to whole workgroup tiles: lanes past N write padding
       if (dc.thresh) {
@@ -1097,10 +1097,13 @@ __global__ __launch_bounds__(256) void relu1_masks_kernel(const float* __restric
 
 
 // keep-mask a launch with (dropout_p, dropout_seed) uses, as 0 / 1 floats [B, H, N, J] (tests only)
-__global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long total, DropCfg dc_in) {
+__global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long total, int J, DropCfg dc_in) {
   const DropCfg dc = drop_resolve(dc_in);
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) mask[i] = (dc.thresh == 0 || drop_hash(dc.seed, i) >= dc.thresh) ? 1.f : 0.f;
+  if (i >= total) return;
+  const unsigned long long row = i / (unsigned long long)J;
+  const int j = (int)(i - row * (unsigned long long)J);
+  mask[i] = (dc.thresh == 0 || ((drop_keep2(dc, row * (unsigned long long)((J + 1) >> 1) + (j >> 1)) >> (j & 1)) & 1u)) ? 1.f : 0.f;
 }
 
 }  // namespace
@@ -1125,7 +1128,7 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
   SMML_REQUIRE(mask && B > 0 && N > 0 && J > 0 && H > 0 && dropout_p >= 0.f && dropout_p < 1.f,
                "smml_deform_attn_dropout_mask_f32: bad argument");
   const unsigned long long total = (unsigned long long)B * H * N * J;
-  hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total,
+  hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total, J,
                      make_drop(dropout_p, dropout_seed));
   SMML_LAUNCH_CHECK("smml_deform_attn_dropout_mask_f32");
   return SMML_OK;

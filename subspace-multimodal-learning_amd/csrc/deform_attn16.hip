@@ -19,6 +19,26 @@
 // Per (key, 32 queries) that is 3 + 8/32 MFMAs forward (7 + 24/32 in the fp32-grade path) and 8 backward (12).
 #include "deform_common.h"
 
+// measurement knobs of this file (tests/build_variants.py)
+#ifndef SMML16_FWD_WPS
+#define SMML16_FWD_WPS 2      // waves per SIMD the forward is register-budgeted for
+#endif
+#ifndef SMML16_CPB_WPS
+#define SMML16_CPB_WPS 2      // same, position-bias backward
+#endif
+#ifndef SMML16_FWD_PAIR
+#define SMML16_FWD_PAIR 0     // 1: two keys per trip of the forward's position-bias loop (software pipelining left to the scheduler)
+#endif
+#ifndef SMML16_DP_MFMA
+#define SMML16_DP_MFMA 1      // 1 (default; 0 = the fp32 path's vector form: measurement switch): d p = W1^T (m1 . d h1) of the position-bias backward (the d vs path) as one bf16 product on the matrix pipe (2 MFMAs
+                              // + 8 conversions) instead of 16 packed FMAs + 8 LDS table reads: the kernel is vector-ISSUE bound (PMC: VALU issue
+                              // cycles = kernel time, the matrix pipe 23 % busy), so an MFMA costs one issue slot.  A/B on one box, twice:
+                              // 5.83 -> 5.50 and 5.91 -> 5.59 ms per launch (8 bags of 10 000 x 625 x 8 heads)
+#endif
+#ifndef SMML16_GATE_MUL
+#define SMML16_GATE_MUL 0     // 1: the layer-1 ReLU gate of the backward as an exact 0 / 1 multiplier (clamped multiply) instead of compare + select
+#endif
+
 namespace {
 
 typedef unsigned short u16;
@@ -68,12 +88,11 @@ __device__ __forceinline__ unsigned pack_score(float a, float b) {
   return pack2<_Float16>(fminf(fmaxf(a, -60000.f), 60000.f), fminf(fmaxf(b, -60000.f), 60000.f));
 }
 __device__ __forceinline__ float score_of(unsigned u) { return tof<_Float16>(u); }
-// the dropout keep decision in the lowest mantissa bit of a stored 16-bit score (deform_common.h stash_keep, on 16-bit patterns:
-// at most one ulp, direction from the second-lowest bit, never across +-0)
-__device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) {
-  const unsigned flip = (u ^ (keep ? 1u : 0u)) & 1u;
-  const int dir = (u & 0x7FFEu) ? (int)(u & 2u) - 1 : 1;
-  return (u + (unsigned)(flip ? dir : 0)) & 0xFFFFu;
+// The dropout keep decision REPLACES the lowest mantissa bit of a stored fp16 score (one v_and_or per pair; the fp32 path nudges the
+// value by a zero-mean ulp instead - at fp16's 2^-11 the half-ulp this costs is below the rounding the score already carries)
+__device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) { return (u & 0xFFFEu) | (keep ? 1u : 0u); }
+__device__ __forceinline__ unsigned stash_keep16x2(unsigned w, unsigned two_bits) {      // bit 0 -> low half, bit 1 -> high half
+  return (w & 0xFFFEFFFEu) | (two_bits & 1u) | ((two_bits & 2u) << 15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,7 +101,7 @@ __device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) {
 // registers as four B fragments.
 // ------------------------------------------------------------------------------------------------
 template <int PD, bool SAVE, typename T>
-__global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
+__global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O, float* __restrict__ LSE, u16* __restrict__ LT,
     u16* __restrict__ MK, int N, int J, int H, int G, int NST, float scale, DropCfg dc_in) {
@@ -191,7 +210,10 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
 
     // continuous position bias: layer 1 (fp32-grade, deform_common.h) + one T-term layer 2 per key
     const int nk = min(KT, J - j0);
-    for (int jj = 0; jj < nk; ++jj) {
+    // one key's chain: layer 1 (MFMA) -> ReLU, T -> layer 2 (two dependent MFMAs) -> ReLU, layer 3, mask bits.  SMML16_FWD_PAIR runs two
+    // keys per trip so that the scheduler can fill one chain's MFMA latencies with the other's vector work (padded keys of a ragged tile
+    // compute on zero positions; only their mask store is guarded)
+    auto bias_chain = [&](int jj, bool store_mask) {
       const float p0 = slog1p(gq0 - vsl[buf][jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[buf][jj][1]) : 0.f;
       floatx16 d = b2acc;
@@ -218,10 +240,18 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
           mb3 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb3);
         }
       }
-      if (SAVE) MKb[(size_t)(j0 + jj) * 64 + c] = (u16)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded tiles: no bounds check
+      if (SAVE && store_mask) MKb[(size_t)(j0 + jj) * 64 + c] = (u16)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // rows of padded query lanes exist
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);
+    };
+#if SMML16_FWD_PAIR
+    for (int jj = 0; jj < nk; jj += 2) {
+      bias_chain(jj, true);
+      bias_chain(jj + 1, jj + 1 < nk);          // jj + 1 <= 31: inside the staged tile
     }
+#else
+    for (int jj = 0; jj < nk; ++jj) bias_chain(jj, true);
+#endif
     wave_lds_fence();
 
     // bias add, key mask
@@ -232,10 +262,10 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
     }
     unsigned keepbits = 0xFFFFu;
     if (dc.thresh) {
-      const unsigned long long base = ((unsigned long long)(b * H + h) * N + qi) * J + j0;
+      const unsigned long long base2 = ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1) + (j0 >> 1);
       keepbits = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) keepbits |= (drop_hash(dc.seed, base + acc_row(r, hf)) >= dc.thresh) ? (1u << r) : 0u;
+      for (int r = 0; r < 16; r += 2) keepbits |= drop_keep2(dc, base2 + (acc_row(r, hf) >> 1)) << r;     // registers r, r + 1: keys 2 jp, 2 jp + 1
     }
     if (SAVE) {
       // the scores are rounded to T for storage and the forward's own softmax continues on the rounded (and, with dropout, stashed)
@@ -243,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void deform16_fwd_kernel(
       if (nk == KT) {                            // full tile (uniform): no per-key bounds
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const unsigned w = pack_score(s[r], s[r + 1]);
-          unsigned lo = w & 0xFFFFu, hi = w >> 16;
-          if (dc.thresh) { lo = stash_keep16(lo, (keepbits >> r) & 1u); hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u); }
+          unsigned w = pack_score(s[r], s[r + 1]);
+          if (dc.thresh) w = stash_keep16x2(w, keepbits >> r);
+          const unsigned lo = w & 0xFFFFu, hi = w >> 16;
           LTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = (u16)lo;
           LTb[(size_t)(j0 + acc_row(r + 1, hf)) * 32 + c] = (u16)hi;
           s[r] = score_of(lo); s[r + 1] = score_of(hi);
@@ -604,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
 // (1 + 1 layer 1, 2 mask transposition, 2 chain 2, 2 dW2) instead of 12, and none of the residual arithmetic of the splits.
 // ------------------------------------------------------------------------------------------------
 template <int PD>
-__global__ __launch_bounds__(256, 2) void cpb16_bwd_kernel(
+__global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     const u16* __restrict__ dLT, const u16* __restrict__ MK, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -672,6 +702,17 @@ __global__ __launch_bounds__(256, 2) void cpb16_bwd_kernel(
     }
   }
 
+#if SMML16_DP_MFMA
+  bf16x8 a1d[2];                       // W1^T as an A operand: row 0 = w1x, row 1 = w1y over k = hidden channel acc_row(8 kb + j, hf); other rows zero
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = acc_row(8 * kb + j, hf);
+      const float wv = (c == 0) ? cp.w1[ch * PD] : ((c == 1 && PD == 2) ? cp.w1[ch * PD + 1] : 0.f);
+      a1d[kb][j] = (__bf16)wv;
+    }
+#endif
   float big;
   asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
   floatx16 e = {0};                    // sum_q mask[out, q] g[in, q]: rows = out, lane = in (times w3[out] at the end)
@@ -713,9 +754,15 @@ __global__ __launch_bounds__(256, 2) void cpb16_bwd_kernel(
       const uint4v tw = {pt.hw, pt.mw, hf ? pt.hw : pt.lw, hf ? 0x00003F80u : 0x3F803F80u};
       ht = mfma16b(__builtin_bit_cast(bf16x8, tw), a1t, (floatx16){0});
     }
+#if SMML16_GATE_MUL
+    float on1[16];                      // exact 0.0 / 1.0: clamp(x 2^100)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) on1[r] = fminf(fmaxf(xacc[r] * big, 0.f), 1.f);
+#else
     bool on1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) on1[r] = xacc[r] > 0.f;
+#endif
 
     half8 mk[2];
     {
@@ -769,26 +816,44 @@ __global__ __launch_bounds__(256, 2) void cpb16_bwd_kernel(
       e = mfma16b(am[t], cvt8<__bf16>(g8), e);
     }
 
-    // layer-1 backward, d vs (fp32 on the vector unit, as in the fp32 path)
+    // layer-1 backward, d vs
     {
       float2v dp0v = {0.f, 0.f}, dp1v = {0.f, 0.f};
       const float dbl = dbias * unlift2;
       const float p0i = p0 * dbl, p1i = p1 * dbl;
+#if SMML16_DP_MFMA
+      uint4v xw0, xw1;
+#endif
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         float2v g1;
+#if SMML16_GATE_MUL
+        g1 = (float2v){dh[2 * p], dh[2 * p + 1]} * (float2v){on1[2 * p], on1[2 * p + 1]};
+#else
         g1[0] = on1[2 * p] ? dh[2 * p] : 0.f;
         g1[1] = on1[2 * p + 1] ? dh[2 * p + 1] : 0.f;
-        const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);
+#endif
         ab1[p] = g1 * (float2v){dbl, dbl} + ab1[p];
         aw1x[p] = g1 * (float2v){p0i, p0i} + aw1x[p];
+        if (PD == 2) aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
+#if SMML16_DP_MFMA
+        if (p < 4) xw0[p] = pack2<__bf16>(g1[0], g1[1]); else xw1[p - 4] = pack2<__bf16>(g1[0], g1[1]);
+#else
+        const float2 wx = *reinterpret_cast<const float2*>(tabh + 2 * p);
         dp0v = g1 * (float2v){wx.x, wx.y} + dp0v;
         if (PD == 2) {
           const float2 wy = *reinterpret_cast<const float2*>(tabh + 16 + 2 * p);
-          aw1y[p] = g1 * (float2v){p1i, p1i} + aw1y[p];
           dp1v = g1 * (float2v){wy.x, wy.y} + dp1v;
         }
+#endif
       }
+#if SMML16_DP_MFMA
+      // d p[c][query] = sum_ch W1[ch][c] (m1 . d h1)[ch][query]: rows 0 / 1 of the product = registers 0 / 1 of the lanes of half 0 (complete sums:
+      // the K dimension covers all 32 channels); half 1 holds rows 4 / 5 = 0
+      floatx16 dpa = mfma16b(a1d[0], __builtin_bit_cast(bf16x8, xw0), (floatx16){0});
+      dpa = mfma16b(a1d[1], __builtin_bit_cast(bf16x8, xw1), dpa);
+      dp0v[0] = dpa[0]; dp1v[0] = dpa[1];
+#endif
       float2 v;
       v.x = -(dp0v[0] + dp0v[1]) * dbl * (srcp(fabsf(d0) + 1.f) * fminf(fmaxf(fabsf(d0) * big, 0.f), 1.f));
       v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbl * (srcp(fabsf(d1) + 1.f) * fminf(fmaxf(fabsf(d1) * big, 0.f), 1.f)) : 0.f;

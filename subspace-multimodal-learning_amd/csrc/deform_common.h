@@ -184,7 +184,7 @@ __device__ __forceinline__ floatx16 mfma16_split(half8 wh, half8 wm, half8 wl, h
 // forward and in both backward passes, no mask is stored.  keep_scale = 1 / (1 - p); thresh = p * 2^32.
 struct DropCfg {
   unsigned long long seed;
-  unsigned thresh;      // keep iff hash >= thresh; 0 disables dropout
+  unsigned thresh;      // 16-bit threshold p * 2^16: keep iff the element's 16-bit half of its pair's hash >= thresh; 0 disables dropout
   float keep_scale;
   const unsigned long long* seed_dev;   // optional device-resident offset added to `seed` when the kernel runs (a launch captured in
                                         // a hipGraph bakes `seed` in; the offset lets every replay draw a new mask), or nullptr
@@ -217,8 +217,12 @@ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned 
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float drop_factor(const DropCfg& dc, unsigned long long idx) {
-  return (drop_hash(dc.seed, idx) >= dc.thresh) ? dc.keep_scale : 0.f;
+// One hash serves the TWO keys 2 jp, 2 jp + 1 of a (bag, head, query) row: its low / high 16 bits are compared with the 16-bit threshold
+// p 2^16 (the drop rate is p to 2^-16; keep_scale uses the rate actually applied).  Pair index = row * ceil(J / 2) + jp.  Halves the
+// mixer work of the forward (the backward passes read the decision from the saved score); -> bit 0: key 2 jp, bit 1: key 2 jp + 1
+__device__ __forceinline__ unsigned drop_keep2(const DropCfg& dc, unsigned long long pair_idx) {
+  const unsigned h = drop_hash(dc.seed, pair_idx);
+  return ((h & 0xFFFFu) >= dc.thresh ? 1u : 0u) | ((h >> 16) >= dc.thresh ? 2u : 0u);
 }
 // In training with dropout the forward stashes each element's keep decision in the LOWEST MANTISSA BIT of the score it saves for the
 // backward (logits_t): both backward passes read those scores anyway and get the decision for free - the hash (two 32-bit multiplies
@@ -469,8 +473,8 @@ DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg dc;
   dc.seed = seed;
   dc.seed_dev = smml_internal_seed_offset();
-  dc.thresh = (p > 0.f) ? (unsigned)((double)p * 4294967296.0) : 0u;
-  dc.keep_scale = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  dc.thresh = (p > 0.f) ? (unsigned)fmax(1.0, (double)p * 65536.0) : 0u;
+  dc.keep_scale = (p > 0.f) ? (float)(65536.0 / (65536.0 - (double)dc.thresh)) : 1.0f;
   return dc;
 }
 

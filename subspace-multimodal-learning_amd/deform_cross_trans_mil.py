@@ -24,10 +24,9 @@ from .deform_attention import DeformCrossAttention1D, DeformCrossAttention2D
 
 
 class FusionNet(nn.Module):
-    def __init__(self, feature_dim=128, compute_dtype=None):
+    def __init__(self, feature_dim=128):
         super().__init__()
         self.fusion_layer = nn.Linear(feature_dim * 2, feature_dim)
-        self.prec = Fh.prec16(compute_dtype)           # args.deform_compute_dtype: the N-row product follows the branch's compute mode
 
     def forward(self, gene_features, image_features):
         """cat((gene_features, image_features), -1) -> Linear.  `image_features` may be the tiled [B, N, C]
@@ -37,7 +36,7 @@ class FusionNet(nn.Module):
         if image_features.dim() == 3:
             image_features = image_features[:, 0]          # every row of the tile is the same vector
         row_bias = Fh.linear(image_features, w[:, C:], self.fusion_layer.bias)          # [B, C]
-        return Fh.linear(gene_features, w[:, :C], row_bias, rows_per_bias=gene_features.shape[1], prec=self.prec)
+        return Fh.linear(gene_features, w[:, :C], row_bias, rows_per_bias=gene_features.shape[1])
 
 
 class DeformCrossTransLayer(nn.Module):
@@ -75,15 +74,17 @@ class Pooler(nn.Module):
 class DeformCrossTransMIL(nn.Module):
     def __init__(self, args, n_classes=4):
         super().__init__()
-        cd = getattr(args, "deform_compute_dtype", None)          # extension key (absent = None = fp32-grade everywhere)
-        self.fusion_layer = FusionNet(feature_dim=128, compute_dtype=cd)
-        self.prec = Fh.prec16(cd)                                 # the two N-row products outside the attention (_fc1, fusion) follow the mode
+        # extension key (absent = None = fp32-grade everywhere).  Only the fused attention core and its output projection change arithmetic:
+        # everything UPSTREAM of the sample positions (_fc1, fusion, LayerNorm, to_q, the offsets network) stays fp32-grade, so vgrid and the
+        # sampler's integer corner / mask path are bit-identical to the fp32-grade path (north_star: integer paths bit-exact)
+        cd = getattr(args, "deform_compute_dtype", None)
+        self.fusion_layer = FusionNet(feature_dim=128)
         in_dim = int(getattr(args, "input_path_dim", 1024) or 1024)
         self._fc1 = nn.Sequential(nn.Linear(in_dim, args.path_dim), nn.ReLU())
         self.cls_token = nn.Parameter(torch.randn(1, 1, args.path_dim))
         self.args = args
         self.n_classes = n_classes
-        # 'bf16' | 'fp16' runs the fused attention core, its output projection, _fc1 and the fusion layer in the 16-bit compute mode
+        # 'bf16' | 'fp16' runs the fused attention core and its output projection in the 16-bit compute mode
         self.layer3 = DeformCrossTransLayer(dim=args.path_dim, grid_hw=getattr(args, "grid_hw", None), compute_dtype=cd)
         self.norm = nn.LayerNorm(args.path_dim)
         self._fc2 = nn.Linear(args.path_dim, self.n_classes)
@@ -91,7 +92,11 @@ class DeformCrossTransMIL(nn.Module):
         self.multimodal_projection = nn.Linear(args.path_dim, self.args.path_dim)
 
     def forward(self, path, omic):
-        path = Fh.linear(path.float(), self._fc1[0].weight, self._fc1[0].bias, act=Fh.ACT_RELU, prec=self.prec)   # [B, N, C]
+        return self.forward_features(Fh.linear(path.float(), self._fc1[0].weight, self._fc1[0].bias, act=Fh.ACT_RELU), omic)   # [B, N, C]
+
+    def forward_features(self, path, omic):
+        """Everything after relu(_fc1(bag)): DeformPathomicNet evaluates the _fc1 of both branches in one launch over the shared bag
+        (functional.dual_linear_relu) and enters here."""
         omic = omic.float()
         N = path.shape[1]
         h = self.fusion_layer(path, omic)

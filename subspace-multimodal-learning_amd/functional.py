@@ -233,6 +233,50 @@ def linear(x, weight, bias=None, act: int = ACT_NONE, rows_per_bias: int = 1, re
 
 
 # ------------------------------------------------------------------------------------------------
+# two ReLU(Linear) heads over ONE input: the two branches of DeformPathomicNet read the same bag (models/model.py:488-497,
+# SURVEY.md K1) - one batched launch per direction, the bag's rows are addressed once per launch instead of once per branch
+# ------------------------------------------------------------------------------------------------
+class _DualLinearRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        x = _c(x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w0.shape[0]
+        w = torch.stack((_c(w0), _c(w1)))                       # [2, N, K]
+        b = torch.stack((_c(b0), _c(b1)))                       # [2, N]
+        y = torch.empty(2, *x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        _gemm(x, w, y, M=M, N=N, K=K, sam=K, sak=1, sbk=1, sbn=K, ldc=N, bias=b, bias_mode=1, act=ACT_RELU, nb1=2, sa1=0,
+              sb1=N * K, sc1=M * N, sbias1=N)
+        ctx.save_for_backward(x, y)
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x, y = ctx.saved_tensors
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = y.shape[-1]
+        L = capi.lib()
+        dpre = torch.empty_like(y)
+        for i, dy in enumerate((dy0, dy1)):
+            capi.check(L.smml_relu_bwd_f32(capi.fptr(_c(dy)), capi.fptr(y[i]), capi.fptr(dpre[i]), dy.numel(), capi.stream()), "relu_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("dual_linear_relu: the shared input is a bag of features (no gradient path is built)")
+        dw = _ZEROS.zeros((2, N, K), x.device)
+        _gemm(dpre, x, dw, M=N, N=K, K=M, sam=1, sak=N, sbk=K, sbn=1, ldc=K, nb1=2, sa1=M * N, sb1=0, sc1=N * K,
+              splitk=_splitk_for(N, K, M, 2))
+        db = colsum(dpre.reshape(2, M, N))
+        return dx, dw[0], db[0], dw[1], db[1]
+
+
+def dual_linear_relu(x, w0, b0, w1, b1):
+    """(relu(x w0^T + b0), relu(x w1^T + b1)) for two heads of equal shape over one input."""
+    return _DualLinearRelu.apply(x, w0, b0, w1, b1)
+
+
+# ------------------------------------------------------------------------------------------------
 # bf16-storage linear (csrc/gemm_b16.hip): x bf16 [.., K], W an fp32 parameter [N, K] -> y bf16 or fp32 [.., N]
 # ------------------------------------------------------------------------------------------------
 def _bptr(t: torch.Tensor):

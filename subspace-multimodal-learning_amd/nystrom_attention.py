@@ -18,8 +18,10 @@ arrives in that dtype, routes the n'-sized contractions to the 16-bit matrix pip
   * softmax(q kl^T) and softmax(ql k^T) v become two calls of the fused attention kernel (csrc/attn16.hip): the [n', m] and
     [m, n'] probability matrices are never written, out = attn1 (z (attn3 v)) replaces (attn1 z)(attn3 v) (same value, the
     [n', m] x [m, m] product becomes [m, m] x [m, d]);
-  * the qkv / output projections run with single-term bf16 operands (bf16 mode; fp16 mode keeps them exact);
-  * the m x m part - sim2, its softmax and the Newton-Schulz iteration - stays exact fp32 (it is precision-fragile and small).
+  * the qkv / output projections run with single-term 16-bit operands (bf16 mode: bf16 everywhere; fp16 mode: fp16 in the forward
+    product, bf16 in the two gradient products - gradients have no place in fp16's range without a loss scale);
+  * the m x m part - sim2 and its softmax - stays exact fp32; the Newton-Schulz iteration runs on two bf16 planes per matrix (16 operand
+    mantissa bits, z to 2e-5 of an fp64 evaluation: ~25 x finer than the fp16 attention products around it).
 Accuracy of that mode: bf16 ~ 1e-2, fp16 ~ 2e-3 of a tensor's scale (8 / 11 mantissa bits on the operands); the default
 fp32 path is unchanged and is what the 1e-4 parity tests cover."""
 from __future__ import annotations
@@ -243,13 +245,17 @@ class NystromAttention(nn.Module):
             x = x.float()
             if pad:
                 x = F.pad(x, (0, 0, pad, 0), value=0)
-            gm = 0 if fp16 else 3                               # projections: exact in fp16 mode, single-term bf16 operands otherwise
+            # projections on the 16-bit pipe with fp32 storage: single-term bf16 operands (bf16 mode, csrc/gemm.hip mode 3) or single-term
+            # fp16 operands in the forward product and bf16 ones in the two gradient products (fp16 mode, mode 4: fp16 has no range for
+            # gradients without a loss scale).  Round 3 kept the fp16 mode's projections exact: 3 ms of its 5.2 ms step
+            gm = 4 if fp16 else 3
             qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
             q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
         fork = _PinvFork(a2)                                                                   # beside attn3 v and the residual convolution
-        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale, reduced=not fp16), a2)
+        # the two-plane 16-bit form of the Newton-Schulz chain (16 operand mantissa bits: z to 2e-5) in both 16-bit modes
+        z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale, reduced=True), a2)
         right = Fh.attention16(ql, k, v, scale=sc, fp16=fp16)                                  # softmax(ql k^T) v   [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None                   # [b, n', h d]
         fork.join(z)

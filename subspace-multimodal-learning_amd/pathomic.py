@@ -89,10 +89,15 @@ class DeformPathomicNet(nn.Module):
 
     def forward(self, **kwargs):
         x_path = kwargs['x_path']
+        # both branches start with relu(_fc1(x_path)) on the SAME bag (model.py:488-497): one batched launch per direction
+        ft, fi = self.pathomic_net_tumor._fc1[0], self.pathomic_net_immune._fc1[0]
+        shared = ft.weight.shape == fi.weight.shape and x_path.is_cuda and not x_path.requires_grad
+        if shared:
+            pf_t, pf_i = Fh.dual_linear_relu(x_path.float(), ft.weight, ft.bias, fi.weight, fi.bias)
         omic_vec_tumor, _, _ = self.omic_net_tumor(x_omic=kwargs['x_omic_tumor'])
-        rt = self.pathomic_net_tumor(path=x_path, omic=omic_vec_tumor)
+        rt = self.pathomic_net_tumor.forward_features(pf_t, omic_vec_tumor) if shared else self.pathomic_net_tumor(path=x_path, omic=omic_vec_tumor)
         omic_vec_immune, _, _ = self.omic_net_immune(x_omic=kwargs['x_omic_immune'])
-        ri = self.pathomic_net_immune(path=x_path, omic=omic_vec_immune)
+        ri = self.pathomic_net_immune.forward_features(pf_i, omic_vec_immune) if shared else self.pathomic_net_immune(path=x_path, omic=omic_vec_immune)
         pathomic_vec_tumor, pathomic_grads_tumor = rt[0], rt[2]
         pathomic_vec_immune, pathomic_grads_immune = ri[0], ri[2]
         a, b = pathomic_vec_tumor, pathomic_vec_immune

@@ -12,7 +12,7 @@ import importlib
 bld = importlib.import_module("subspace-multimodal-learning_amd._build")
 
 
-def build_variant(name, defs, files=("deform_attn.hip",)):
+def build_variant(name, defs, files=("deform_attn.hip", "deform_attn16.hip")):
     out_dir = os.path.join(PKG, "lib", "variants")
     obj_dir = os.path.join(PKG, "build", "variants", name)
     os.makedirs(out_dir, exist_ok=True); os.makedirs(obj_dir, exist_ok=True)

@@ -2,12 +2,15 @@
   profiles/<tag>_kernel_stats.csv     the --stats table of `python bench.py --steps 3 --warmup 1`
   profiles/<tag>_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels (separate passes), gfx950-corrected
   profiles/<tag>_pmc_notes.md         instruction mix and wait shares per kernel (SQ counters)
-Usage: python tests/summarize_pmc.py r02 [bags_per_launch]"""
+Usage: python tests/summarize_pmc.py r02 [bags_per_launch] [pmc dir prefix = pmc] [kernel-trace dir = prof]
+(the 16-bit compute mode's passes: python tests/summarize_pmc.py r04_deform16 8 pmc16_ prof16)"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 bags = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+PMC = sys.argv[3] if len(sys.argv) > 3 else "pmc"
+PROF = sys.argv[4] if len(sys.argv) > 4 else "prof"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 
@@ -18,7 +21,7 @@ def newest(pattern):
 
 
 def short(name):
-    for key in ("cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel", "gemm_f32_fast_kernel",
+    for key in ("cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel", "gemm_f32_fast_kernel",
                 "gemm_bf3_kernel", "offsets_bwd", "offsets_fwd", "layernorm", "colsum", "attn16_fwd", "attn16_bwd_dq", "attn16_bwd_dkv"):
         if key in name:
             return key
@@ -38,12 +41,14 @@ def counters(path):
     return out
 
 
-ks = newest("prof/runc/*_kernel_stats.csv")
+KERNELS = ("cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel",
+           "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel")
+ks = newest(PROF + "/runc/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_bench_b{bags}_kernel_stats.csv"))
     print("copied", ks)
 mean = lambda v: sum(v) / len(v) if v else float("nan")
-f3, f4 = newest("pmc3/runc/*_counter_collection.csv"), newest("pmc4/runc/*_counter_collection.csv")
+f3, f4 = newest(PMC + "3/runc/*_counter_collection.csv"), newest(PMC + "4/runc/*_counter_collection.csv")
 traffic = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tests/gpu_bench_prof.sh) of `python bench.py --steps 3 --warmup 1 "
                        f"--no-cpu-baseline --no-nystrom` at B = {bags} bags of 10000 x 512 per launch; counter values are KB per dispatch, mean over the "
                        "dispatches of the run.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes -> x 2 for "
@@ -51,21 +56,21 @@ traffic = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separat
            "bags_per_launch": bags, "kernels": {}}
 if f3 and f4:
     c3, c4 = counters(f3), counters(f4)
-    for k in ("cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel"):
+    for k in [k for k in KERNELS if c3[k]["FETCH_SIZE"]]:
         fe, wr = mean(c3[k]["FETCH_SIZE"]), mean(c4[k]["WRITE_SIZE"])
         name = {"cpb_bwd_kernel": "cpb_bwd_kernel<2>", "deform_attn_fwd_kernel": "deform_attn_fwd_kernel<2>"}.get(k, k)
         traffic["kernels"][name] = {"FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "dispatches": len(c3[k]["FETCH_SIZE"])}
     with open(os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps(traffic["kernels"], indent=1))
-f1, f2 = newest("pmc1/runc/*_counter_collection.csv"), newest("pmc2/runc/*_counter_collection.csv")
+f1, f2 = newest(PMC + "1/runc/*_counter_collection.csv"), newest(PMC + "2/runc/*_counter_collection.csv")
 if f1 and f2:
     c1, c2 = counters(f1), counters(f2)
     lines = [f"# PMC notes ({tag}): `python bench.py --steps 3 --warmup 1`, B = {bags} bags of 10 000 x 512, means per dispatch", "",
              "SQ_* cycle counters are in quad-cycles summed over waves (MI355X_MICROARCH.md); instruction counters are wave-instructions.", "",
              "| kernel | VALU insts | MFMA insts | VALU / MFMA | LDS insts | LDS bank-conflict / LDS active | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY (shares of WAVE_CYCLES) | MFMA busy cycles | MFMA busy / SIMD cycles | co-exec / MFMA busy | clock GHz |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for k in ("cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel"):
+    for k in [k for k in KERNELS if c1[k]["SQ_WAVE_CYCLES"]]:
         a, b = c1[k], c2[k]
         wc = mean(a["SQ_WAVE_CYCLES"])
         valu, mf = mean(a["SQ_INSTS_VALU"]), mean(b["SQ_INSTS_MFMA"])

@@ -15,6 +15,7 @@ from test_gpu_parity import _load
 pytestmark = pytest.mark.gpu
 Fh = smml.functional
 TOL = {False: 1.5e-2, True: 2e-3}      # [fp16]
+GRAD_TOL_FP16 = 5e-3                   # whole-block gradients in fp16 mode (bf16 gradient products, see test_nystrom_16bit_mode_vs_oracle)
 
 
 def _ref_attention(q, k, v, scale, residual=None, merged=False):
@@ -122,9 +123,13 @@ def test_nystrom_16bit_mode_vs_oracle(cuda, mode, B, n):
     tol = TOL[mode == "fp16"]
     assert mod.matrix_pipe(xd.dtype) == ("f16" if mode == "fp16" else "bf16")
     assert_close(tag + " out", out, o64, tol)
-    assert_close(tag + " dx", xd.grad, xr.grad, tol)
+    # gradients: bf16 mode tol; fp16 mode GRAD_TOL_FP16 - its gradient products (dx = dy W, dW = dy^T x of the two projections, and the
+    # landmark-side chain) run on bf16 operands since round 4 (fp16 has no range for gradients without a loss scale; the forward products
+    # keep fp16's 11 bits): measured dx 3.1e-3 at 1 x 4096, 3.4e-3 at 1 x 50 000 (round 3, exact fp32 projections: 1.6e-3)
+    gtol = tol if mode != "fp16" else GRAD_TOL_FP16
+    assert_close(tag + " dx", xd.grad, xr.grad, gtol)
     for k, p in mod.named_parameters():
-        assert_close(tag + " d" + k, p.grad, pr[k].grad, 2 * tol)      # weight gradients sum B n' rounded products
+        assert_close(tag + " d" + k, p.grad, pr[k].grad, 2 * gtol)      # weight gradients sum B n' rounded products
     mod32 = _load(smml.NystromAttention(dim=512, dim_head=64, heads=8, num_landmarks=256, dropout=0.1), params, cuda)
     with torch.no_grad():
         assert_close(tag + " fp32 mode out", mod32(x.to(cuda)), o64, 1e-4)
@@ -211,3 +216,32 @@ def test_attention16_large_score_range(cuda, fp16):
     assert_close(f"large range out fp16={fp16}", o, o64, tol)
     for t, r, n in zip(dev, ref, "qkv"):
         assert_close(f"large range d{n} fp16={fp16}", t.grad, r.grad, tol)
+
+
+@pytest.mark.parametrize("b,n", [(1, 33), (2, 700), (1, 257), (3, 512)])
+def test_queries_long_two_query_blocks_per_wave(cuda, b, n):
+    """attn16_fwd_q2_kernel (two 32-query blocks per wave) against the one-block kernel on ragged lengths: each block
+    runs the same MFMA / softmax sequence on the same fragments, so outputs and log-sum-exps are the same BITS - with and without the residual."""
+    from importlib import import_module
+    capi = import_module("subspace-multimodal-learning_amd._capi")
+    L = capi.lib()
+    h, d, m = 8, 64, 256
+    gen = torch.Generator().manual_seed(3 + n)
+    qkv = (torch.randn(b, n, 3, h, d, generator=gen) * 0.7).to(torch.bfloat16).to(cuda)
+    kl = (torch.randn(b, h, m, d, generator=gen) * 0.7).to(cuda)
+    w = torch.randn(b, h, m, d, generator=gen).to(cuda)
+    res = torch.randn(b, n, h * d, generator=gen).to(torch.bfloat16).to(cuda)
+    wo = torch.randn(b, n, h * d, generator=gen).to(cuda)
+    outs = {}
+    try:
+        for mode in (0, 2):
+            L.smml_attn16_set_query_blocks(mode)
+            q = qkv.clone().requires_grad_()
+            o_res = Fh.attention16_queries_long(q, kl, w, res, heads=h, scale=0.125)
+            (o_res.float() * wo).sum().backward()          # the backward reads the forward's log-sum-exp: equal gradients = equal lse
+            outs[mode] = (o_res.detach(), Fh.attention16_queries_long(qkv, kl, w, None, heads=h, scale=0.125), q.grad[:, :, 0].clone())
+    finally:
+        L.smml_attn16_set_query_blocks(1)
+    for a, bb in zip(outs[0], outs[2]):
+        assert torch.equal(a, bb)
+    assert torch.isfinite(outs[2][0].float()).all()

@@ -46,11 +46,12 @@ def _nystrom_vs_oracle(cuda, tag, B, n, in_dtype=torch.float32, seed=21):
         # a 16-bit bag selects the 16-bit compute mode of the block (operands rounded to bf16 / fp16 on the matrix pipe, fp32
         # accumulation): tolerance per dtype as stated in tests/test_gpu_attn16.py; the gradient comes back in the bag's dtype
         tol = 1e-2 if in_dtype == torch.bfloat16 else 2e-3
+        gtol = tol if in_dtype == torch.bfloat16 else 5e-3     # fp16 mode: forward products fp16, gradient products bf16 (tests/test_gpu_attn16.py GRAD_TOL_FP16)
         assert xd.grad.dtype == in_dtype
         assert_close(tag + " out (16-bit mode)", out, r64[0], tol)
-        assert_close(tag + " dx (16-bit mode)", xd.grad.float(), r64[1], tol + (2.0 ** -8 if in_dtype == torch.bfloat16 else 2.0 ** -11))
+        assert_close(tag + " dx (16-bit mode)", xd.grad.float(), r64[1], gtol + (2.0 ** -8 if in_dtype == torch.bfloat16 else 2.0 ** -11))
         for k, p in mod.named_parameters():
-            assert_close(tag + " d" + k + " (16-bit mode)", p.grad, r64[2][k].grad, 2 * tol)
+            assert_close(tag + " d" + k + " (16-bit mode)", p.grad, r64[2][k].grad, 2 * gtol)
 
 
 @pytest.mark.parametrize("B,in_dtype", [(1, torch.float32), (2, torch.bfloat16)])
@@ -85,6 +86,17 @@ def test_cfg5_nystrom_long_bag_50000(cuda):
         out3 = mod(x1)
         w[2 * 512:] /= 3.0
         assert_close("linear in v", out3 - b, 3.0 * (out1 - b), 2e-5)
+
+
+# Named exceptions of the full-size case: gradients on the tumor branch's QUERY path - d(fused features) and what hangs below
+# it.  Their fp32 evaluations scatter between realisations: over four (parameters, bag) seeds the error of d to_offsets.2.weight through this
+# path is 1.9e-5 ... 5.1e-5 on the HIP kernels and 7.2e-6 ... 4.9e-5 for the oracle in fp32 on the host (ratio 0.9 ... 4.3), and seed 17 - this
+# test's - is the draw with the smallest host error and the largest HIP one (profiles/r04_fp32_scatter.txt; the error enters through dk, and
+# no precision variant of the kernels - three-term dkv / dQ products, re-centred or two-sweep delta, libm math, five-term layer 2 - moves it).
+# One host run therefore underestimates the fp32 noise of these tensors; they get an explicit bound instead of the larger-of-two-back-ends
+# yardstick of round 3 (the GPU-ATen fp32 figure is still recorded beside every tensor).
+CFG4_FP32_SCATTER = {p: 2.5e-4 for p in ("omic_net_tumor.encoder.", "pathomic_net_tumor.fusion_layer.", "pathomic_net_tumor.layer3.norm.",
+                                          "pathomic_net_tumor.layer3.attn2d.to_offsets.", "pathomic_net_tumor.layer3.attn2d.to_q.")}
 
 
 @pytest.mark.parametrize("B,S", [(2, 24), (1, 100)])
@@ -137,4 +149,4 @@ def test_cfg4_full_fusion_10000x512(cuda, B, S):
     assert lg[4].shape == (B * 8, 2, S // 4, S // 4)
     with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
     assert with_grad == {k for k, v in r64[7].items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
-    _compare_param_grads(net, r32[7], r64[7], skip=("cls_token",), probe=probe, p32_alt=g32[7])
+    _compare_param_grads(net, r32[7], r64[7], skip=("cls_token",), probe=probe, p32_alt=g32[7], scatter=CFG4_FP32_SCATTER if S >= 100 else None)
