@@ -227,7 +227,7 @@ def test_queries_long_two_query_blocks_per_wave(cuda, b, n):
     L = capi.lib()
     h, d, m = 8, 64, 256
     gen = torch.Generator().manual_seed(3 + n)
-    qkv = (torch.randn(b, n, 3, h, d, generator=gen) * 0.7).to(torch.bfloat16).to(cuda)
+    qkv = (torch.randn(b, n, 3 * h * d, generator=gen) * 0.7).to(torch.bfloat16).to(cuda)       # token-major [b, n, (3 h d)]
     kl = (torch.randn(b, h, m, d, generator=gen) * 0.7).to(cuda)
     w = torch.randn(b, h, m, d, generator=gen).to(cuda)
     res = torch.randn(b, n, h * d, generator=gen).to(torch.bfloat16).to(cuda)
@@ -239,7 +239,7 @@ def test_queries_long_two_query_blocks_per_wave(cuda, b, n):
             q = qkv.clone().requires_grad_()
             o_res = Fh.attention16_queries_long(q, kl, w, res, heads=h, scale=0.125)
             (o_res.float() * wo).sum().backward()          # the backward reads the forward's log-sum-exp: equal gradients = equal lse
-            outs[mode] = (o_res.detach(), Fh.attention16_queries_long(qkv, kl, w, None, heads=h, scale=0.125), q.grad[:, :, 0].clone())
+            outs[mode] = (o_res.detach(), Fh.attention16_queries_long(qkv, kl, w, None, heads=h, scale=0.125), q.grad[:, :, :h * d].clone())
     finally:
         L.smml_attn16_set_query_blocks(1)
     for a, bb in zip(outs[0], outs[2]):

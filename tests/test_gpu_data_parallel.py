@@ -229,6 +229,12 @@ def test_syncbn_pofusion_two_ranks(cuda, smml):
         assert torch.equal(g0, g1), f"ranks disagree on {k}"
         if k.endswith("rel_pos_bias.mlp.2.bias"):
             continue
+        if k in ("fusion.encoder1.0.bias", "fusion.encoder2.0.bias"):
+            # the bias of a Linear that feeds a BatchNorm: its gradient is exactly zero in exact arithmetic (the batch mean removes it) -
+            # both sides are rounding noise, held against the scale of the layer's weight gradient
+            scale = float(ref[k.replace(".bias", ".weight")].abs().max())
+            assert float(g0.abs().max()) <= 1e-4 * scale and float(v.abs().max()) <= 1e-4 * scale, k
+            continue
         err = float((g0 - v).abs().max() / v.abs().max().clamp_min(1e-30))
         helpers.record(f"syncbn dp2 d{k}", err, None, 2e-4, "max vs single process")
         if err > 2e-4:

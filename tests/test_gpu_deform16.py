@@ -136,7 +136,7 @@ def test_deform2d_16bit_vs_oracle(cuda, mode, train):
     for k, p in mod.named_parameters():
         if k.endswith("rel_pos_bias.mlp.2.bias"):           # zero in exact arithmetic (softmax shift invariance)
             continue
-        assert_close(tag + " d" + k, p.grad, pref[k].grad, GRAD_TOL[mode])
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, MLP_GRAD_TOL_SMALL if "rel_pos_bias" in k else GRAD_TOL[mode])   # 2e5 pairs: a small problem
     # the mode changes nothing outside the fused core: same vgrid bits as the fp32-grade module
     ref_mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww))
     ref_mod.load_state_dict(params)
@@ -175,7 +175,7 @@ def test_deform1d_16bit_vs_oracle(cuda, mode):
     for k, p in mod.named_parameters():
         if k.endswith("rel_pos_bias.mlp.2.bias") or pref[k].grad is None:
             continue
-        assert_close(tag + " d" + k, p.grad, pref[k].grad, GRAD_TOL[mode])
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, MLP_GRAD_TOL_SMALL if "rel_pos_bias" in k else GRAD_TOL[mode])
 
 
 def test_core16_gradients_are_run_to_run_identical(cuda):
