@@ -129,6 +129,10 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
                          const float* dvgrid, const float* dvs, float* dq, float* dw0, float* db0,
                          float* dw2, void* workspace, size_t workspace_bytes, int B, int Hh, int Ww, int G, int dg,
                          int ks, int r, int posdim, float offset_scale, void* stream);
+/* 1: the NEXT smml_offsets_bwd_f32 call of this host thread ADDS the gradient of q into dq (which already holds the gradient q received from
+ * its other consumer, the fused attention core) instead of overwriting it - one pass over the [B, N, 512] tensor instead of a store plus an
+ * elementwise add; 0 (default) restores overwriting.  Thread-local, like smml_deform_attn_set_seed_offset. */
+void smml_offsets_bwd_accumulate_dq(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear sampling = F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) of the

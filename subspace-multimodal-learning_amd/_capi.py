@@ -49,6 +49,7 @@ SIGNATURES = {
     "smml_offsets_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
     "smml_offsets_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "smml_offsets_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
+    "smml_offsets_bwd_accumulate_dq": (None, [_i]),
     "smml_bilinear_sample_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
     "smml_bilinear_sample_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
     "smml_bilinear_corners_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),

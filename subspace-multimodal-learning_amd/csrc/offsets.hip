@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void offsets_bwd_kernel(
 
 // dq[b, y, x, g*dg + ch] = sum over the windows (ty, tx) covering (y, x) of dy[(b, g, ty, tx)][ch] * w0[ch][ky][kx];
 // one block row per (b, y), a thread per (x, 4 channels): float4 loads of dy, float4 store of dq
+// ACC: dq += (the buffer already holds the gradient q received from the attention core: one pass instead of this kernel's store + an
+// elementwise add of two 164 MB tensors per 8-bag step)
+template <bool ACC>
 __global__ __launch_bounds__(256) void offsets_bwd_gather_kernel(const float* __restrict__ dyb, const float* __restrict__ w0,
                                                                  float* __restrict__ dq, int Hh, int Ww, int G, int dg, int KH,
                                                                  int KW, int rh, int rw, int ph, int pw, int th, int tw) {
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(256) void offsets_bwd_gather_kernel(const float* __
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Ww * iq; t += gridDim.x * blockDim.x) {
     const int x = t / iq, c4 = (t - x * iq) * 4, g = c4 / dg, ch = c4 - g * dg;
     const int tx1 = min(tw - 1, (x + pw) / rw), tx0 = max(0, (x + pw - (KW - 1) + rw - 1) / rw);
+    float4* dst = reinterpret_cast<float4*>(dq + (((size_t)b * Hh + y) * Ww + x) * inner + c4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) acc = *dst;
     for (int ty = ty0; ty <= ty1; ++ty) {
       const int ky = y + ph - ty * rh;
       for (int tx = tx0; tx <= tx1; ++tx) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void offsets_bwd_gather_kernel(const float* __
         acc.z = fmaf(d.z, w.z, acc.z); acc.w = fmaf(d.w, w.w, acc.w);
       }
     }
-    *reinterpret_cast<float4*>(dq + (((size_t)b * Hh + y) * Ww + x) * inner + c4) = acc;
+    *dst = acc;
   }
 }
 
@@ -361,6 +366,11 @@ static int offsets_geometry(const char* fn, int Hh, int Ww, int dg, int ks, int 
   return SMML_OK;
 }
 
+// dq of the NEXT smml_offsets_bwd_f32 call of this host thread is accumulated into (the caller hands over a buffer that already holds
+// another consumer's gradient of q) instead of overwritten
+static thread_local int t_accumulate_dq = 0;
+void smml_offsets_bwd_accumulate_dq(int on) { t_accumulate_dq = on; }
+
 // out-length of the strided offset conv along one axis of size s (0 if it does not fit)
 int smml_offsets_out_len(int s, int ks, int r) {
   const int pad = (ks - r) / 2;
@@ -438,9 +448,12 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
   // grid.x: slices of a (b, y) row; few enough that the weight staging is amortised, enough rows x slices to fill the chip
   const int row_threads = Ww * (G * dg / 4);
   const int slices = max(1, min((row_threads + 255) / 256, (4096 + B * Hh - 1) / (B * Hh)));
-  hipLaunchKernelGGL(offsets_bwd_gather_kernel, dim3(slices, B * Hh), block,
-                     (size_t)dg * kh * ks * sizeof(float), st, dyb, w0, dq, Hh,
-                     Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
+  if (t_accumulate_dq)
+    hipLaunchKernelGGL(offsets_bwd_gather_kernel<true>, dim3(slices, B * Hh), block, (size_t)dg * kh * ks * sizeof(float), st, dyb, w0, dq, Hh,
+                       Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
+  else
+    hipLaunchKernelGGL(offsets_bwd_gather_kernel<false>, dim3(slices, B * Hh), block, (size_t)dg * kh * ks * sizeof(float), st, dyb, w0, dq, Hh,
+                       Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
   SMML_LAUNCH_CHECK("smml_offsets_bwd_f32/gather");
   float* part = slab + (size_t)nblk * nred;
   const int chunk = (nblk + OFF_RED_PARTS - 1) / OFF_RED_PARTS;

@@ -148,9 +148,10 @@ class DeformCrossAttention2D(nn.Module):
         Hh, Ww = self._grid(N)
         G, H = self.offset_groups, self.heads
         q = Fh.grouped_pointwise(x1t, self.to_q.weight, G if self.group_queries else 1)            # [B, N, inner]
+        fork = Fh.GradFork() if (q.requires_grad and not self.consistent_grid_norm) else None       # q's two gradients meet in one buffer
         vgrid, vs = Fh.offsets(q.view(B, Hh, Ww, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
                                self.to_offsets[2].weight.reshape(2, -1), groups=G, ks=self.offset_kernel_size,
-                               r=self.downsample_factor, posdim=2, offset_scale=self.offset_scale)
+                               r=self.downsample_factor, posdim=2, offset_scale=self.offset_scale, fork=fork)
         gq = _grid_queries_2d(Hh, Ww, x1t.device)
         if self.consistent_grid_norm:          # corrected semantics (off by default): pixel-centre convention on both sides
             th, tw = vgrid.shape[-2:]
@@ -163,7 +164,7 @@ class DeformCrossAttention2D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
-                                compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
+                                compute_dtype=self.compute_dtype, fork=fork, **_dropout_args(self, q.device))
         # the output projection follows the core's compute mode (single-term 16-bit operands, fp32 accumulation and storage)
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out

@@ -720,9 +720,21 @@ def layer_norm_token_mean(x, gamma, beta, eps: float = 1e-5):
 # ------------------------------------------------------------------------------------------------
 # offset network: q [B, Hh, Ww, G*dg] -> vgrid [(B G), posdim, th, tw] (or [(B G), t]), vs [(B G), J, posdim]
 # ------------------------------------------------------------------------------------------------
+class GradFork:
+    """q feeds two consumers - the offsets network and the fused attention core - and autograd would add their two [B, N, 512] gradients with
+    an elementwise kernel (492 MB of traffic per 8-bag step).  The attention's backward always runs first (the offsets network's backward
+    needs the d vs it produces): it parks its dq here, the offsets backward ADDS its own contribution into that buffer in place
+    (smml_offsets_bwd_accumulate_dq) and reports no gradient of its own for q.  One object per forward call; None = plain autograd."""
+    __slots__ = ("dq",)
+
+    def __init__(self):
+        self.dq = None
+
+
 class _Offsets(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, w0, b0, w2, groups, ks, r, posdim, offset_scale):
+    def forward(ctx, q, w0, b0, w2, groups, ks, r, posdim, offset_scale, fork=None):
+        ctx.fork = fork
         q = _c(q); w0c = _c(w0); b0c = _c(b0); w2c = _c(w2)
         B, Hh, Ww, inner = q.shape
         dg = inner // groups
@@ -748,22 +760,33 @@ class _Offsets(torch.autograd.Function):
         groups, ks, r, posdim, offset_scale = ctx.cfg
         B, Hh, Ww, inner = q.shape
         dg = inner // groups
-        dq = torch.empty_like(q)
+        fork = ctx.fork
+        parked = fork.dq if fork is not None else None
+        if fork is not None:
+            fork.dq = None
+        acc = parked is not None and parked.numel() == q.numel() and parked.is_contiguous() and parked.dtype == torch.float32
+        dq = parked if acc else torch.empty_like(q)
         dw0, db0, dw2 = torch.empty_like(w0), torch.empty_like(b0), torch.empty_like(w2)
         dvgrid = _c(dvgrid) if dvgrid is not None else None
         dvs = _c(dvs) if dvs is not None else None
         L = capi.lib()
         wsb = L.smml_offsets_bwd_workspace_bytes(B, Hh, Ww, groups, dg, ks, r, posdim)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
-        capi.check(L.smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
-                                          capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
-                                          capi.fptr(db0), capi.fptr(dw2), capi.fptr(ws), wsb, B, Hh, Ww, groups, dg, ks, r,
-                                          posdim, offset_scale, capi.stream()), "offsets_bwd")
-        return dq, dw0, db0, dw2, None, None, None, None, None
+        L.smml_offsets_bwd_accumulate_dq(1 if acc else 0)
+        try:
+            capi.check(L.smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
+                                              capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
+                                              capi.fptr(db0), capi.fptr(dw2), capi.fptr(ws), wsb, B, Hh, Ww, groups, dg, ks, r,
+                                              posdim, offset_scale, capi.stream()), "offsets_bwd")
+        finally:
+            L.smml_offsets_bwd_accumulate_dq(0)
+        # acc: the contribution went into the attention's dq in place - autograd already holds that tensor as q's gradient
+        return (None if acc else dq), dw0, db0, dw2, None, None, None, None, None, None
 
 
-def offsets(q, w0, b0, w2, *, groups, ks, r, posdim, offset_scale):
-    return _Offsets.apply(q, w0, b0, w2, groups, ks, r, posdim, offset_scale)
+def offsets(q, w0, b0, w2, *, groups, ks, r, posdim, offset_scale, fork=None):
+    """fork: a GradFork shared with the deform_attention call that consumes the same q (see GradFork)."""
+    return _Offsets.apply(q, w0, b0, w2, groups, ks, r, posdim, offset_scale, fork)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -840,7 +863,8 @@ def _dtype16(compute_dtype):
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
-                compute_dtype=None):
+                compute_dtype=None, fork=None):
+        ctx.fork = fork
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
         B, N, HD = q.shape
@@ -920,7 +944,9 @@ class _DeformAttn(torch.autograd.Function):
                 *TIMER.events("cpb16_bwd", B * heads * N * J),
                 capi.stream()), "deform_attn16_bwd")
         _set_seed_offset(L, None)
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None
+        if ctx.fork is not None and ctx.needs_input_grad[0]:
+            ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None
 
 
 def _set_seed_offset(L, t):
@@ -956,14 +982,14 @@ def graph_seed_offset(device, allocate_only: bool = False):
 
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
-                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None):
+                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
     compute_dtype None: fp32-grade split products (csrc/deform_attn.hip); 'bf16' / 'fp16': the 16-bit compute mode
     (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32)."""
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
-                             dropout_seed_offset, compute_dtype)
+                             dropout_seed_offset, compute_dtype, fork)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):
