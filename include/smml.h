@@ -281,7 +281,7 @@ int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, flo
 
 /* ------------------------------------------------------------------------------------------------
  * Train-step glue: the gradient-modulation block of the reference's training loop,
- * train_test.py:87-184 (task types diag2021 / grade / subtype), as one launch with no host synchronisation:
+ * train_test.py:87-184 (task types diag2021 / grade / subtype; 'survival' below), as one launch with no host synchronisation:
  * per-branch logits feat_x W_x^T + b / 2, score_x = sum_b softmax(.)[label_b], ratio_t = score_t / score_i, and for
  * every class row of classifier.weight.grad [C, 2 hs] whose tumor / immune halves have negative cosine similarity the
  * projection + renormalisation of the weaker branch's half (:158-183), IN PLACE in weight_grad.
@@ -289,6 +289,15 @@ int smml_dwconv7_bwd_weight_f32(const float* x, const float* dy, float* dwm, flo
  *   info (nullable) [4 + 2 C]: score_t, score_i, ratio_t, ratio_i, then (cosine similarity, branch taken 0 / 1 / 2) per row. */
 int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
                            const long long* label, float* weight_grad, float* info, int B, int C, int hs, void* stream);
+/* task_type 'survival' of the same block (train_test.py:99-102,121-149): the two branch scores are the concordance indices of
+ * risk_b = -sum_t cumprod_t (1 - sigmoid(out_b)) against (censor, survtime) - what the reference obtains on the host from scikit-survival's
+ * concordance_index_censored(event = 1 - censor, survtime, risk, tied_tol = 1e-8) (utils/utils.py:315-317): a sample with an event is
+ * comparable with every sample of later time and with every sample censored at the same time; concordant if its risk is larger, tied within
+ * 1e-8 counts one half.  censor, survtime [B] fp32 (censor 1 = censored).  All samples censored (:127-133) or no comparable pair: no edit.
+ * info[0..1] = cindex_t, cindex_i, the rest as above.  scikit-survival is absent from the build image: parity of this entry is unpinned. */
+int smml_grad_modulate_survival_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
+                                    const float* censor, const float* survtime, float* weight_grad, float* info, int B, int C, int hs,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data-format step in front of the path: bags stored as packed bf16 rows, resampled to the fixed

@@ -19,10 +19,10 @@ from .pathomic import DeformPathomicNet, MaxNet, define_net  # noqa: F401
 from .losses import BatchLoss, GatherLayer, OrthogonalLoss  # noqa: F401
 from .data_parallel import BagDataParallel  # noqa: F401
 from .bag_store import BagStore, BagStoreDataset, BagStoreWriter, fixdim_gather, fixdim_indices  # noqa: F401
-from .train_step import PinnedBagStager, allreduce_scores_then_modulate, gradient_modulate  # noqa: F401
+from .train_step import PinnedBagStager, allreduce_scores_then_modulate, gradient_modulate, gradient_modulate_survival  # noqa: F401
 
 __all__ = [
     "CPB", "Scale", "DeformCrossAttention1D", "DeformCrossAttention2D", "FusionNet", "DeformCrossTransLayer",
     "DeformCrossTransMIL", "Pooler", "NystromAttention", "TransLayer", "PPEG", "TransMIL", "moore_penrose_iter_pinv", "MultiheadAttention", "CMTA", "Transformer_P", "Transformer_G", "SNN_Block", "BilinearFusion", "define_bifusion", "MaxNet", "DeformPathomicNet", "define_net", "BatchLoss", "GatherLayer",
-    "OrthogonalLoss", "BagDataParallel", "gradient_modulate", "PinnedBagStager", "BagStore", "BagStoreWriter", "BagStoreDataset", "fixdim_gather", "fixdim_indices", "functional", "synth", "lib",
+    "OrthogonalLoss", "BagDataParallel", "gradient_modulate", "gradient_modulate_survival", "PinnedBagStager", "BagStore", "BagStoreWriter", "BagStoreDataset", "fixdim_gather", "fixdim_indices", "functional", "synth", "lib",
 ]

@@ -79,6 +79,7 @@ SIGNATURES = {
     "smml_dwconv7_fwd_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_dwconv7_bwd_weight_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "smml_grad_modulate_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
+    "smml_grad_modulate_survival_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f]),
     "smml_fixdim_indices": (_i, [_f, _ll, _ll, _f]),
     "smml_fixdim_gather_bf16": (_i, [_f, _ll, _f, _i, _ll, _i, _f]),
     "smml_event_create": (C.c_void_p, []),

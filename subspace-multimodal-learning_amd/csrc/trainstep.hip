@@ -1,8 +1,10 @@
 // Train-step glue around the hot path: the gradient-modulation block of the reference's training loop
 // as ONE device kernel, so that nothing between loss.backward() and optimizer.step() touches the host.
 //
-// Replaces train_test.py:87-184 (task types diag2021 / grade / subtype; the survival branch needs a host-side C-index from
-// sksurv, train_test.py:121-134, and is not built):
+// Replaces train_test.py:87-184.  Task types diag2021 / grade / subtype (softmax scores) and, since round 4, 'survival': the branch scores
+// are then the concordance indices of risk = -sum_t S_t, S = cumprod(1 - sigmoid(out)) (:99-102,121-128), which the reference obtains on the
+// host from scikit-survival's concordance_index_censored(event = 1 - censor, time, risk, tied_tol = 1e-8) (utils/utils.py:315-317; the
+// package is absent from this image: its published pair rule is restated here - PARITY UNPINNED for this branch, oracle/trainstep.py):
 //   out_t = feat_t W[:, :hs]^T + b / 2,  out_i = feat_i W[:, hs:]^T + b / 2                         (:90-93)
 //   score_x = sum_b softmax(out_x[b])[label[b]]   (Python sum over b in order)                     (:119-120)
 //   ratio_t = score_t / score_i, ratio_i = 1 / ratio_t                                            (:150-152)
@@ -18,9 +20,11 @@ namespace {
 
 constexpr int GM_MAX_C = 16;
 
+// censor / survtime non-null: the survival scores (C-index per branch); label is then unused
 __global__ __launch_bounds__(256) void grad_modulate_kernel(const float* __restrict__ ft, const float* __restrict__ fi,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
-                                                            const long long* __restrict__ label, float* __restrict__ G,
+                                                            const long long* __restrict__ label, const float* __restrict__ censor,
+                                                            const float* __restrict__ survtime, float* __restrict__ G,
                                                             float* __restrict__ info, int B, int C, int hs) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* outs = sm;                       // [2][B][C]
@@ -39,25 +43,72 @@ __global__ __launch_bounds__(256) void grad_modulate_kernel(const float* __restr
     if (lane == 0) outs[item] = s + 0.5f * bias[c];
   }
   __syncthreads();
-  // ---- phase 2: softmax probability of the labelled class per sample ----
-  for (int i = tid; i < 2 * B; i += 256) {
-    const int side = i / B, b = i - side * B;
-    const float* o = outs + (side * B + b) * C;
-    float m = o[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, o[c]);
-    float den = 0.f;
-    for (int c = 0; c < C; ++c) den += expf(o[c] - m);
-    long long lb = label[b];
-    lb = lb < 0 ? 0 : (lb >= C ? C - 1 : lb);      // the reference would raise on an out-of-range label; never fault here
-    pl[i] = expf(o[lb] - m) / den;
-  }
-  __syncthreads();
-  if (tid == 0) {                                   // Python's sum([...]): left to right, starting from 0
-    float st = 0.f, si = 0.f;
-    for (int b = 0; b < B; ++b) { st += pl[b]; si += pl[B + b]; }
-    const float rt = st / si;
-    ratio[0] = rt; ratio[1] = 1.f / rt;
-    if (info) { info[0] = st; info[1] = si; info[2] = rt; info[3] = 1.f / rt; }
+  if (!censor) {
+    // ---- phase 2: softmax probability of the labelled class per sample ----
+    for (int i = tid; i < 2 * B; i += 256) {
+      const int side = i / B, b = i - side * B;
+      const float* o = outs + (side * B + b) * C;
+      float m = o[0];
+      for (int c = 1; c < C; ++c) m = fmaxf(m, o[c]);
+      float den = 0.f;
+      for (int c = 0; c < C; ++c) den += expf(o[c] - m);
+      long long lb = label[b];
+      lb = lb < 0 ? 0 : (lb >= C ? C - 1 : lb);      // the reference would raise on an out-of-range label; never fault here
+      pl[i] = expf(o[lb] - m) / den;
+    }
+    __syncthreads();
+    if (tid == 0) {                                   // Python's sum([...]): left to right, starting from 0
+      float st = 0.f, si = 0.f;
+      for (int b = 0; b < B; ++b) { st += pl[b]; si += pl[B + b]; }
+      const float rt = st / si;
+      ratio[0] = rt; ratio[1] = 1.f / rt;
+      if (info) { info[0] = st; info[1] = si; info[2] = rt; info[3] = 1.f / rt; }
+    }
+  } else {
+    // ---- phase 2 (survival): risk_b = -sum_t cumprod_t (1 - sigmoid(out_b)) per branch (:99-102,123-124) ----
+    for (int i = tid; i < 2 * B; i += 256) {
+      const float* o = outs + i * C;
+      float S = 1.f, acc = 0.f;
+      for (int c = 0; c < C; ++c) { S *= 1.f - 1.f / (1.f + expf(-o[c])); acc += S; }
+      pl[i] = -acc;
+    }
+    __syncthreads();
+    // concordance index per branch, scikit-survival's rule: sample i with an event (censor == 0) is comparable with every j whose time is
+    // later, and with every j CENSORED at the same time; a comparable pair is concordant if risk_i > risk_j, tied if |risk_i - risk_j| <= 1e-8
+    // (counted 1/2), else discordant; c = (concordant + tied / 2) / comparable.  One thread per (branch, i), integer counts, then a serial sum.
+    float* cnt = outs;                              // reuse the logits' LDS: [2][B][2] (numerator x 2, comparable)
+    __syncthreads();
+    for (int i = tid; i < 2 * B; i += 256) {
+      const int side = i / B, a = i - side * B;
+      int num2 = 0, den = 0;                        // numerator in halves
+      if (censor[a] == 0.f) {
+        const float ta = survtime[a], ra = pl[side * B + a];
+        for (int j = 0; j < B; ++j) {
+          if (j == a) continue;
+          const float tj = survtime[j];
+          if (tj > ta || (tj == ta && censor[j] != 0.f)) {
+            const float rj = pl[side * B + j];
+            ++den;
+            num2 += (fabsf(ra - rj) <= 1e-8f) ? 1 : ((ra > rj) ? 2 : 0);
+          }
+        }
+      }
+      cnt[2 * i] = (float)num2; cnt[2 * i + 1] = (float)den;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float n2[2] = {0.f, 0.f}, dn[2] = {0.f, 0.f};
+      float cm = 0.f;
+      for (int b = 0; b < B; ++b) cm += censor[b];
+      for (int sd = 0; sd < 2; ++sd)
+        for (int b = 0; b < B; ++b) { n2[sd] += cnt[2 * (sd * B + b)]; dn[sd] += cnt[2 * (sd * B + b) + 1]; }
+      // all samples censored (:127-133), or no comparable pair (scikit-survival raises there): no modulation - ratios that take no branch
+      const bool ok = (cm != (float)B) && dn[0] > 0.f && dn[1] > 0.f;
+      const float ct = ok ? 0.5f * n2[0] / dn[0] : 1.f, ci = ok ? 0.5f * n2[1] / dn[1] : 1.f;
+      const float rt = ok ? ct / ci : 1.f;
+      ratio[0] = rt; ratio[1] = ok ? 1.f / rt : 1.f;
+      if (info) { info[0] = ct; info[1] = ci; info[2] = ratio[0]; info[3] = ratio[1]; }
+    }
   }
   __syncthreads();
   const float ratio_t = ratio[0], ratio_i = ratio[1];
@@ -106,8 +157,24 @@ int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float
   const size_t lds = ((size_t)2 * B * C + 2 * B + 2) * sizeof(float);
   SMML_REQUIRE(lds <= 64 * 1024, "smml_grad_modulate_f32: B x C = %d x %d needs %zu bytes of LDS (limit 64 KiB: B (C + 1) <= 8191)", B, C, lds);
   hipLaunchKernelGGL(grad_modulate_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, feat_t, feat_i, weight, bias, label,
-                     weight_grad, info, B, C, hs);
+                     (const float*)nullptr, (const float*)nullptr, weight_grad, info, B, C, hs);
   SMML_LAUNCH_CHECK("smml_grad_modulate_f32");
+  return SMML_OK;
+}
+
+// task_type 'survival' (train_test.py:99-102,121-149): the branch scores are concordance indices of risk = -sum_t S_t against
+// (censor, survtime) [B] fp32 each (censor 1 = censored); info[0..1] = cindex_t, cindex_i.  All censored / no comparable pair: no edit.
+int smml_grad_modulate_survival_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
+                                    const float* censor, const float* survtime, float* weight_grad, float* info, int B, int C, int hs,
+                                    void* stream) {
+  SMML_REQUIRE(feat_t && feat_i && weight && bias && censor && survtime && weight_grad, "smml_grad_modulate_survival_f32: null pointer");
+  SMML_REQUIRE(B > 0 && B <= 1024 && C >= 2 && C <= GM_MAX_C && hs > 0, "smml_grad_modulate_survival_f32: need 0 < B <= 1024, 2 <= C <= %d, hs > 0",
+               GM_MAX_C);
+  const size_t lds = ((size_t)2 * B * C + 2 * B + 2) * sizeof(float);
+  SMML_REQUIRE(lds <= 64 * 1024, "smml_grad_modulate_survival_f32: B x C = %d x %d needs %zu bytes of LDS (limit 64 KiB)", B, C, lds);
+  hipLaunchKernelGGL(grad_modulate_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, feat_t, feat_i, weight, bias,
+                     (const long long*)nullptr, censor, survtime, weight_grad, info, B, C, hs);
+  SMML_LAUNCH_CHECK("smml_grad_modulate_survival_f32");
   return SMML_OK;
 }
 

@@ -78,6 +78,7 @@ def _dropout_args(mod, device=None):
 
 
 _GRID_CACHE = {}
+_GRAD_FORK = __import__("os").environ.get("SMML_GRAD_FORK", "1") != "0"       # measurement switch (functional.GradFork)
 
 
 def _grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
@@ -148,7 +149,7 @@ class DeformCrossAttention2D(nn.Module):
         Hh, Ww = self._grid(N)
         G, H = self.offset_groups, self.heads
         q = Fh.grouped_pointwise(x1t, self.to_q.weight, G if self.group_queries else 1)            # [B, N, inner]
-        fork = Fh.GradFork() if (q.requires_grad and not self.consistent_grid_norm) else None       # q's two gradients meet in one buffer
+        fork = Fh.GradFork() if (q.requires_grad and not self.consistent_grid_norm and _GRAD_FORK) else None       # q's two gradients meet in one buffer
         vgrid, vs = Fh.offsets(q.view(B, Hh, Ww, -1), self.to_offsets[0].weight, self.to_offsets[0].bias,
                                self.to_offsets[2].weight.reshape(2, -1), groups=G, ks=self.offset_kernel_size,
                                r=self.downsample_factor, posdim=2, offset_scale=self.offset_scale, fork=fork)

@@ -2,8 +2,9 @@
 
   gradient_modulate   train_test.py:87-184   the gradient-modulation block between loss.backward() and optimizer.step()
                                              as ONE device launch (csrc/trainstep.hip): no .item(), no per-sample Python
-                                             loop, no host synchronisation.  Task types diag2021 / grade / subtype; the
-                                             survival branch needs sksurv's C-index on the host (:121-134) and is not built.
+                                             loop, no host synchronisation.  Task types diag2021 / grade / subtype, and
+                                             'survival' (gradient_modulate_survival: the C-index of :121-134 on the device;
+                                             scikit-survival is absent from this image - that branch's parity is unpinned).
   PinnedBagStager     train_test.py:53       `x_path.cuda()` of a pageable [B, 2500, 1024] fp32 batch (82 MB per step) replaced
                                              by three pinned staging slots and asynchronous copies on a side stream: the host
                                              copy and the PCIe transfer of batch k + 2 run while batch k computes.
@@ -46,6 +47,33 @@ def gradient_modulate(classifier: torch.nn.Module, feat_t: torch.Tensor, feat_i:
         capi.check(capi.lib().smml_grad_modulate_f32(capi.fptr(ft), capi.fptr(fi), capi.fptr(w.detach()), capi.fptr(b.detach()),
                                                      capi.ptr(lab), capi.fptr(g), capi.fptr(info), B, C, hs,
                                                      capi.stream(g.device)), "grad_modulate")
+    return info
+
+
+def gradient_modulate_survival(classifier: torch.nn.Module, feat_t: torch.Tensor, feat_i: torch.Tensor, censor: torch.Tensor,
+                               survtime: torch.Tensor, hs: Optional[int] = None, return_info: bool = False):
+    """task_type 'survival' (train_test.py:99-102,121-149): as gradient_modulate, with the branch scores = concordance index of
+    risk = -sum_t cumprod(1 - sigmoid(out)) against censor (label[:, 9], 1 = censored) and survtime (label[:, 11]), both [B]."""
+    w, b = classifier.weight, classifier.bias
+    g = w.grad
+    if g is None:
+        raise RuntimeError("gradient_modulate_survival: classifier.weight.grad is None (call it after backward())")
+    C, two_hs = w.shape
+    hs = int(hs) if hs is not None else two_hs // 2
+    if two_hs != 2 * hs or feat_t.shape[-1] != hs or feat_i.shape[-1] != hs:
+        raise RuntimeError("gradient_modulate_survival: classifier.weight must be [C, 2 hs] and the branch vectors [B, hs]")
+    if not g.is_contiguous():
+        raise RuntimeError("gradient_modulate_survival: classifier.weight.grad must be contiguous")
+    B = feat_t.shape[0]
+    ft, fi = feat_t.detach().float().contiguous(), feat_i.detach().float().contiguous()
+    cen, tim = censor.detach().float().contiguous(), survtime.detach().float().contiguous()
+    if cen.numel() != B or tim.numel() != B:
+        raise RuntimeError("gradient_modulate_survival: censor and survtime must hold one value per sample")
+    info = torch.empty(4 + 2 * C, device=g.device, dtype=torch.float32) if return_info else None
+    with torch.cuda.device_of(g):
+        capi.check(capi.lib().smml_grad_modulate_survival_f32(capi.fptr(ft), capi.fptr(fi), capi.fptr(w.detach()), capi.fptr(b.detach()),
+                                                              capi.fptr(cen), capi.fptr(tim), capi.fptr(g), capi.fptr(info), B, C, hs,
+                                                              capi.stream(g.device)), "grad_modulate_survival")
     return info
 
 

@@ -106,3 +106,44 @@ def test_pinned_bag_stager(cuda):
     for k, (bag, om, lab) in enumerate(st16):
         assert bag.dtype == torch.bfloat16 and torch.equal(bag.cpu(), batches[k][0].to(torch.bfloat16))
     assert list(smml.PinnedBagStager([], cuda)) == []
+
+
+def _surv_case(seed, B=8, C=4, hs=128, all_censored=False, tied_times=True):
+    gen = torch.Generator().manual_seed(seed)
+    ft, fi = torch.randn(B, hs, generator=gen), torch.randn(B, hs, generator=gen)
+    W = torch.randn(C, 2 * hs, generator=gen) * 0.2; b = torch.randn(C, generator=gen) * 0.1
+    G = torch.randn(C, 2 * hs, generator=gen) * 0.05
+    for r in range(0, C, 2):                                   # make some rows' halves point against each other (sim < 0)
+        G[r, hs:] = -G[r, :hs] * 0.7 + 0.05 * torch.randn(hs, generator=gen)
+    censor = (torch.rand(B, generator=gen) < 0.4).float()
+    if all_censored:
+        censor[:] = 1.0
+    elif float(censor.mean()) == 1.0:
+        censor[0] = 0.0
+    time = torch.randint(1, 12 if tied_times else 10 ** 6, (B,), generator=gen).float()      # small range: ties in time occur
+    return ft, fi, W, b, censor, time, G
+
+
+@pytest.mark.parametrize("seed,B", [(1, 8), (2, 8), (3, 16), (4, 64), (5, 5), (6, 2)])
+def test_gradient_modulate_survival_vs_oracle(cuda, seed, B):
+    """task_type 'survival' (train_test.py:99-102,121-149; VERDICT r03 'missing' 3): risk = -sum_t S_t, C-index per branch by scikit-survival's
+    pair rule, ratios, row edits - against the oracle's restatement (PARITY UNPINNED: scikit-survival is absent from this image), incl. ties in
+    time, censored samples and batches without a comparable pair."""
+    from oracle.trainstep import gradient_modulate_survival as oracle_surv
+    ft, fi, W, b, censor, time, G = _surv_case(seed, B=B)
+    ref, info = oracle_surv(ft, fi, W, b, censor, time, G)
+    cls = _classifier(W, b, G, cuda)
+    got = smml.gradient_modulate_survival(cls, ft.to(cuda), fi.to(cuda), censor.to(cuda), time.to(cuda), return_info=True).cpu()
+    assert_close(f"gradmod survival seed {seed} B {B}", cls.weight.grad, ref, 1e-5)
+    assert [int(x) for x in got[5::2].tolist()] == info["branch"]
+    if info["cindex_t"] is not None:
+        assert abs(float(got[0]) - info["cindex_t"]) <= 1e-6 and abs(float(got[1]) - info["cindex_i"]) <= 1e-6
+    else:
+        assert torch.equal(cls.weight.grad.cpu(), G)
+
+
+def test_gradient_modulate_survival_all_censored_is_a_no_op(cuda):
+    ft, fi, W, b, censor, time, G = _surv_case(7, all_censored=True)
+    cls = _classifier(W, b, G, cuda)
+    smml.gradient_modulate_survival(cls, ft.to(cuda), fi.to(cuda), censor.to(cuda), time.to(cuda))
+    assert torch.equal(cls.weight.grad.cpu(), G)               # train_test.py:127-133: "All samples are censored" -> ratios None -> no edit
