@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     // VALU instruction between two of these MFMAs adds its full issue time), so the loop is written for the
     // fewest vector instructions: b2 rides in as the chain's initial accumulator, no register copies.
     const int nk = min(KT, J - j0);
-    for (int jj = 0; jj < nk; ++jj) {
+    auto bias_chain = [&](int jj, bool store_mask) {
       const float p0 = slog1p(gq0 - vsl[jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
@@ -227,10 +227,18 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
           mb3 = fmaf(fminf(fmaxf(rb[1] * big, 0.f), 1.f), (float)(1u << ((16 + r) & 15)), mb3);
         }
       }
-      if (SAVE) MKb[(size_t)(j0 + jj) * 64 + c] = (unsigned short)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // padded tiles: no bounds check
+      if (SAVE && store_mask) MKb[(size_t)(j0 + jj) * 64 + c] = (unsigned short)(unsigned)((mb0 + mb1) + (mb2 + mb3));   // rows of padded query lanes exist
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);   // both halves store the same sum: no exec masking in the loop
+    };
+#if SMML_FWD_PAIR
+    for (int jj = 0; jj < nk; jj += 2) {              // two keys per trip: one chain's MFMA latencies under the other's vector work
+      bias_chain(jj, true);
+      bias_chain(jj + 1, jj + 1 < nk);                // jj + 1 <= 31: inside the staged tile (zero positions past the last key)
     }
+#else
+    for (int jj = 0; jj < nk; ++jj) bias_chain(jj, true);
+#endif
     wave_lds_fence();
 
     // bias add, key mask, online softmax

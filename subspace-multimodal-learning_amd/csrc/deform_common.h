@@ -28,6 +28,9 @@
                               // dW3 4x and, with every ReLU unit active, dW2 / db 3-4x closer to fp64; everything else
                               // unchanged; costs 0.3-0.45 ms of the 17.5 ms step (one more score read + an exp per pair).
 #endif
+#ifndef SMML_FWD_PAIR
+#define SMML_FWD_PAIR 0       // 1: two keys per trip of the forward's position-bias loop (measurement variant)
+#endif
 #ifndef SMML_DELTA_EXACT
 #define SMML_DELTA_EXACT 0    // 1: the dq pass forms delta = sum_k P_k dP_k from its own dP products in a first sweep over the keys (measurement
                               // variant, deform_attn.hip; + ~0.4 ms per 8-bag step).  Default: delta = rowsum(dO . O).
