@@ -108,6 +108,12 @@ int smml_colsum_f32(const float* x, float* out, int nb, long long R, int C, floa
 int smml_orth_loss_f32(const float* P, const float* Ph, const float* G, const float* Gh, const float* dloss, float* loss,
                        float* dP, float* dPh, float* dG, float* dGh, int B, int D, float gamma, void* stream);
 
+/* Tail of BatchLoss after its two Gram products (utils/loss.py:26-40): S = go / ||go||_row, V = mean_g gv[g] / ||gv[g]||_row,
+ * loss = (S - V)^2 / n_total on [R, R] (dloss NULL), or the gradients dgo [R, R], dgv [nv, R, R] for a given dloss [R, R]; R = batch x world
+ * <= 64, nv <= 16 (the reference's 8 offset groups).  One launch per direction instead of ~30 launch-bound elementwise kernels. */
+int smml_batchloss_tail_f32(const float* go, const float* gv, const float* dloss, float* loss, float* dgo, float* dgv, int R, int nv,
+                            float n_total, void* stream);
+
 /* dx = dy * (y > 0)  (ReLU of _fc1, DeformCrossTransMIL.py:83) */
 int smml_relu_bwd_f32(const float* dy, const float* y, float* dx, long long n, void* stream);
 

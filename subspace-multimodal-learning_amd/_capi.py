@@ -44,6 +44,7 @@ SIGNATURES = {
     "smml_layernorm_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _ll, _i, _ll, _fl, _i, _f]),
     "smml_colsum_f32": (_i, [_f, _f, _i, _ll, _i, _fl, _f]),
     "smml_orth_loss_f32": (_i, [_f] * 10 + [_i, _i, _fl, _f]),
+    "smml_batchloss_tail_f32": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _fl, _f]),
     "smml_relu_bwd_f32": (_i, [_f, _f, _f, _ll, _f]),
     "smml_offsets_out_len": (_i, [_i, _i, _i]),
     "smml_offsets_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),

@@ -268,6 +268,61 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 
 
 // OrthogonalLoss (models/cmta_utils.py:1217-1228): one wave per sample, five |cosine similarities| of the
+// Tail of BatchLoss (utils/loss.py:26-40) after the two Gram products: S = G_o / ||G_o||_row, V = mean_g G_v[g] / ||G_v[g]||_row,
+// L = (S - V)^2 / N - and its backward - on [R, R] / [nv, R, R] matrices with R = batch x world <= 64: one workgroup, one thread per row.
+// (In torch this tail is ~30 launch-bound ATen kernels per loss and direction: norm, div, stack, mean, sub, pow, div and their autograd twins.)
+//   dL given:  dS = 2 (S - V) dL / N;  d G_o row i = (dS_i - S_i (S_i . dS_i)) / ||G_o,i||;  the same through each G_v[g] with -dS / nv
+__global__ __launch_bounds__(64) void batchloss_tail_kernel(const float* __restrict__ Go, const float* __restrict__ Gv,
+                                                            const float* __restrict__ dL, float* __restrict__ L,
+                                                            float* __restrict__ dGo, float* __restrict__ dGv, int R, int nv, float Nf) {
+  const int i = threadIdx.x;
+  if (i >= R) return;
+  const float* go = Go + (size_t)i * R;
+  float no = 0.f;
+  for (int j = 0; j < R; ++j) no = fmaf(go[j], go[j], no);
+  no = sqrtf(no);
+  float nvn[16];
+  for (int g = 0; g < nv; ++g) {
+    const float* gv = Gv + ((size_t)g * R + i) * R;
+    float t = 0.f;
+    for (int j = 0; j < R; ++j) t = fmaf(gv[j], gv[j], t);
+    nvn[g] = sqrtf(t);
+  }
+  const float invn = 1.f / (float)nv;
+  if (!dL) {
+    for (int j = 0; j < R; ++j) {
+      float v = 0.f;
+      for (int g = 0; g < nv; ++g) v += Gv[((size_t)g * R + i) * R + j] / nvn[g];
+      const float d = go[j] / no - v * invn;
+      L[(size_t)i * R + j] = d * d / Nf;
+    }
+    return;
+  }
+  // backward: dS row, its projection on S, then the same per vgrid group
+  float sdot = 0.f;
+  float vdot[16];
+  for (int g = 0; g < nv; ++g) vdot[g] = 0.f;
+  for (int j = 0; j < R; ++j) {
+    float v = 0.f;
+    for (int g = 0; g < nv; ++g) v += Gv[((size_t)g * R + i) * R + j] / nvn[g];
+    const float s = go[j] / no;
+    const float ds = 2.f * (s - v * invn) * dL[(size_t)i * R + j] / Nf;
+    sdot = fmaf(s, ds, sdot);
+    for (int g = 0; g < nv; ++g) vdot[g] = fmaf(Gv[((size_t)g * R + i) * R + j] / nvn[g], -ds * invn, vdot[g]);
+  }
+  for (int j = 0; j < R; ++j) {
+    float v = 0.f;
+    for (int g = 0; g < nv; ++g) v += Gv[((size_t)g * R + i) * R + j] / nvn[g];
+    const float s = go[j] / no;
+    const float ds = 2.f * (s - v * invn) * dL[(size_t)i * R + j] / Nf;
+    dGo[(size_t)i * R + j] = (ds - s * sdot) / no;
+    for (int g = 0; g < nv; ++g) {
+      const float y = Gv[((size_t)g * R + i) * R + j] / nvn[g];
+      dGv[((size_t)g * R + i) * R + j] = (-ds * invn - y * vdot[g]) / nvn[g];
+    }
+  }
+}
+
 // rows P, P_hat, G, G_hat [B, D] by wavefront reductions:
 //   loss = (1 - |cos(sg P, Ph)|) + (1 - |cos(sg G, Gh)|) + gamma (|cos(P, G)| + |cos(sg P, Gh)| + |cos(sg G, Ph)|)
 // (sg = stop-gradient / .detach()).  Backward in the same kernel family: d cos(a,b)/da = b/(|a||b|) - cos a/|a|^2.
@@ -369,6 +424,16 @@ int smml_orth_loss_f32(const float* P, const float* Ph, const float* G, const fl
   hipLaunchKernelGGL(orth_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, P, Ph, G, Gh, dloss, loss, dP, dPh, dG,
                      dGh, D, gamma, 1e-8f);
   SMML_LAUNCH_CHECK("smml_orth_loss_f32");
+  return SMML_OK;
+}
+
+// BatchLoss tail (utils/loss.py:26-40): go [R, R], gv [nv, R, R] -> loss [R, R] (dloss == NULL) or dgo, dgv (dloss given); R <= 64, nv <= 16
+int smml_batchloss_tail_f32(const float* go, const float* gv, const float* dloss, float* loss, float* dgo, float* dgv, int R, int nv,
+                            float n_total, void* stream) {
+  SMML_REQUIRE(go && gv && R > 0 && R <= 64 && nv > 0 && nv <= 16 && n_total > 0.f, "smml_batchloss_tail_f32: need 0 < R <= 64, 0 < nv <= 16");
+  SMML_REQUIRE(dloss ? (dgo && dgv) : (loss != nullptr), "smml_batchloss_tail_f32: outputs missing");
+  hipLaunchKernelGGL(batchloss_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, go, gv, dloss, loss, dgo, dgv, R, nv, n_total);
+  SMML_LAUNCH_CHECK("smml_batchloss_tail_f32");
   return SMML_OK;
 }
 

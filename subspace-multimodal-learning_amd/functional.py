@@ -1073,6 +1073,35 @@ def gram(x):
     return _Gram.apply(x)
 
 
+class _BatchLossTail(torch.autograd.Function):
+    """(go / ||go||_row - mean_g gv[g] / ||gv[g]||_row)^2 / n on [R, R] matrices (utils/loss.py:26-40): one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, go, gv, n_total):
+        go, gv = _c(go), _c(gv)
+        R, nv = go.shape[-1], gv.shape[0]
+        out = torch.empty(R, R, device=go.device, dtype=torch.float32)
+        capi.check(capi.lib().smml_batchloss_tail_f32(capi.fptr(go), capi.fptr(gv), None, capi.fptr(out), None, None, R, nv, float(n_total),
+                                                      capi.stream()), "batchloss_tail")
+        ctx.n_total = float(n_total)
+        ctx.save_for_backward(go, gv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        go, gv = ctx.saved_tensors
+        R, nv = go.shape[-1], gv.shape[0]
+        dgo, dgv = torch.empty_like(go), torch.empty_like(gv)
+        capi.check(capi.lib().smml_batchloss_tail_f32(capi.fptr(go), capi.fptr(gv), capi.fptr(_c(dl)), None, capi.fptr(dgo), capi.fptr(dgv), R, nv,
+                                                      ctx.n_total, capi.stream()), "batchloss_tail_bwd")
+        return dgo, dgv, None
+
+
+def batchloss_tail(go, gv, n_total):
+    """go [R, R] (Gram of the omic rows), gv [nv, R, R] (Grams of the vgrid groups) -> the BatchLoss matrix [R, R]."""
+    return _BatchLossTail.apply(go, gv, n_total)
+
+
 # ------------------------------------------------------------------------------------------------
 # generic batched product on the matrix cores: C = alpha * op(A) @ op(B) + beta * R
 # (Nystrom sims / landmark products / pinv iteration, co-attention)
