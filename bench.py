@@ -198,6 +198,19 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
             "qkav_share_of_flops": qkav / total}
 
 
+def make_adam(params, capturable=False):
+    """torch.optim.Adam as the reference configures it (lr / weight decay of config_mine.yaml:41-47 scaled down for a synthetic step); the
+    fused implementation (one multi-tensor launch instead of seven) where this torch build has it - SMML_ADAM=foreach selects the other."""
+    params = list(params)
+    kw = dict(lr=1e-4, weight_decay=0.1, capturable=capturable)
+    if os.environ.get("SMML_ADAM", "fused") == "fused":
+        try:
+            return torch.optim.Adam(params, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.Adam(params, foreach=True, **kw)
+
+
 def nystrom_legs(pkg, dev):
     """BASELINE config 2 (8 x 4096 bf16), the N = 10 000 bag in bf16 / fp32, and config 5 (one 50 000-instance fp16 bag)."""
     legs = []
@@ -219,7 +232,7 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3):
     mil = pkg.DeformCrossTransMIL(mil_args(in_dim, dtype))
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
     mil = mil.to(dev).train()
-    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True)
+    opt = make_adam(mil.parameters())
     bloss = pkg.BatchLoss(B, 1)
     path = pkg.synth.bag(B, N, in_dim, 42, "bench:bag").to(dev)
     omic = torch.relu(pkg.synth.normal((B, 128), 42, "bench:omicvec")).to(dev)
@@ -314,7 +327,7 @@ def main():
     mil = mil.to(dev).train()              # train mode: attention dropout 0.1 (DeformCrossTransMIL.py:49) is active
     model = pkg.BagDataParallel(mil) if world > 1 else mil
     use_graph = bool(a.graph and world == 1)
-    opt = torch.optim.Adam(mil.parameters(), lr=1e-4, weight_decay=0.1, foreach=True, capturable=use_graph)
+    opt = make_adam(mil.parameters(), capturable=use_graph)
     bloss = pkg.BatchLoss(B, world)
     # synthetic bags, resident in HBM before timing; a different bag set per rank (whole bags per rank)
     path = pkg.synth.bag(B, N, in_dim, 42 + rank, "bench:bag").to(dev)
