@@ -34,7 +34,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: pe
 F16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PF dense BF16/F16 MFMA - the pipe every contraction of the dominant kernels issues on
 CPB_BWD_MFMAS = 12                  # 32x32x16 MFMAs cpb_bwd_kernel issues per (key, 32 queries): 1 + 1 + 2 + 4 + 4
 CPB_FWD_MFMAS = 7                   # deform_attn_fwd_kernel: 1 (layer 1) + 6 (layer 2, three-term split) 16-bit MFMAs per (key, 32 queries)
-CPB16_BWD_MFMAS = 8                 # cpb16_bwd_kernel (16-bit compute mode): 1 + 1 + 2 + 2 + 2
+CPB16_BWD_MFMAS = 10                # cpb16_bwd_kernel (16-bit compute mode): 1 + 1 + 2 + 2 + 2, + 2 for d p on the matrix pipe (SMML16_DP_MFMA)
 CPB16_FWD_MFMAS = 3                 # deform16_fwd_kernel: 1 (layer 1) + 2 (layer 2, one term) + 8/32 for QK^T / PV
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
