@@ -119,8 +119,9 @@ def nystrom_flop(n, D=512, h=8, d=64, m=256, iters=6, k=33):
     return total, qkav
 
 
-def mil_args(in_dim, deform_dtype=None):
-    return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim, deform_compute_dtype=deform_dtype)
+def mil_args(in_dim, deform_dtype=None, cpb_table=False):
+    return argparse.Namespace(path_dim=128, attn_dim=2, return_vgrid=True, input_path_dim=in_dim, deform_compute_dtype=deform_dtype,
+                              deform_cpb_table=cpb_table)
 
 
 def algorithmic_flop_per_bag(N, J, in_dim, C=128, H=8):
@@ -222,14 +223,14 @@ def nystrom_legs(pkg, dev):
     return legs
 
 
-def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3):
+def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_table=False):
     """The headline training step (same model, parameters, bags, losses, Adam) with the fused attention core in its 16-bit compute
     mode (csrc/deform_attn16.hip; BASELINE config 4 names bf16): ms per step by wall clock between synchronisations, the two dominant
     kernels by HIP events on their launch stream, algorithmic flops as for the fp32-grade line.  Not part of `value`."""
     Fh = pkg.functional
     N = S * S
     torch.manual_seed(42)
-    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, dtype))
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, dtype, cpb_table))
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
     mil = mil.to(dev).train()
     opt = make_adam(mil.parameters())
@@ -260,6 +261,15 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3):
     out = {"workload": f"the headline step with DeformCrossAttention2D(compute_dtype='{dtype}'): {B} bags of {N} x {in_dim} per step, "
                        f"fwd + bwd + Adam, CE + BatchLoss; parameters, inputs, outputs and gradients fp32 in memory",
            "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
+    if cpb_table:
+        out["workload"] += ("; position bias in TABLE mode (cpb_table=True: the MLP evaluated once per call on a 96 x 96 grid, interpolated per pair - an "
+                            "APPROXIMATION of the reference's per-pair MLP, see tests/test_gpu_deform_table.py; not a parity-grade line)")
+        out["approximate"] = True
+        for key in ("deform_table_fwd", "cpb_table_bwd"):
+            if key in kt:
+                n, ms, pairs = kt[key]
+                out[key] = {"avg_ms": ms, "launches": n, "pairs_per_launch": pairs,
+                            "note": "forward kernel" if key == "deform_table_fwd" else "d vs (per pair) + d table (two dense products per key on the matrix pipe)"}
     if "cpb16_bwd" in kt:
         n, ms, pairs = kt["cpb16_bwd"]
         flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR
@@ -428,6 +438,11 @@ def main():
                     out["deform16"]["speedup_vs_fp32_line"] = out["deform16"]["bags_per_s"] / out["value"]
                 except Exception as e:
                     out["deform16"] = {"error": f"{type(e).__name__}: {e}"}
+                try:        # the same step with the tabulated position bias (approximate mode; extra key, never part of `value`)
+                    out["deform16_table"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3, cpb_table=True)
+                    out["deform16_table"]["speedup_vs_fp32_line"] = out["deform16_table"]["bags_per_s"] / out["value"]
+                except Exception as e:
+                    out["deform16_table"] = {"error": f"{type(e).__name__}: {e}"}
             if world == 1 and not a.no_nystrom:
                 # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
                 # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU

@@ -210,6 +210,30 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
                            float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
                            int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                            int dtype, void* ev_start, void* ev_stop, void* stream);
+/* Table mode of the 16-bit core (csrc/deform_attn16.hip, "table mode"): the continuous position bias CPB(slog(gq - vs)) of
+ * models/DeformableAttention2D.py:120-157 / DeformableAttention1D.py:60-102 is ONE function of the posdim signed-log offsets for every
+ * pair of a launch, so the caller evaluates the MLP once on a grid - `table` [H / G, points^posdim] fp32, point (i0, i1) at index
+ * i1 * points + i0 <-> p = -table_pmax + i * 2 table_pmax / (points - 1), points = smml_deform_attn_table_points(posdim) - and the
+ * kernels interpolate it (bi)linearly per pair (positions beyond +-table_pmax take the edge value).  The backward returns
+ * d table (the interpolation's adjoint: a histogram of d bias over the cells, fp32 atomics in LDS - the one order-dependent sum) in
+ * place of the six parameter gradients, which follow from it through the table's own small backward; dq / dk / dv / dvs as in
+ * smml_deform_attn16_bwd (fixed-order reductions).  grid_h, grid_w > 0 (posdim 2, grid_h * grid_w = N, both <= 128) assert that the
+ * queries sit on a regular grid - gq[y * grid_w + x] = (X[x], Y[y]), as the 2-D module's do: the weight of a pair then factorises over
+ * the axes and d table becomes two small dense products per key on the matrix pipe (no atomics: fixed-order sums); 0, 0 = any queries.
+ * An additive mode: values differ from the per-pair MLP by the interpolation error
+ * (tests/test_gpu_deform_table.py states the bounds); everything else - logits16 / dlogits16 layouts, dtype, dropout, events - as above. */
+int smml_deform_attn_table_points(int posdim);
+size_t smml_deform_attn_table_bwd_workspace_bytes(int B, int N, int J, int H, int posdim);
+int smml_deform_attn_table_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
+                               float* out, float* lse, unsigned short* logits16, int B, int N, int J, int H, int G, int posdim,
+                               int table_g, float table_pmax, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
+                               void* ev_start, void* ev_stop, void* stream);
+int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
+                               const float* out, const float* dout, const float* lse, const unsigned short* logits16,
+                               unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dtable, void* workspace,
+                               size_t workspace_bytes, int B, int N, int J, int H, int G, int posdim, int table_g, float table_pmax,
+                               int grid_h, int grid_w, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
+                               void* ev_start, void* ev_stop, void* stream);
 
 /* hipGraph support for attention dropout.  `dropout_seed` is a host value and is baked into a captured launch; to give every
  * replay its own mask, point the calling thread at a device-resident 64-bit offset first: the forward / backward / mask

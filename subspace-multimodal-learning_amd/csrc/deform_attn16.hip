@@ -100,13 +100,23 @@ __device__ __forceinline__ unsigned stash_keep16x2(unsigned w, unsigned two_bits
 // (double-buffered: one barrier per tile, the next tile's loads in flight during the key loop), the wave's scaled Q tile lives in
 // registers as four B fragments.
 // ------------------------------------------------------------------------------------------------
-template <int PD, bool SAVE, typename T>
+// Tabulated position bias (TG > 0; section "table mode" at the end of this file): the bias MLP is a function of the 2 (1) signed-log
+// offsets only - one function for every (bag, head of a group index, query, key) of a launch - so it is evaluated ONCE per launch on a
+// TG^PD grid over [-pmax, pmax]^PD (by the caller: three small GEMMs) and every pair interpolates it (bi)linearly from LDS.
+struct TabCfg {
+  const float* tab;        // [o][TG^PD] fp32, point (i0, i1) at index i1 * TG + i0 <-> p = -pmax + i * h
+  float invh, off, umax;   // u = p * invh + off (off = pmax * invh), clamped to [0, umax] (umax just below TG - 1)
+};
+template <int PD, int TG> constexpr int tab_cells() { return TG <= 0 ? 1 : (PD == 2 ? TG * TG : TG); }
+
+template <int PD, bool SAVE, typename T, int TG = 0>
 __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O, float* __restrict__ LSE, u16* __restrict__ LT,
-    u16* __restrict__ MK, int N, int J, int H, int G, int NST, float scale, DropCfg dc_in) {
+    u16* __restrict__ MK, int N, int J, int H, int G, int NST, float scale, DropCfg dc_in, TabCfg tc = TabCfg{}) {
   typedef typename Vec8<T>::type vec8;
   const DropCfg dc = drop_resolve(dc_in);
+  __shared__ float tabl[tab_cells<PD, TG>()];                          // table mode: this head's bias table
   __shared__ __attribute__((aligned(16))) T Kp[2][KT * FRLD];          // K tile, row image (A operand of S^T)
   __shared__ __attribute__((aligned(16))) T Vp[2][KT * FTLD];          // V tile, read transposed (A operand of O^T)
   __shared__ float vsl[2][KT][2];                                      // sample positions of the tile's keys
@@ -139,23 +149,31 @@ __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
   // 2 (W2 h1 + b2), and relu2 of that is 4 relu(.): b2 rides in doubled, w3 carries 1/4.
   float w3v[16];
   floatx16 b2acc, b1acc;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int oc = acc_row(s, hf);
-    b2acc[s] = 2.f * cp.b2[oc];
-    w3v[s] = 0.25f * cp.w3[oi * CH + oc];
-    b1acc[s] = cp.b1[oc];
-  }
-  const bf16x8 a1 = cpb_l1_weights_q(cp.w1[c * PD], (PD == 2) ? cp.w1[c * PD + 1] : 0.f, hf);
+  bf16x8 a1;
   vec8 w2t[2];                       // W2 as ONE T term: lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
+  float b3h = 0.f;
+  if constexpr (TG == 0) {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    float wv[8];
+    for (int s = 0; s < 16; ++s) {
+      const int oc = acc_row(s, hf);
+      b2acc[s] = 2.f * cp.b2[oc];
+      w3v[s] = 0.25f * cp.w3[oi * CH + oc];
+      b1acc[s] = cp.b1[oc];
+    }
+    a1 = cpb_l1_weights_q(cp.w1[c * PD], (PD == 2) ? cp.w1[c * PD + 1] : 0.f, hf);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
-    w2t[kb] = cvt8<T>(wv);
+    for (int kb = 0; kb < 2; ++kb) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
+      w2t[kb] = cvt8<T>(wv);
+    }
+    b3h = (hf == 0) ? cp.b3[oi] : 0.f;
+  } else {
+    constexpr int NC = tab_cells<PD, TG>();
+    const float* tsrc = tc.tab + (size_t)oi * NC;
+    for (int i = tid; i < NC; i += 256) tabl[i] = tsrc[i];         // visible after the first tile's barrier
   }
-  const float b3h = (hf == 0) ? cp.b3[oi] : 0.f;
 
   floatx16 oacc0 = {0}, oacc1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
@@ -244,14 +262,36 @@ __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
       ta += tb;
       biasT[wave][jj][c] = xhalf_sum(ta[0] + ta[1]);
     };
+    if constexpr (TG > 0) {
+      // table mode: the two lane halves take one key each (key jj + hf of the staged tile; a padded key computes on zero positions and
+      // is masked below), four (two) LDS reads and one (bi)linear interpolation per pair
+      for (int jj = 0; jj < nk; jj += 2) {
+        const int key = jj + hf;
+        const float u0 = __builtin_amdgcn_fmed3f(fmaf(slog1p(gq0 - vsl[buf][key][0]), tc.invh, tc.off), 0.f, tc.umax);
+        const float f0 = __builtin_amdgcn_fractf(u0);
+        if constexpr (PD == 2) {
+          const float u1 = __builtin_amdgcn_fmed3f(fmaf(slog1p(gq1 - vsl[buf][key][1]), tc.invh, tc.off), 0.f, tc.umax);
+          const float f1 = __builtin_amdgcn_fractf(u1);
+          const int idx = __mul24((int)u1, TG) + (int)u0;
+          const float t00 = tabl[idx], t10 = tabl[idx + 1], t01 = tabl[idx + TG], t11 = tabl[idx + TG + 1];
+          const float lo = fmaf(f0, t10 - t00, t00), hi = fmaf(f0, t11 - t01, t01);
+          biasT[wave][key][c] = fmaf(f1, hi - lo, lo);
+        } else {
+          const int idx = (int)u0;
+          const float t0 = tabl[idx], t1 = tabl[idx + 1];
+          biasT[wave][key][c] = fmaf(f0, t1 - t0, t0);
+        }
+      }
+    } else {
 #if SMML16_FWD_PAIR
-    for (int jj = 0; jj < nk; jj += 2) {
-      bias_chain(jj, true);
-      bias_chain(jj + 1, jj + 1 < nk);          // jj + 1 <= 31: inside the staged tile
-    }
+      for (int jj = 0; jj < nk; jj += 2) {
+        bias_chain(jj, true);
+        bias_chain(jj + 1, jj + 1 < nk);          // jj + 1 <= 31: inside the staged tile
+      }
 #else
-    for (int jj = 0; jj < nk; ++jj) bias_chain(jj, true);
+      for (int jj = 0; jj < nk; ++jj) bias_chain(jj, true);
 #endif
+    }
     wave_lds_fence();
 
     // bias add, key mask
@@ -920,6 +960,261 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     sl[i] = (r0[i] + r0[CPB_SLAB + i]) + (r0[2 * CPB_SLAB + i] + r0[3 * CPB_SLAB + i]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// table mode, backward of the position bias.  bias(q, key) = interp(table, slog(gq - vs)), so
+//   d table[cell] = sum over pairs of d bias . (interpolation weight of the cell)      - a histogram over the TG^PD cells, and
+//   d vs[key]     = - sum over queries of d bias . (d interp / d p) / (|d| + 1)
+// (the parameter gradients follow from d table through the three small GEMMs that built the table).  One LANE owns one KEY: it reads
+// its key's row of a 32-query tile of d scores (64 contiguous bytes; the wave's 64 rows are one 4 KB block), walks the 32 queries with
+// the query position in scalar registers, and keeps its d vs sum in registers - no cross-lane reduction anywhere.  The histogram lives
+// in LDS (fp32 atomic adds: the one order-dependent sum of this mode) and is flushed to a per-workgroup slab.
+// grid (nkb * S, H, B): key block kb = 64 keys, S query slices; the 8 waves of a workgroup take every 8th query tile of the slice.
+// ------------------------------------------------------------------------------------------------
+constexpr int TBW = 8;            // waves per workgroup of the table backward
+template <int PD, int TG, bool HIST = true>
+__global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
+    const u16* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, TabCfg tc, float* __restrict__ hist_slab,
+    float2* __restrict__ dvs_rows, int N, int J, int H, int G, int NST, int S, int tiles_per_slice) {
+  constexpr int NC = tab_cells<PD, TG>();
+  __shared__ float tabl[NC];
+  __shared__ float hist[HIST ? NC : 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y, kb = blockIdx.x / S, sl = blockIdx.x - kb * S;
+  const int o = H / G, g = h / o, oi = h - g * o;
+  {
+    const float* tsrc = tc.tab + (size_t)oi * NC;
+    for (int i = tid; i < NC; i += 64 * TBW) {
+      tabl[i] = tsrc[i];
+      if (HIST) hist[i] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int key = kb * 64 + lane;
+  const bool kvalid = key < J;
+  const int keyc = kvalid ? key : (J - 1);
+  const float* VSb = VS + ((size_t)(b * G + g) * J + keyc) * PD;
+  const float vs0 = VSb[0], vs1 = (PD == 2) ? VSb[1] : 0.f;
+  float acc0 = 0.f, acc1 = 0.f;
+  const int ntq = (N + 31) / 32;
+  const int t_end = min((sl + 1) * tiles_per_slice, ntq);
+  for (int t = sl * tiles_per_slice + wave; t < t_end; t += TBW) {
+    const int q0 = t * 32, nq = min(32, N - q0);
+    uint4v rw[4];
+    {
+      const uint4v* rp = reinterpret_cast<const uint4v*>(dLT + (((size_t)(b * H + h) * NST + q0) * J + (size_t)keyc * 32));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rw[i] = kvalid ? rp[i] : (uint4v){0u, 0u, 0u, 0u};
+    }
+    // the tile's query positions: one coalesced load (lane l holds float l of the tile's 32 x PD block), read back per query with
+    // v_readlane - no memory wait inside the query loop, and no branch: queries past the bag's end run on a clamped position with d bias = 0
+    const float gqv = GQ[min((size_t)q0 * PD + lane, (size_t)N * PD - 1)];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      {
+        const unsigned w = rw[i >> 3][(i >> 1) & 3];
+        const float db = (i < nq) ? ((i & 1) ? bf_hi(w) : bf_lo(w)) : 0.f;
+        const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gqv), i * PD)) - vs0;
+        const float a0 = fabsf(d0) + 1.0f;
+        const float u0r = fmaf(copysignf(__builtin_amdgcn_logf(a0) * 0.6931471805599453f, d0), tc.invh, tc.off);
+        const float u0 = __builtin_amdgcn_fmed3f(u0r, 0.f, tc.umax);
+        const float f0 = __builtin_amdgcn_fractf(u0);
+        if constexpr (PD == 2) {
+          const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gqv), i * PD + 1)) - vs1;
+          const float a1 = fabsf(d1) + 1.0f;
+          const float u1r = fmaf(copysignf(__builtin_amdgcn_logf(a1) * 0.6931471805599453f, d1), tc.invh, tc.off);
+          const float u1 = __builtin_amdgcn_fmed3f(u1r, 0.f, tc.umax);
+          const float f1 = __builtin_amdgcn_fractf(u1);
+          const int idx = __mul24((int)u1, TG) + (int)u0;
+          const float t00 = tabl[idx], t10 = tabl[idx + 1], t01 = tabl[idx + TG], t11 = tabl[idx + TG + 1];
+          // slopes of the bilinear patch (zero where the position was clamped to the table's edge)
+          const float gx0 = t10 - t00, gx1 = t11 - t01, gy0 = t01 - t00, gy1 = t11 - t10;
+          float sx = fmaf(f1, gx1 - gx0, gx0), sy = fmaf(f0, gy1 - gy0, gy0);
+          sx = (u0r == u0) ? sx : 0.f;
+          sy = (u1r == u1) ? sy : 0.f;
+          const float dbh = db * tc.invh;
+          acc0 = fmaf(-dbh * sx, srcp(a0), acc0);
+          acc1 = fmaf(-dbh * sy, srcp(a1), acc1);
+          if (HIST) {
+            const float w1x = db * f0, w0x = db - w1x;
+            const float h01 = w0x * f1, h11 = w1x * f1;
+            atomicAdd(&hist[idx], w0x - h01);
+            atomicAdd(&hist[idx + 1], w1x - h11);
+            atomicAdd(&hist[idx + TG], h01);
+            atomicAdd(&hist[idx + TG + 1], h11);
+          }
+        } else {
+          const int idx = (int)u0;
+          const float t0 = tabl[idx], t1 = tabl[idx + 1];
+          const float sx = (u0r == u0) ? (t1 - t0) : 0.f;
+          acc0 = fmaf(-db * tc.invh * sx, srcp(a0), acc0);
+          if (HIST) {
+            const float w1x = db * f0;
+            atomicAdd(&hist[idx], db - w1x);
+            atomicAdd(&hist[idx + 1], w1x);
+          }
+        }
+      }
+    }
+  }
+  if (kvalid) dvs_rows[((size_t)((b * H + h) * S + sl) * TBW + wave) * J + key] = make_float2(acc0, acc1);
+  if (HIST) {
+    __syncthreads();
+    float* slab = hist_slab + (size_t)((((size_t)b * H + h) * gridDim.x) + blockIdx.x) * NC;
+    for (int i = tid; i < NC; i += 64 * TBW) slab[i] = hist[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table mode, d table for queries on a REGULAR GRID (the 2-D module: query q = y * Ww + x sits at (X[x], Y[y])).  The bilinear weight
+// of a pair factorises, w(c1, c0) = hat(c1; u1(y, key)) . hat(c0; u0(x, key)) with hat(c; u) = clamp(1 - |u - c|, 0, 1), and u0 depends on
+// (x, key) only, u1 on (y, key) only, so the histogram of one key is a pair of small dense products on the matrix pipe,
+//      d table[c1][c0] += sum_x hat0[c0][x] . ( sum_y DB_key[y][x] . hat1[c1][y] ),
+// with DB_key the key's Hh x Ww sheet of d scores (bf16 as stored: exact operands) - no atomics anywhere (the LDS float atomics of
+// cpb_table_bwd_kernel run at ~0.3 lane-operations per clock and CU: 8.8 ms per launch at the headline shape; this form: see DESIGN.md).
+// The hat weights and the intermediate sheet are rounded to bf16 (8 bits; random-sign errors over >= 10^4 pairs per cell).
+// One workgroup = (bag, head, chunk of keys); wave w owns the c1 block [32 w, 32 w + 32) of the 96 x 96 table and keeps its 32 x 96
+// part of the sum in 48 accumulator registers across the chunk's keys; the second product takes the first one's accumulators as its
+// B operand directly (register r <-> row x = acc_row(r, half): the A fragments of hat0 are read in the same order).
+// Per key the workgroup stages the sheet (coalesced 16-byte pieces of the [J][32] tile rows) and the two hat tables in LDS.
+// Requires Hh, Ww <= 128 (LDS: the sheet is padded to 16-row / 32-column blocks); other shapes take cpb_table_bwd_kernel's atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int TGW = 3;                       // waves per workgroup = 32-wide c1 blocks of the 96-point table
+constexpr int HATLD = 128 + 8;               // halves per row of a hat table (272-byte rows)
+constexpr int TABLE_GRID_MAX = 128;          // largest grid side of the fast path
+constexpr int TABLE_GRID_KEYS = 32;          // keys per workgroup
+__host__ __device__ inline int table_sheet_halves(int Hh, int Ww) {     // LDS halves of one key's padded sheet
+  return (((Hh + 15) / 16) * 16 - 1) * Ww + ((Ww + 31) / 32) * 32 + 8;
+}
+template <int TG>
+__global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
+    const u16* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, TabCfg tc, float* __restrict__ hist_slab,
+    int N, int J, int H, int G, int NST, int Hh, int Ww) {
+  static_assert(TG == 32 * TGW, "one wave per 32 table rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  __bf16* dbs = reinterpret_cast<__bf16*>(dyn_lds);                    // the key's sheet, linear in q (zero beyond N)
+  __shared__ __attribute__((aligned(16))) __bf16 hat1[TG * HATLD];     // [c1][y]
+  __shared__ __attribute__((aligned(16))) __bf16 hat0[TG * HATLD];     // [c0][x]
+  __shared__ __attribute__((aligned(16))) float u0s[TABLE_GRID_MAX], u1s[TABLE_GRID_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int o = H / G, g = h / o;
+  const int k0 = blockIdx.x * TABLE_GRID_KEYS, k1 = min(k0 + TABLE_GRID_KEYS, J);
+  const int nxb = (Ww + 31) / 32, nsy = (Hh + 15) / 16;
+  const int sheet = table_sheet_halves(Hh, Ww);
+  const int nchunk = ((N + 31) / 32) * 4;            // 16-byte pieces of the tile rows that hold queries
+  for (int i = nchunk * 8 + tid; i < sheet; i += 64 * TGW) dbs[i] = (__bf16)0.f;     // never written again
+  floatx16 acc2[3] = {{0}, {0}, {0}};
+  const float* VSb = VS + (size_t)(b * G + g) * J * 2;
+  const u16* Lb = dLT + (size_t)(b * H + h) * NST * J;
+  for (int key = k0; key < k1; ++key) {
+    __syncthreads();                                 // the previous key's tables have been consumed
+    const float vs0 = VSb[(size_t)key * 2], vs1 = VSb[(size_t)key * 2 + 1];
+    for (int i = tid; i < 2 * TABLE_GRID_MAX; i += 64 * TGW) {
+      const int a = i & (TABLE_GRID_MAX - 1);
+      if (i < TABLE_GRID_MAX)          // x axis: query x of row 0
+        u0s[a] = (a < Ww) ? __builtin_amdgcn_fmed3f(fmaf(slog1p(GQ[(size_t)a * 2] - vs0), tc.invh, tc.off), 0.f, tc.umax) : -10.f;
+      else                             // y axis: first query of row y
+        u1s[a] = (a < Hh) ? __builtin_amdgcn_fmed3f(fmaf(slog1p(GQ[(size_t)a * Ww * 2 + 1] - vs1), tc.invh, tc.off), 0.f, tc.umax) : -10.f;
+    }
+    for (int ch = tid; ch < nchunk; ch += 64 * TGW) {
+      const int q = ch * 8;
+      uint4v w = *reinterpret_cast<const uint4v*>(Lb + ((size_t)(q >> 5) * 32 * J + (size_t)key * 32 + (q & 31)));
+      if (q + 8 > N) {                               // the bag's last tile: padded query lanes hold no d score
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (q + 2 * e >= N) w[e] = 0u;
+          else if (q + 2 * e + 1 >= N) w[e] &= 0xFFFFu;
+        }
+      }
+      *reinterpret_cast<uint4v*>(&dbs[q]) = w;
+    }
+    __syncthreads();
+    // hat tables: groups of 8 positions per table row
+    for (int gi = tid; gi < 2 * TG * (TABLE_GRID_MAX / 8); gi += 64 * TGW) {
+      const int which = gi / (TG * (TABLE_GRID_MAX / 8)), r = gi - which * (TG * (TABLE_GRID_MAX / 8));
+      const int row = r >> 4, p8 = (r & 15) * 8;
+      const float* us = which ? u0s : u1s;
+      const float4 ua = *reinterpret_cast<const float4*>(us + p8), ub = *reinterpret_cast<const float4*>(us + p8 + 4);
+      const float cf = (float)row;
+      const float hv[8] = {__builtin_amdgcn_fmed3f(1.f - fabsf(ua.x - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.y - cf), 0.f, 1.f),
+                           __builtin_amdgcn_fmed3f(1.f - fabsf(ua.z - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.w - cf), 0.f, 1.f),
+                           __builtin_amdgcn_fmed3f(1.f - fabsf(ub.x - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.y - cf), 0.f, 1.f),
+                           __builtin_amdgcn_fmed3f(1.f - fabsf(ub.z - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.w - cf), 0.f, 1.f)};
+      *reinterpret_cast<bf16x8*>(&(which ? hat0 : hat1)[row * HATLD + p8]) = cvt8<__bf16>(hv);
+    }
+    __syncthreads();
+    for (int xb = 0; xb < nxb; ++xb) {
+      floatx16 out1 = {0};
+      const __bf16* ap = dbs + (8 * hf) * Ww + 32 * xb + c;
+      const __bf16* bp = hat1 + (32 * wave + c) * HATLD + 8 * hf;
+      for (int st = 0; st < nsy; ++st) {
+        bf16x8 a1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a1[j] = ap[(16 * st + j) * Ww];
+        out1 = mfma16b(a1, *reinterpret_cast<const bf16x8*>(bp + 16 * st), out1);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = out1[8 * kb + j];
+        const bf16x8 b2 = cvt8<__bf16>(o8);
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+          const __bf16* hp = hat0 + (32 * cb + c) * HATLD + 32 * xb + 16 * kb + 4 * hf;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(hp), hi = *reinterpret_cast<const bf16x4*>(hp + 8);
+          const bf16x8 a2 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc2[cb] = mfma16b(a2, b2, acc2[cb]);
+        }
+      }
+    }
+  }
+  // this workgroup's partial table: lane <-> c1 = 32 wave + c, register r of block cb <-> c0 = 32 cb + acc_row(r, hf)
+  float* slab = hist_slab + (size_t)((((size_t)b * H + h) * gridDim.x) + blockIdx.x) * (TG * TG) + (size_t)(32 * wave + c) * TG;
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[32 * cb + acc_row(r, hf)] = acc2[cb][r];
+}
+
+// d vs[(b, g)][j] = sum over the heads of the group and the S * TBW rows of each, in that fixed order
+__global__ void dvs_table_reduce_kernel(const float2* __restrict__ rows, float* __restrict__ dVS, int Bn, int G, int H, int rows_per_head,
+                                        int J, int PD) {
+  const long long out = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (out >= (long long)Bn * G * J) return;
+  const int j = (int)(out % J);
+  const int bg = (int)(out / J), b = bg / G, g = bg - b * G, o = H / G;
+  float2 s = make_float2(0.f, 0.f);
+  for (int oi = 0; oi < o; ++oi) {
+    const float2* p = rows + (size_t)(b * H + g * o + oi) * rows_per_head * J + j;
+    for (int r = 0; r < rows_per_head; ++r) {
+      const float2 v = p[(size_t)r * J];
+      s.x += v.x; s.y += v.y;
+    }
+  }
+  dVS[out * PD] = s.x;
+  if (PD == 2) dVS[out * PD + 1] = s.y;
+}
+
+// d table[oi][cell] += sum over the workgroup slabs of heads h with h % o == oi (slabs ordered (b, h, block)); grid (cells / 256, chunks):
+// fixed order inside a chunk, one fp32 atomic per chunk into the zero-initialised output
+__global__ void table_hist_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dtab, int NC, int nwg, int wg_per_head,
+                                         int H, int o, int chunk) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= NC) return;
+  const int w0 = blockIdx.y * chunk, w1 = min(w0 + chunk, nwg);
+  float s0 = 0.f, s1 = 0.f;
+  for (int w = w0; w < w1; ++w) {
+    const int oi = ((w / wg_per_head) % H) % o;
+    const float v = slab[(size_t)w * NC + cell];
+    if (oi == 0) s0 += v; else s1 += v;
+  }
+  atomicAdd(&dtab[cell], s0);
+  if (o > 1) atomicAdd(&dtab[NC + cell], s1);
+}
+
 int check16(const char* fn, int B, int N, int J, int H, int G, int posdim, int dtype) {
   SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0 && G > 0, "%s: non-positive dimension", fn);
   SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
@@ -943,6 +1238,61 @@ void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float*
     hipLaunchKernelGGL((deform16_fwd_kernel<1, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else
     hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+}
+
+constexpr int TABLE_G2 = 96;      // grid points per axis of the 2-D table (36 KB in LDS: two forward workgroups per CU)
+constexpr int TABLE_G1 = 1024;    // points of the 1-D table
+
+template <typename T>
+void launch_fwd_table(dim3 grid, hipStream_t st, bool save, int posdim, const float* q, const float* k, const float* v, const float* vs,
+                      const float* gq, float* out, float* lse, u16* lt, int N, int J, int H, int G, int nst, float scale, DropCfg dc,
+                      TabCfg tc) {
+  dim3 block(256);
+  const CpbParams cp{};
+  u16* mk = nullptr;
+  if (posdim == 2 && save)
+    hipLaunchKernelGGL((deform16_fwd_kernel<2, true, T, TABLE_G2>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc, tc);
+  else if (posdim == 2)
+    hipLaunchKernelGGL((deform16_fwd_kernel<2, false, T, TABLE_G2>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc, tc);
+  else if (save)
+    hipLaunchKernelGGL((deform16_fwd_kernel<1, true, T, TABLE_G1>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc, tc);
+  else
+    hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T, TABLE_G1>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc, tc);
+}
+
+TabCfg make_tab(const float* table, int tg, float pmax) {
+  TabCfg tc;
+  tc.tab = table;
+  tc.invh = (float)((double)(tg - 1) / (2.0 * (double)pmax));
+  tc.off = (float)((double)pmax * (double)(tg - 1) / (2.0 * (double)pmax));
+  tc.umax = (float)(tg - 1) - 1.0f / 1024.0f;
+  return tc;
+}
+int table_slices(int B, int N, int J, int H) {
+  const int nkb = (J + 63) / 64, ntq = (N + 31) / 32;
+  const long base = (long)B * H * nkb;
+  long S = (1280 + base / 2) / base;
+  if (S > ntq / TBW) S = ntq / TBW;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+struct TableWorkspace { size_t rows, slab, total; };      // float offsets behind bwd_workspace(...).total
+TableWorkspace table_workspace(int B, int N, int J, int H, int cells) {
+  TableWorkspace w;
+  const size_t S = table_slices(B, N, J, H), nkb = (J + 63) / 64;
+  w.rows = (bwd_workspace(B, N, J, H).total + 3) & ~(size_t)3;
+  w.slab = w.rows + (size_t)B * H * S * TBW * J * 2;
+  size_t nslab = nkb * S;
+  const size_t kc = (J + TABLE_GRID_KEYS - 1) / TABLE_GRID_KEYS;        // the grid fast path's workgroups per (bag, head)
+  if (kc > nslab) nslab = kc;
+  w.total = w.slab + (size_t)B * H * nslab * cells;
+  return w;
+}
+int check_table(const char* fn, int posdim, int table_g, float pmax) {
+  SMML_REQUIRE(table_g == (posdim == 2 ? TABLE_G2 : TABLE_G1), "%s: the table kernels are built for %d grid points per axis with posdim %d (got %d)",
+               fn, posdim == 2 ? TABLE_G2 : TABLE_G1, posdim, table_g);
+  SMML_REQUIRE(pmax > 0.f, "%s: table_pmax must be positive", fn);
+  return SMML_OK;
 }
 
 }  // namespace
@@ -1045,6 +1395,121 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     hipLaunchKernelGGL(cpb_partial_kernel, dim3((CPB_SLAB + 63) / 64, nchunks), dim3(256), 0, st, slab, nwg, H / G, qtiles, H, chunk, wsf + wsl.partial);
     hipLaunchKernelGGL(cpb_final_kernel, dim3((CPB_SLAB + 255) / 256), dim3(256), 0, st, wsf + wsl.partial, nchunks, H / G, dw1, db1, dw2, db2, dw3, db3, posdim);
     SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/reduce");
+  }
+  return SMML_OK;
+}
+
+// ---- table mode (tabulated position bias): same contract as the two entry points above with `table` [o, table_g^posdim] in place of
+// the six MLP tensors and d table in place of their gradients
+int smml_deform_attn_table_points(int posdim) { return posdim == 2 ? TABLE_G2 : TABLE_G1; }
+
+size_t smml_deform_attn_table_bwd_workspace_bytes(int B, int N, int J, int H, int posdim) {
+  return table_workspace(B, N, J, H, posdim == 2 ? TABLE_G2 * TABLE_G2 : TABLE_G1).total * sizeof(float);
+}
+
+int smml_deform_attn_table_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
+                               float* out, float* lse, unsigned short* logits16, int B, int N, int J, int H, int G, int posdim,
+                               int table_g, float table_pmax, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
+                               void* ev_start, void* ev_stop, void* stream) {
+  int rc = check16("smml_deform_attn_table_fwd", B, N, J, H, G, posdim, dtype);
+  if (rc) return rc;
+  rc = check_table("smml_deform_attn_table_fwd", posdim, table_g, table_pmax);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_table_fwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && table && out && lse, "smml_deform_attn_table_fwd: null pointer");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const TabCfg tc = make_tab(table, table_g, table_pmax);
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B);
+  const int nst = smml_deform_attn_nst(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (dtype == 1) launch_fwd_table<_Float16>(grid, st, logits16 != nullptr, posdim, q, k, v, vs, gq, out, lse, logits16, N, J, H, G, nst, scale, dc, tc);
+  else launch_fwd_table<__bf16>(grid, st, logits16 != nullptr, posdim, q, k, v, vs, gq, out, lse, logits16, N, J, H, G, nst, scale, dc, tc);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK("smml_deform_attn_table_fwd");
+  return SMML_OK;
+}
+
+int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
+                               const float* out, const float* dout, const float* lse, const unsigned short* logits16,
+                               unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dtable, void* workspace,
+                               size_t workspace_bytes, int B, int N, int J, int H, int G, int posdim, int table_g, float table_pmax,
+                               int grid_h, int grid_w, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
+                               void* ev_start, void* ev_stop, void* stream) {
+  int rc = check16("smml_deform_attn_table_bwd", B, N, J, H, G, posdim, dtype);
+  if (rc) return rc;
+  rc = check_table("smml_deform_attn_table_bwd", posdim, table_g, table_pmax);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_table_bwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && table && out && dout && lse && logits16 && dlogits16 && dq && dk && dv && dvs && dtable && workspace,
+               "smml_deform_attn_table_bwd: null pointer");
+  const size_t need = smml_deform_attn_table_bwd_workspace_bytes(B, N, J, H, posdim);
+  SMML_REQUIRE(workspace_bytes >= need, "smml_deform_attn_table_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_deform_attn_table_bwd: workspace must be 16-byte aligned");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const TabCfg tc = make_tab(table, table_g, table_pmax);
+  hipStream_t st = (hipStream_t)stream;
+  const int nst = smml_deform_attn_nst(N);
+  const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
+  dim3 block(256);
+  const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
+  const int cells = posdim == 2 ? TABLE_G2 * TABLE_G2 : TABLE_G1;
+  const TableWorkspace tw = table_workspace(B, N, J, H, cells);
+  float* wsf = reinterpret_cast<float*>(workspace);
+  const int o = H / G;
+  (void)hipMemsetAsync(dtable, 0, (size_t)o * cells * sizeof(float), st);
+  // pass 1: d scores (bf16), dQ
+  if (dtype == 1)
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<_Float16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc);
+  else
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<__bf16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc);
+  SMML_LAUNCH_CHECK("smml_deform_attn_table_bwd/dq");
+  // pass 2: dK, dV
+  {
+    const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+    const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
+    const int nslices = parts * H * B;
+    const dim3 gk(((nslices + 7) / 8) * 8 * nkg);
+    hipLaunchKernelGGL(deform16_bwd_dkv_kernel, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    SMML_LAUNCH_CHECK("smml_deform_attn_table_bwd/dkv");
+    const size_t n4 = (size_t)B * J * H * DH / 4;
+    hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,
+                       reinterpret_cast<const float4*>(wsf + wsl.dkp), reinterpret_cast<const float4*>(wsf + wsl.dvp),
+                       reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts, scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn_table_bwd/dkv_reduce");
+  }
+  // pass 3: d table (histogram of d bias over the table cells) and d vs
+  {
+    const int S = table_slices(B, N, J, H), nkb = (J + 63) / 64, ntq = (N + 31) / 32, tps = (ntq + S - 1) / S;
+    float* slab = wsf + tw.slab;
+    float2* rows = reinterpret_cast<float2*>(wsf + tw.rows);
+    const dim3 gt(nkb * S, H, B), bt(64 * TBW);
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
+    // queries on a regular grid (grid_h x grid_w = N, both <= 128): d table on the matrix pipe, d vs from the per-pair kernel without its histogram
+    const bool on_grid = posdim == 2 && grid_h > 0 && grid_w > 0 && (long long)grid_h * grid_w == N && grid_h <= TABLE_GRID_MAX && grid_w <= TABLE_GRID_MAX;
+    int wg_per_head = nkb * S;
+    if (on_grid) {
+      hipLaunchKernelGGL((cpb_table_bwd_kernel<2, TABLE_G2, false>), gt, bt, 0, st, dlogits16, vs, gq, tc, slab, rows, N, J, H, G, nst, S, tps);
+      wg_per_head = (J + TABLE_GRID_KEYS - 1) / TABLE_GRID_KEYS;
+      const int need_h = max(table_sheet_halves(grid_h, grid_w), ((N + 31) / 32) * 32);
+      const size_t dyn = (((size_t)need_h * 2 + 15) / 16) * 16;
+      static size_t dyn_set = 0;
+      if (dyn > dyn_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_table_grid_bwd_kernel<TABLE_G2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        dyn_set = dyn;
+      }
+      hipLaunchKernelGGL((cpb_table_grid_bwd_kernel<TABLE_G2>), dim3(wg_per_head, H, B), dim3(64 * TGW), dyn, st, dlogits16, vs, gq, tc, slab, N, J, H, G, nst, grid_h, grid_w);
+    } else if (posdim == 2)
+      hipLaunchKernelGGL((cpb_table_bwd_kernel<2, TABLE_G2>), gt, bt, 0, st, dlogits16, vs, gq, tc, slab, rows, N, J, H, G, nst, S, tps);
+    else
+      hipLaunchKernelGGL((cpb_table_bwd_kernel<1, TABLE_G1>), gt, bt, 0, st, dlogits16, vs, gq, tc, slab, rows, N, J, H, G, nst, S, tps);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    SMML_LAUNCH_CHECK("smml_deform_attn_table_bwd/cpb");
+    const long long outs = (long long)B * G * J;
+    hipLaunchKernelGGL(dvs_table_reduce_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st, rows, dvs, B, G, H, S * TBW, J, posdim);
+    const int nwg = wg_per_head * H * B, nchunks = min(32, nwg), chunk = (nwg + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(table_hist_reduce_kernel, dim3((cells + 255) / 256, nchunks), dim3(256), 0, st, slab, dtable, cells, nwg, wg_per_head, H, o, chunk);
+    SMML_LAUNCH_CHECK("smml_deform_attn_table_bwd/reduce");
   }
   return SMML_OK;
 }

@@ -101,11 +101,15 @@ def _build_grid_queries_2d(Hh: int, Ww: int, device) -> torch.Tensor:
 class DeformCrossAttention2D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=4,
                  offset_groups=8, offset_kernel_size=6, group_queries=True, group_key_values=True,
-                 grid_hw: Optional[Tuple[int, int]] = None, consistent_grid_norm: bool = False, compute_dtype=None):
+                 grid_hw: Optional[Tuple[int, int]] = None, consistent_grid_norm: bool = False, compute_dtype=None,
+                 cpb_table: bool = False):
         super().__init__()
         self.consistent_grid_norm = bool(consistent_grid_norm)
         Fh._dtype16(compute_dtype)             # validates: None | 'bf16' | 'fp16'
         self.compute_dtype = compute_dtype     # additive: None = the fp32-grade path, else the 16-bit compute mode of the fused core
+        if cpb_table and compute_dtype is None:
+            raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
+        self.cpb_table = bool(cpb_table)       # additive: position bias from a table of the MLP (functional.deform_attention)
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -164,8 +168,17 @@ class DeformCrossAttention2D(nn.Module):
         gk = G if self.group_key_values else 1
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
+        tab = {}
+        if self.cpb_table:
+            # |gq|, |vs| are bounded by the grids' shapes and tanh . offset_scale (normalize_grid divides x by rows - 1, y by cols - 1)
+            th, tw = vgrid.shape[-2:]
+            lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
+            gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
+            vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
+            tab = {"cpb_table": True, "cpb_table_pmax": None if self.consistent_grid_norm else Fh.table_pmax(gqb, vsb),   # None: from the data
+                   "cpb_table_grid": (Hh, Ww)}                 # gq is a regular grid in both normalisations
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
-                                compute_dtype=self.compute_dtype, fork=fork, **_dropout_args(self, q.device))
+                                compute_dtype=self.compute_dtype, fork=fork, **tab, **_dropout_args(self, q.device))
         # the output projection follows the core's compute mode (single-term 16-bit operands, fp32 accumulation and storage)
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out
@@ -181,11 +194,14 @@ class DeformCrossAttention2D(nn.Module):
 class DeformCrossAttention1D(nn.Module):
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0., downsample_factor=4, offset_scale=None,
                  offset_groups=4, offset_kernel_size=6, cpb_log_distance=True, group_queries=False,
-                 group_key_values=False, true_1d_sampling: bool = False, compute_dtype=None):
+                 group_key_values=False, true_1d_sampling: bool = False, compute_dtype=None, cpb_table: bool = False):
         super().__init__()
         self.true_1d_sampling = bool(true_1d_sampling)
         Fh._dtype16(compute_dtype)
         self.compute_dtype = compute_dtype
+        if cpb_table and compute_dtype is None:
+            raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
+        self.cpb_table = bool(cpb_table)
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -232,8 +248,12 @@ class DeformCrossAttention1D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         seq = (2.0 * torch.arange(n, dtype=torch.float32, device=x1t.device) / max(n - 1, 1) - 1.0).view(n, 1)
+        tab = {}
+        if self.cpb_table:
+            t = vgrid.shape[-1]
+            tab = {"cpb_table": True, "cpb_table_pmax": Fh.table_pmax(1.0, 1.0 + 2.0 * self.offset_scale / max(t - 1, 1))}
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
-                                scale=self.scale, compute_dtype=self.compute_dtype, **_dropout_args(self, q.device))
+                                scale=self.scale, compute_dtype=self.compute_dtype, **tab, **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out
 

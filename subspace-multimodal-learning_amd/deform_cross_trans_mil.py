@@ -5,7 +5,8 @@ signatures, return tuples and parameter names.
 Additive knobs (reference defaults kept): `args.input_path_dim` (config/config_mine.yaml:25, default 1024)
 sizes `_fc1`; the token count is taken from the bag instead of the hard-wired 2500
 (DeformCrossTransMIL.py:104); `grid_hw` is forwarded to the 2-D attention; `args.deform_compute_dtype` (absent / None | 'bf16' |
-'fp16') selects the 16-bit compute mode of the fused attention core (BASELINE config 4).  `args.wrap_pad_to_square` (off by default;
+'fp16') selects the 16-bit compute mode of the fused attention core (BASELINE config 4), `args.deform_cpb_table` its table mode
+(the position-bias MLP evaluated on a grid once per call and interpolated per pair: include/smml.h).  `args.wrap_pad_to_square` (off by default;
 SURVEY.md 8(f) row 4) lets the 2-D branch take bags whose instance count is not a square: both token streams are
 wrap-padded to the next square as TransMIL does (models/mil.py:232-235), attended, and cropped back to N.
 
@@ -40,14 +41,14 @@ class FusionNet(nn.Module):
 
 
 class DeformCrossTransLayer(nn.Module):
-    def __init__(self, norm_layer=nn.LayerNorm, dim=128, grid_hw=None, compute_dtype=None):
+    def __init__(self, norm_layer=nn.LayerNorm, dim=128, grid_hw=None, compute_dtype=None, cpb_table=False):
         super().__init__()
         self.norm = norm_layer(dim)
         self.attn2d = DeformCrossAttention2D(dim=128, dim_head=64, heads=8, dropout=0.1, downsample_factor=4,
                                              offset_scale=4, offset_groups=8, offset_kernel_size=6, grid_hw=grid_hw,
-                                             compute_dtype=compute_dtype)
+                                             compute_dtype=compute_dtype, cpb_table=cpb_table)
         self.attn1d = DeformCrossAttention1D(dim=128, downsample_factor=4, offset_scale=2, offset_kernel_size=6,
-                                             compute_dtype=compute_dtype)
+                                             compute_dtype=compute_dtype, cpb_table=cpb_table)
 
     def forward(self, x1, x2, attn_dim, return_vgrid):
         n = self.norm
@@ -85,7 +86,9 @@ class DeformCrossTransMIL(nn.Module):
         self.args = args
         self.n_classes = n_classes
         # 'bf16' | 'fp16' runs the fused attention core and its output projection in the 16-bit compute mode
-        self.layer3 = DeformCrossTransLayer(dim=args.path_dim, grid_hw=getattr(args, "grid_hw", None), compute_dtype=cd)
+        # `args.deform_cpb_table` (absent / False; with a 16-bit compute dtype only): position bias from a table of the MLP
+        self.layer3 = DeformCrossTransLayer(dim=args.path_dim, grid_hw=getattr(args, "grid_hw", None), compute_dtype=cd,
+                                            cpb_table=bool(getattr(args, "deform_cpb_table", False)))
         self.norm = nn.LayerNorm(args.path_dim)
         self._fc2 = nn.Linear(args.path_dim, self.n_classes)
         self.pooler = Pooler(args.path_dim)

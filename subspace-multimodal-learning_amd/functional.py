@@ -949,6 +949,108 @@ class _DeformAttn(torch.autograd.Function):
         return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# table mode of the 16-bit core: the position-bias MLP evaluated once per call on a grid, interpolated per pair (include/smml.h)
+# ------------------------------------------------------------------------------------------------
+_TABLE_POINTS = {}
+
+
+def _table_points(points: int, posdim: int, pmax: float, device) -> torch.Tensor:
+    """[points^posdim, posdim] grid of signed-log offsets, point (i0, i1) in row i1 * points + i0 (a constant per (pmax, device))."""
+    key = (points, posdim, float(pmax), str(device))
+    g = _TABLE_POINTS.get(key)
+    if g is None:
+        ax = (-pmax + torch.arange(points, dtype=torch.float64) * (2.0 * pmax / (points - 1))).float()
+        if posdim == 2:
+            g = torch.stack((ax.view(1, points).expand(points, points), ax.view(points, 1).expand(points, points)), dim=-1).reshape(-1, 2)
+        else:
+            g = ax.view(points, 1)
+        if len(_TABLE_POINTS) > 16:
+            _TABLE_POINTS.clear()
+        g = _TABLE_POINTS[key] = g.contiguous().to(device)
+    return g
+
+
+def cpb_table_fn(w1, b1, w2, b2, w3, b3, *, posdim: int, pmax: float, device):
+    """The position-bias MLP (DeformableAttention2D.py:129-152 / DeformableAttention1D.py:69-98, already log-transformed input) on the
+    table grid: [heads // groups, points^posdim], fp32, three exact-fp32 GEMM launches; autograd carries d table back to the six tensors."""
+    points = capi.lib().smml_deform_attn_table_points(posdim)
+    pts = _table_points(points, posdim, pmax, device)
+    h = linear(pts, w1, b1, act=ACT_RELU)
+    h = linear(h, w2, b2, act=ACT_RELU)
+    t = linear(h, w3, b3)                                   # [cells, o]
+    return t.reshape(1, -1) if t.shape[1] == 1 else t.t().contiguous()
+
+
+class _DeformAttnTable(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, vs, gq, table, heads, groups, scale, dropout_p, dropout_seed, seed_offset, compute_dtype, fork, pmax, grid):
+        ctx.fork = fork
+        ctx.grid = tuple(int(x) for x in grid) if grid else (0, 0)
+        q, k, v, vs, gq, table = _c(q), _c(k), _c(v), _c(vs), _c(gq), _c(table)
+        B, N, HD = q.shape
+        J = k.shape[1]
+        posdim = vs.shape[-1]
+        if HD != heads * 64:
+            raise RuntimeError("the attention kernels are built for dim_head = 64")
+        L = capi.lib()
+        m16 = _dtype16(compute_dtype)
+        if m16 is None:
+            raise ValueError("the table mode belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
+        points = L.smml_deform_attn_table_points(posdim)
+        if tuple(table.shape) != (heads // groups, points ** posdim):
+            raise RuntimeError(f"table must be [{heads // groups}, {points ** posdim}] (got {tuple(table.shape)})")
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
+        logits = None
+        if any(ctx.needs_input_grad):
+            nst = L.smml_deform_attn_nst(N)
+            logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float16)
+        _set_seed_offset(L, seed_offset)
+        capi.check(L.smml_deform_attn_table_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table),
+                                                capi.fptr(out), capi.fptr(lse), capi.ptr(logits), B, N, J, heads, groups, posdim, points,
+                                                float(pmax), float(scale), float(dropout_p), int(dropout_seed), m16[0],
+                                                *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream()), "deform_attn_table_fwd")
+        _set_seed_offset(L, None)
+        ctx.seed_offset = seed_offset
+        ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16, points, float(pmax))
+        ctx.save_for_backward(q, k, v, vs, gq, table, out, lse, logits)
+        if DECISION_TAP is not None:       # no per-pair ReLU decisions in this mode: the MLP runs on grid points only
+            DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "masks2": None, "B": B, "N": N, "J": J,
+                                 "heads": heads, "groups": groups})
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, vs, gq, table, out, lse, logits = ctx.saved_tensors
+        heads, groups, scale, dropout_p, dropout_seed, m16, points, pmax = ctx.cfg
+        B, N, _ = q.shape
+        J = k.shape[1]
+        posdim = vs.shape[-1]
+        L = capi.lib()
+        dout = _c(dout)
+        dlogits = torch.empty(logits.shape, device=q.device, dtype=torch.bfloat16)
+        dq, dk, dv, dvs, dtable = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(vs), torch.empty_like(table)
+        wsb = L.smml_deform_attn_table_bwd_workspace_bytes(B, N, J, heads, posdim)
+        ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
+        _set_seed_offset(L, ctx.seed_offset)
+        capi.check(L.smml_deform_attn_table_bwd(
+            capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table), capi.fptr(out), capi.fptr(dout),
+            capi.fptr(lse), capi.ptr(logits), capi.ptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+            capi.fptr(dtable), capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, points, pmax, ctx.grid[0], ctx.grid[1], scale, dropout_p,
+            dropout_seed, m16[0],
+            *TIMER.events("cpb_table_bwd", B * heads * N * J), capi.stream()), "deform_attn_table_bwd")
+        _set_seed_offset(L, None)
+        if ctx.fork is not None and ctx.needs_input_grad[0]:
+            ctx.fork.dq = dq.view(B, N, -1)
+        return dq, dk, dv, dvs, None, dtable, None, None, None, None, None, None, None, None, None, None
+
+
+def table_pmax(gq_bound: float, vs_bound: float) -> float:
+    """Half-width of the table in signed-log units for |gq| <= gq_bound, |vs| <= vs_bound (positions beyond it take the edge value)."""
+    return float(__import__("math").log1p(gq_bound + vs_bound) * 1.0001)
+
+
 def _set_seed_offset(L, t):
     if t is None:
         L.smml_deform_attn_set_seed_offset(None)
@@ -982,12 +1084,24 @@ def graph_seed_offset(device, allocate_only: bool = False):
 
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
-                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None):
+                     dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None,
+                     cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
     compute_dtype None: fp32-grade split products (csrc/deform_attn.hip); 'bf16' / 'fp16': the 16-bit compute mode
-    (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32)."""
+    (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32).
+    cpb_table (with a 16-bit compute_dtype): the position-bias MLP is evaluated once on a grid and interpolated per pair (include/smml.h,
+    "table mode"); cpb_table_pmax = half-width of the grid in signed-log units (table_pmax(); None: taken from the data, one host sync);
+    cpb_table_grid = (rows, cols) asserts that the queries sit on a regular grid, gq[y * cols + x] = (X[x], Y[y]) - the backward then
+    builds d table on the matrix pipe instead of with LDS atomics."""
+    if cpb_table:
+        posdim = vs.shape[-1]
+        if cpb_table_pmax is None:
+            cpb_table_pmax = table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
+        table = cpb_table_fn(w1, b1, w2, b2, w3, b3, posdim=posdim, pmax=cpb_table_pmax, device=q.device)
+        return _DeformAttnTable.apply(q, k, v, vs, gq, table, heads, groups, scale, dropout_p, dropout_seed, dropout_seed_offset,
+                                      compute_dtype, fork, cpb_table_pmax, cpb_table_grid)
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
                              dropout_seed_offset, compute_dtype, fork)
 

@@ -1,9 +1,8 @@
 #!/bin/bash
-# trip 10: re-run of the tests fixed after trip 9, then the profiler passes of the default command (kernel stats + PMC) for profiles/r04_*
+# trip 10: table mode of the 16-bit core - parity tests and core timing
 set -u
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_data_parallel.py tests/test_gpu_attn16.py tests/test_gpu_deform16.py tests/test_bag_store.py tests/test_gpu_trainstep.py -q -m gpu > gpurun_out/r4_pytest_c.log 2>&1
-echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error" gpurun_out/r4_pytest_c.log | cut -c1-300 | tail -8
-cp gpurun_out/parity_report.tsv gpurun_out/r4_parity_report_c.tsv 2>/dev/null
-bash tests/gpu_bench_prof.sh > gpurun_out/r4_bench_prof.log 2>&1; echo "bench prof rc=$?"; tail -5 gpurun_out/r4_bench_prof.log | cut -c1-300
-timeout -k 10 300 python tests/bench_modules.py > gpurun_out/r4_modules_bench.txt 2>&1; echo "modules rc=$?"; grep -v amdgpu gpurun_out/r4_modules_bench.txt | tail -12
+timeout -k 10 600 python -m pytest tests/test_gpu_deform_table.py -q -m gpu -s > gpurun_out/r4_table_pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error|worst" gpurun_out/r4_table_pytest.log | cut -c1-600 | tail -12
+timeout -k 10 300 python tests/bench_deform_table.py > gpurun_out/r4_table_core.txt 2>&1
+echo "bench rc=$?"; cat gpurun_out/r4_table_core.txt | tail -8

@@ -1,16 +1,15 @@
 #!/bin/bash
-# trip 11: A/B of GradFork on both lines, then the complete GPU suite on the final code
 set -u
 mkdir -p gpurun_out
-for f in 1 0 1 0; do
-  SMML_GRAD_FORK=$f timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --no-nystrom > gpurun_out/r4_fork_$f.log 2>&1 || { echo "bench fork=$f rc=$?"; tail -3 gpurun_out/r4_fork_$f.log; continue; }
-  python - <<PY
-import json
-d=json.loads(open("gpurun_out/r4_fork_$f.log").read().strip().splitlines()[-1])
-print("fork=$f fp32 ms/step", round(d["ms_per_step"],3), "bags/s", round(d["value"],1), "| deform16 ms", round(d["deform16"]["ms_per_step"],3), "bags/s", round(d["deform16"]["bags_per_s"],1))
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+rm -rf gpurun_out/prof_table
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_table -- python3 tests/bench_deform_table.py > gpurun_out/r4_table_prof.log 2>&1
+echo "rc=$?"
+f=$(find gpurun_out/prof_table -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:16]:
+    print(f'{r["Name"][:90]:90s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:9.1f} us  total {float(r["TotalDurationNs"]) / 1e6:8.2f} ms')
 PY
-done
-timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/r4_pytest_full.log 2>&1
-echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error" gpurun_out/r4_pytest_full.log | cut -c1-300 | tail -8
-cp gpurun_out/parity_report.tsv gpurun_out/r4_parity_report_full.tsv 2>/dev/null
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2

@@ -1,17 +1,18 @@
 #!/bin/bash
-# trip 13: A/B of the late layer-1 gate (sign-mask AND, second layer-1 MFMA) in both position-bias backward kernels
+# trip 13: table mode - parity tests, core timing, default bench (with the deform16 and deform16_table legs)
 set -u
 mkdir -p gpurun_out
-V=$PWD/subspace-multimodal-learning_amd/lib/variants
-for name in base gl base gl; do
-  if [ "$name" = base ]; then unset SMML_LIB; else export SMML_LIB=$V/$name.so; fi
-  timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --no-nystrom > gpurun_out/r4_gl_$name.log 2>&1 || { echo "bench $name rc=$?"; tail -3 gpurun_out/r4_gl_$name.log; continue; }
-  python - <<PY
+timeout -k 10 900 python -m pytest tests/test_gpu_deform_table.py -q -m gpu -s > gpurun_out/r4_table_pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error|worst|deform table" gpurun_out/r4_table_pytest.log | cut -c1-900 | tail -12
+cp gpurun_out/parity_report.tsv gpurun_out/r4_parity_report_table.tsv 2>/dev/null
+timeout -k 10 300 python tests/bench_deform_table.py > gpurun_out/r4_table_core.txt 2>&1
+echo "core rc=$?"; tail -7 gpurun_out/r4_table_core.txt
+timeout -k 10 600 python bench.py --no-nystrom --no-cpu-baseline --no-traffic > gpurun_out/r4_bench_table.json 2> gpurun_out/r4_bench_table.err
+echo "bench rc=$?"; python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r4_gl_$name.log").read().strip().splitlines()[-1])
-print("$name fp32 ms/step", round(d["ms_per_step"],3), "bags/s", round(d["value"],1), "cpb", round(d["roofline"]["avg_ms"],3), "| deform16 ms", round(d["deform16"]["ms_per_step"],3), "bags/s", round(d["deform16"]["bags_per_s"],1), "cpb16", round(d["deform16"]["roofline"]["avg_ms"],3))
+d = json.loads(open("gpurun_out/r4_bench_table.json").read().strip().splitlines()[-1])
+print("fp32-grade", d["value"], d["ms_per_step"])
+for k in ("deform16", "deform16_table"):
+    x = d.get(k, {})
+    print(k, x.get("bags_per_s"), x.get("ms_per_step"), x.get("speedup_vs_fp32_line"), x.get("error"), {a: x[a]["avg_ms"] for a in ("deform_table_fwd", "cpb_table_bwd") if a in x})
 PY
-done
-export SMML_LIB=$V/gl.so
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_deform16.py -q -m gpu -k "fused_core or core16 or deform2d or masks" > gpurun_out/r4_gl_tests.log 2>&1
-echo "gl tests rc=$?"; grep -E "passed|failed|FAILED" gpurun_out/r4_gl_tests.log | tail -3

@@ -182,8 +182,11 @@ class Decisions:
         self.cells = (cx[:, 0].reshape(BG, J).long().cpu(), cy[:, 0].reshape(BG, J).long().cpu())     # (x0, y0) = floor of the pixel coordinates
         a = attn_entry
         B, N, G, H = a["B"], a["N"], a["groups"], a["heads"]
-        assert a["vs"].shape[0] == BG == B * G and a["J"] == J and a["masks2"] is not None
+        assert a["vs"].shape[0] == BG == B * G and a["J"] == J
         self.N = N
+        self.m1 = self.m2 = None
+        if a["masks2"] is None:           # table mode of the 16-bit core: the MLP runs on grid points only, no per-pair ReLU decisions
+            return
         self.m1 = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G).cpu()          # int16 [(B G), J, 2, nst]
         o = H // G                                                    # the heads of a group share layers 1 and 2: take the first
         self.m2 = Fh.relu_masks_rows(a["masks2"])[:, ::o].reshape(B * G, J, 2, -1).cpu()                    # int16 [(B G), J, 2, nst]
@@ -201,6 +204,8 @@ class Decisions:
         return out
 
     def relu_masks(self, i0, i1, device="cpu"):
+        if self.m2 is None:
+            return None
         return self.decode(self.m1, i0, i1, device), self.decode(self.m2, i0, i1, device)
 
 

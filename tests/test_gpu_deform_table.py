@@ -1,0 +1,312 @@
+"""GPU parity of the TABLE mode of the 16-bit fused deformable attention (csrc/deform_attn16.hip "table mode", include/smml.h
+smml_deform_attn_table_*): the continuous position bias CPB(slog(gq - vs)) of models/DeformableAttention2D.py:120-157 /
+DeformableAttention1D.py:60-102 is one function of the 2 (1) signed-log offsets for every pair of a launch; this mode evaluates the MLP
+once per call on a grid (96 x 96 points in 2-D, 1024 in 1-D: three exact-fp32 GEMMs) and interpolates it (bi)linearly per pair.  The
+backward is the exact adjoint of that interpolant: d table is a histogram of d bias over the grid cells and flows back to the six MLP
+tensors through the table's own three-GEMM backward.
+
+Two statements are tested, separately:
+ (A) the kernels compute the INTERPOLATED function and its adjoint correctly - against plain torch in fp64 evaluating the same
+     interpolant (fp64 table, same grid): tolerances of the 16-bit compute mode (tests/test_gpu_deform16.py) - forward bf16 1.5e-2 /
+     fp16 4e-3, gradients 3e-2 - and the six MLP gradients at the SAME 3e-2 (no per-pair 16-bit products in their path here, where the
+     MLP mode needs 6e-2 on small problems);
+ (B) how far the interpolant is from the per-pair MLP (the reference's function; fp64): forward values and the q / k / v gradients stay
+     within the SAME 16-bit bounds (the interpolation error of the bias, <= ~1e-3 of its range, is below the operand rounding).  The
+     gradients that pass through the interpolant's cells - d vs and the six MLP tensors - are the INTERPOLANT's own: exact for the function
+     the forward computed, but not the per-pair MLP's.  d bias / d parameter of the MLP is a step function across a ReLU kink, its
+     bilinear interpolation is wrong inside the cells a kink crosses, and d bias sums to zero per query (softmax), so the parameter
+     gradient is a heavily cancelled sum in which those cells' errors do not cancel: measured 0.10 ... 0.19 relative l2 distance on the
+     fuzz problems (d bias of random sign), falling only like sqrt(grid spacing) (0.125 at 96 points, 0.05 at 383 - not a
+     discretisation one can extrapolate away).  THIS MODE IS THEREFORE AN APPROXIMATION, not a parity claim: bound TABLE_MLP_TOL records it.
+No ReLU decision is exported or imposed in this mode: the MLP runs on grid points only."""
+import pytest
+import torch
+
+import helpers
+import oracle.deform as odeform
+from helpers import assert_close, decision_tap, l2_err, params_for, rel_err, smml, synth
+from oracle.deform import deform_cross_attention_1d, deform_cross_attention_2d
+from test_gpu_parity import _core_reference
+
+pytestmark = pytest.mark.gpu
+Fh = smml.functional
+
+FWD_TOL = {"bf16": 1.5e-2, "fp16": 4e-3}
+GRAD_TOL = 3e-2
+TABLE_MLP_TOL = 3e-1         # (B): relative l2 distance of the interpolant's position-path gradients (d vs, the six MLP tensors) from the per-pair MLP's
+
+
+def _interp_reference(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, keep, keep_scale, points, pmax):
+    """dropout(softmax(scale q k^T + interp(table, slog(gq - vs)))) v in plain torch: the table mode's contract."""
+    B, N, _ = q.shape
+    J, PD, o = k.shape[1], vs.shape[-1], heads // groups
+    ax = -pmax + torch.arange(points, dtype=q.dtype, device=q.device) * (2.0 * pmax / (points - 1))
+    if PD == 2:
+        pts = torch.stack((ax.view(1, -1).expand(points, points), ax.view(-1, 1).expand(points, points)), dim=-1).reshape(-1, 2)
+    else:
+        pts = ax.view(-1, 1)
+    table = (torch.relu(torch.relu(pts @ w1.T + b1) @ w2.T + b2) @ w3.T + b3).T          # [o, cells]
+    pos = gq[None, :, None, :] - vs.view(B * groups, 1, J, PD)
+    p = torch.sign(pos) * torch.log(pos.abs() + 1)
+    u = ((p + pmax) * ((points - 1) / (2.0 * pmax))).clamp(0.0, (points - 1) - 1.0 / 1024.0)
+    i = u.detach().floor().long()
+    f = u - i
+    if PD == 2:
+        idx = i[..., 1] * points + i[..., 0]
+        f0, f1 = f[..., 0], f[..., 1]
+        bias = []
+        for oi in range(o):
+            T = table[oi]
+            lo = T[idx] * (1 - f0) + T[idx + 1] * f0
+            hi = T[idx + points] * (1 - f0) + T[idx + points + 1] * f0
+            bias.append(lo * (1 - f1) + hi * f1)
+    else:
+        idx, f0 = i[..., 0], f[..., 0]
+        bias = [table[oi][idx] * (1 - f0) + table[oi][idx + 1] * f0 for oi in range(o)]
+    bias = torch.stack(bias, dim=-1).view(B, groups, N, J, o).permute(0, 1, 4, 2, 3).reshape(B, heads, N, J)
+    d = q.shape[-1] // heads
+    qh = q.view(B, N, heads, d).permute(0, 2, 1, 3) * scale
+    kh = k.view(B, J, heads, d).permute(0, 2, 1, 3)
+    vh = v.view(B, J, heads, d).permute(0, 2, 1, 3)
+    attn = torch.softmax(qh @ kh.transpose(-1, -2) + bias, dim=-1)
+    if keep is not None:
+        attn = attn * (keep.to(attn.dtype) * keep_scale)
+    return (attn @ vh).permute(0, 2, 1, 3).reshape(B, N, heads * d)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_table_core_random_shapes(cuda, mode):
+    """Forward + backward of the table-mode core on random ragged shapes (N, J off the tiles, one or two heads per group, 1-D and 2-D,
+    with and without dropout) against (A) the fp64 interpolant and (B) the fp64 per-pair MLP."""
+    gen = torch.Generator().manual_seed(2468)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    forced = [(1, 1, 65, 8, 1, 0.0), (2, 33, 5, 4, 2, 0.25), (1, 129, 33, 8, 2, 0.0), (1, 300, 1, 8, 2, 0.0), (2, 290, 130, 8, 2, 0.0)]
+    nrand = 8
+    worst = {}
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    for case in range(nrand + len(forced)):
+        B, N, J = ri(1, 3), ri(1, 300), ri(2, 90)
+        groups = (4, 8)[ri(0, 1)]
+        heads, PD, p_drop = 8, ri(1, 2), (0.0, 0.25)[ri(0, 1)]
+        if case >= nrand:
+            B, N, J, groups, PD, p_drop = forced[case - nrand]
+        rn = lambda *s: torch.randn(*s, generator=gen)
+        t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+                 gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+                 w3=rn(heads // groups, 32) * 0.3, b3=rn(heads // groups) * 0.1)
+        wo = rn(B, N, 512)
+        dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+        seed = 270 + case
+        pmax = Fh.table_pmax(1.0, 1.2)
+        out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=p_drop, dropout_seed=seed,
+                                  compute_dtype=mode, cpb_table=True, cpb_table_pmax=pmax)
+        (out * wo.to(cuda)).sum().backward()
+        keep = Fh.deform_attention_dropout_mask(B, N, J, heads, p_drop, seed, cuda) if p_drop else None
+        points = smml._capi.lib().smml_deform_attn_table_points(PD)
+        tag = f"table {mode} case {case}: B={B} N={N} J={J} G={groups} PD={PD} p={p_drop}"
+        for which in ("A", "B"):
+            r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+            if which == "A":
+                o = _interp_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / (1.0 - p_drop), points, pmax)
+            else:
+                o = _core_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / (1.0 - p_drop))
+            (o * wo.to(cuda, torch.float64)).sum().backward()
+            e = rel_err(out, o); worst[which + " out"] = max(worst.get(which + " out", 0.0), e)
+            assert_close(f"{tag} ({which}) out", out, o, FWD_TOL[mode])
+            for n in t:
+                if n in ("gq", "b3"):
+                    continue
+                g, g64 = dev[n].grad, r[n].grad
+                if float(g64.abs().max()) < 1e-9:           # identically zero in exact arithmetic (one key: dS = 0)
+                    assert float(g.abs().max()) < 5e-2, f"{tag} d{n}: expected ~0, got {float(g.abs().max()):.3e}"
+                    continue
+                position_path = n in ("vs", "w1", "b1", "w2", "b2", "w3")           # gradients that pass through the interpolant's slopes / cells
+                if which == "B" and position_path:
+                    if N * J < 2000:
+                        continue                 # a handful of pairs: the slope of ONE cell against the MLP's (see the docstring)
+                    e = l2_err(g, g64); worst[f"B d{n} (l2)"] = max(worst.get(f"B d{n} (l2)", 0.0), e)
+                    assert e < TABLE_MLP_TOL, f"{tag} (B) d{n}: relative l2 error {e:.3e} > {TABLE_MLP_TOL}"
+                    continue
+                e = rel_err(g, g64); worst[f"{which} d{n}"] = max(worst.get(f"{which} d{n}", 0.0), e)
+                assert_close(f"{tag} ({which}) d{n}", g, g64, GRAD_TOL)
+    print(f"\n[deform table {mode}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
+
+
+@pytest.mark.parametrize("shape", [(20, 20), (7, 33), (16, 32), (100, 3), (1, 50), (37, 128)])
+def test_table_core_grid_queries(cuda, shape):
+    """Queries on a regular grid (cpb_table_grid): d table comes from the two dense products per key on the matrix pipe instead of the
+    LDS atomics - against (A) the fp64 interpolant, and against the atomics path of the same launch (every other output is bit-identical:
+    the two paths share all other kernels)."""
+    Hh, Ww = shape
+    gen = torch.Generator().manual_seed(97 + Hh * 131 + Ww)
+    B, N, J, heads, groups, PD = 2, Hh * Ww, 45, 8, 8, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    X = torch.sort(torch.rand(Ww, generator=gen) * 2 - 1).values
+    Y = torch.sort(torch.rand(Hh, generator=gen) * 2 - 1).values
+    gq = torch.stack((X.view(1, Ww).expand(Hh, Ww), Y.view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(N, 2).contiguous()
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=gq, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2, w3=rn(1, 32) * 0.3, b3=rn(1) * 0.1)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    wo = rn(B, N, 512)
+    pmax = Fh.table_pmax(1.0, 1.2)
+    grads = {}
+    for label, grid in (("grid", (Hh, Ww)), ("atomics", None)):
+        dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+        out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=0.2, dropout_seed=11,
+                                  compute_dtype="bf16", cpb_table=True, cpb_table_pmax=pmax, cpb_table_grid=grid)
+        (out * wo.to(cuda)).sum().backward()
+        grads[label] = (out.detach(), {n: dev[n].grad for n in names if n not in ("gq", "b3")})
+    keep = Fh.deform_attention_dropout_mask(B, N, J, heads, 0.2, 11, cuda)
+    r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+    o = _interp_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / 0.8, 96, pmax)
+    (o * wo.to(cuda, torch.float64)).sum().backward()
+    tag = f"table grid {Hh}x{Ww}"
+    assert torch.equal(grads["grid"][0], grads["atomics"][0])
+    for n in ("q", "k", "v", "vs"):
+        assert torch.equal(grads["grid"][1][n], grads["atomics"][1][n]), f"{tag}: d{n} differs between the two d-table paths"
+    assert_close(tag + " out", grads["grid"][0], o, FWD_TOL["bf16"])
+    for n, g in grads["grid"][1].items():
+        assert_close(f"{tag} (A) d{n}", g, r[n].grad, GRAD_TOL)
+        if n in ("w1", "b1", "w2", "b2", "w3"):
+            assert_close(f"{tag} d{n} grid vs atomics", g, grads["atomics"][1][n], GRAD_TOL)     # bf16 hat weights / intermediate sheet vs fp32 atomics (measured <= 1.8e-2)
+
+
+def test_table_core_full_size_grid(cuda):
+    """BASELINE's headline shape for one bag - 100 x 100 query grid, 625 keys, 8 heads, dropout 0.1 - through the grid fast path against
+    (A) the fp64 interpolant (asserted, tolerances of the 16-bit mode) and (B) the fp64 per-pair MLP (forward / dq / dk / dv asserted; the
+    position-path gradients recorded: the interpolant's own, see the module docstring)."""
+    gen = torch.Generator().manual_seed(1234)
+    Hh = Ww = 100
+    B, N, J, heads, groups, PD = 1, Hh * Ww, 625, 8, 8, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    ax = lambda n, den: 2.0 * torch.arange(n, dtype=torch.float32) / den - 1.0
+    gq = torch.stack((ax(Ww, Hh - 1).view(1, Ww).expand(Hh, Ww), ax(Hh, Ww - 1).view(Hh, 1).expand(Hh, Ww)), dim=-1).reshape(N, 2).contiguous()
+    lin = lambda o, i: (torch.rand(o, i, generator=gen) * 2 - 1) / i ** 0.5          # nn.Linear's default initialisation range
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.6 - 1.3,
+             gq=gq, w1=lin(32, PD), b1=lin(32, PD)[:, 0].contiguous(), w2=lin(32, 32), b2=lin(32, 32)[:, 0].contiguous(), w3=lin(1, 32),
+             b3=lin(1, 32)[:, 0].contiguous())
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    wo = rn(B, N, 512)
+    pmax = Fh.table_pmax(1.0, 1.3)
+    dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+    out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=0.1, dropout_seed=77,
+                              compute_dtype="bf16", cpb_table=True, cpb_table_pmax=pmax, cpb_table_grid=(Hh, Ww))
+    (out * wo.to(cuda)).sum().backward()
+    keep = Fh.deform_attention_dropout_mask(B, N, J, heads, 0.1, 77, cuda)
+    rec = {}
+    for which in ("A", "B"):
+        r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+        if which == "A":
+            o = _interp_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / 0.9, 96, pmax)
+        else:
+            o = _core_reference(*(r[n] for n in names), heads, groups, 0.125, keep, 1.0 / 0.9)
+        (o * wo.to(cuda, torch.float64)).sum().backward()
+        assert_close(f"table full size ({which}) out", out, o, FWD_TOL["bf16"])
+        rec[which + " out"] = rel_err(out, o)
+        for n in ("q", "k", "v", "vs", "w1", "b1", "w2", "b2", "w3"):
+            g, g64 = dev[n].grad, r[n].grad
+            rec[f"{which} d{n}"] = rel_err(g, g64)
+            if which == "A" or n in ("q", "k", "v"):
+                assert_close(f"table full size ({which}) d{n}", g, g64, GRAD_TOL)
+            else:
+                rec[f"B d{n} (l2)"] = l2_err(g, g64)
+                assert rec[f"B d{n} (l2)"] < TABLE_MLP_TOL
+        del r, o
+    print("\n[deform table, 1 x 10 000 x 625 x 8] " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(rec.items())))
+
+
+def test_table_core_positions_beyond_the_table(cuda):
+    """Positions outside +-pmax take the table's edge value and pass no gradient to vs (the interpolant is flat there): a deliberately
+    narrow table against the same interpolant in fp64."""
+    gen = torch.Generator().manual_seed(5)
+    B, N, J, heads, groups, PD = 1, 70, 40, 8, 8, 2
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    t = dict(q=rn(B, N, 512) * 0.4, k=rn(B, J, 512) * 0.4, v=rn(B, J, 512), vs=torch.rand(B * groups, J, PD, generator=gen) * 2.4 - 1.2,
+             gq=torch.rand(N, PD, generator=gen) * 2 - 1, w1=rn(32, PD) * 0.7, b1=rn(32) * 0.3, w2=rn(32, 32) * 0.25, b2=rn(32) * 0.2,
+             w3=rn(1, 32) * 0.3, b3=rn(1) * 0.1)
+    names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
+    wo = rn(B, N, 512)
+    pmax = 0.6                     # slog offsets reach ~1.16 here: a third of the pairs are clamped on at least one axis
+    dev = {n: x.to(cuda).requires_grad_() for n, x in t.items()}
+    out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, compute_dtype="fp16", cpb_table=True,
+                              cpb_table_pmax=pmax)
+    (out * wo.to(cuda)).sum().backward()
+    r = {n: x.to(cuda, torch.float64).requires_grad_() for n, x in t.items()}
+    o = _interp_reference(*(r[n] for n in names), heads, groups, 0.125, None, 1.0, 96, pmax)
+    (o * wo.to(cuda, torch.float64)).sum().backward()
+    assert_close("clamped table out", out, o, FWD_TOL["fp16"])
+    for n in ("q", "k", "v", "vs", "w1", "b1", "w2", "b2", "w3"):
+        assert_close("clamped table d" + n, dev[n].grad, r[n].grad, GRAD_TOL)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("train", [False, True])
+def test_deform2d_table_vs_oracle(cuda, mode, train):
+    """DeformCrossAttention2D(compute_dtype=..., cpb_table=True) on a 20 x 20 grid against the fp64 oracle (the per-pair MLP; the sampler's
+    cells imposed as everywhere, no ReLU decisions): the module-level statement (B)."""
+    B, Hh, Ww, C = 2, 20, 20, 128
+    N = Hh * Ww
+    tag = f"d2dtab:{mode}:{int(train)}"
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww), compute_dtype=mode, cpb_table=True)
+    params = params_for(mod, 31, tag)
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).train(train)
+    x1 = synth.normal((B, C, N), 31, tag + ":x1"); x2 = synth.normal((B, C, N), 31, tag + ":x2")
+    w_out = synth.normal((B, C, N), 31, tag + ":wo")
+    torch.manual_seed(99)
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o, vg = mod(ad, bd, return_vgrid=True)
+    (o * w_out.to(cuda)).sum().backward()
+    J = vg.shape[-1] * vg.shape[-2]
+    keep = Fh.deform_attention_dropout_mask(B, N, J, 8, 0.1, mod.last_dropout_seed, cuda).cpu() if train else None
+    dt = torch.float64
+    pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+    a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+    odeform.DECISIONS = tap.decisions()
+    kw = dict(attn_keep=keep, dropout_p=0.1) if train else {}
+    o_ref, vg_ref = deform_cross_attention_2d(a, b, pref, grid_hw=(Hh, Ww), **kw)
+    (o_ref * w_out.to(dt)).sum().backward()
+    assert_close(tag + " vgrid", vg, vg_ref, 1e-5)
+    assert_close(tag + " out", o, o_ref, FWD_TOL[mode])
+    assert_close(tag + " dx1", ad.grad, a.grad, GRAD_TOL)
+    assert_close(tag + " dx2", bd.grad, b.grad, GRAD_TOL)
+    for k, p in mod.named_parameters():
+        if k.endswith("rel_pos_bias.mlp.2.bias"):           # zero in exact arithmetic (softmax shift invariance)
+            continue
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, TABLE_MLP_TOL if "rel_pos_bias" in k else GRAD_TOL)
+
+
+@pytest.mark.parametrize("mode", ["bf16"])
+def test_deform1d_table_vs_oracle(cuda, mode):
+    """DeformCrossAttention1D(compute_dtype=..., cpb_table=True): two heads per offset group (two table rows), 1-D positions."""
+    B, n, C = 2, 120, 128
+    tag = f"d1dtab:{mode}"
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, compute_dtype=mode, cpb_table=True)
+    params = params_for(mod, 37, tag)
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).eval()
+    x1 = synth.normal((B, C, n), 37, tag + ":x1"); x2 = synth.normal((B, C, n), 37, tag + ":x2")
+    w_out = synth.normal((B, C, n), 37, tag + ":wo")
+    ad, bd = x1.to(cuda).requires_grad_(), x2.to(cuda).requires_grad_()
+    with decision_tap() as tap:
+        o = mod(ad, bd)
+    (o * w_out.to(cuda)).sum().backward()
+    dt = torch.float64
+    pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+    a, b = x1.clone().to(dt).requires_grad_(), x2.clone().to(dt).requires_grad_()
+    odeform.DECISIONS = tap.decisions()
+    o_ref, _ = deform_cross_attention_1d(a, b, pref, downsample_factor=4, offset_scale=2, offset_kernel_size=6)
+    (o_ref * w_out.to(dt)).sum().backward()
+    assert_close(tag + " out", o, o_ref, FWD_TOL[mode])
+    assert_close(tag + " dx1", ad.grad, a.grad, GRAD_TOL)
+    assert_close(tag + " dx2", bd.grad, b.grad, GRAD_TOL)
+    for k, p in mod.named_parameters():
+        if k.endswith("rel_pos_bias.mlp.2.bias") or pref[k].grad is None:
+            continue
+        assert_close(tag + " d" + k, p.grad, pref[k].grad, TABLE_MLP_TOL if "rel_pos_bias" in k else GRAD_TOL)
+
+
+def test_table_mode_needs_a_16bit_dtype():
+    with pytest.raises(ValueError):
+        smml.DeformCrossAttention2D(dim=128, cpb_table=True)
