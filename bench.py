@@ -295,6 +295,8 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deform-table", action="store_true", help="measurement switch (with --deform-dtype): the headline step with the tabulated position "
+                    "bias (approximate mode; the default run reports it in the extra key `deform16_table`)")
     ap.add_argument("--no-deform16", action="store_true", help="skip the 16-bit-compute-mode leg of the headline step (extra key `deform16`, not part of `value`)")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
@@ -332,7 +334,9 @@ def main():
     J = pkg.lib().smml_offsets_out_len(S, 6, 4) ** 2
 
     torch.manual_seed(42)
-    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, a.deform_dtype))
+    if a.deform_table and not a.deform_dtype:
+        raise SystemExit("--deform-table needs --deform-dtype bf16|fp16")
+    mil = pkg.DeformCrossTransMIL(mil_args(in_dim, a.deform_dtype, a.deform_table))
     mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
     mil = mil.to(dev).train()              # train mode: attention dropout 0.1 (DeformCrossTransMIL.py:49) is active
     model = pkg.BagDataParallel(mil) if world > 1 else mil
@@ -397,7 +401,8 @@ def main():
 
     kt = Fh.TIMER.collect()
     if a.deform_dtype:                      # measurement switch: the 16-bit kernels report under the same two roofline keys
-        kt = {{"deform16_fwd": "deform_attn_fwd", "cpb16_bwd": "cpb_bwd"}.get(k, k): v for k, v in kt.items()}
+        kt = {{"deform16_fwd": "deform_attn_fwd", "cpb16_bwd": "cpb_bwd", "deform_table_fwd": "deform_attn_fwd", "cpb_table_bwd": "cpb_bwd"}.get(k, k): v
+              for k, v in kt.items()}
     dp_info = None
     if world > 1:
         # self-check of a multi-GPU run: the world size the collective backend reports, every rank's device, and the data-parallel

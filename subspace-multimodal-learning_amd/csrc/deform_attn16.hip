@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
     if constexpr (TG > 0) {
       // table mode: the two lane halves take one key each (key jj + hf of the staged tile; a padded key computes on zero positions and
       // is masked below), four (two) LDS reads and one (bi)linear interpolation per pair
+#pragma unroll 4
       for (int jj = 0; jj < nk; jj += 2) {
         const int key = jj + hf;
         const float u0 = __builtin_amdgcn_fmed3f(fmaf(slog1p(gq0 - vsl[buf][key][0]), tc.invh, tc.off), 0.f, tc.umax);
@@ -1069,28 +1070,29 @@ __global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
 // table mode, d table for queries on a REGULAR GRID (the 2-D module: query q = y * Ww + x sits at (X[x], Y[y])).  The bilinear weight
 // of a pair factorises, w(c1, c0) = hat(c1; u1(y, key)) . hat(c0; u0(x, key)) with hat(c; u) = clamp(1 - |u - c|, 0, 1), and u0 depends on
 // (x, key) only, u1 on (y, key) only, so the histogram of one key is a pair of small dense products on the matrix pipe,
-//      d table[c1][c0] += sum_x hat0[c0][x] . ( sum_y DB_key[y][x] . hat1[c1][y] ),
+//      d table[c1][c0] += sum_y hat1[c1][y] . ( sum_x DB_key[y][x] . hat0[c0][x] ),
 // with DB_key the key's Hh x Ww sheet of d scores (bf16 as stored: exact operands) - no atomics anywhere (the LDS float atomics of
 // cpb_table_bwd_kernel run at ~0.3 lane-operations per clock and CU: 8.8 ms per launch at the headline shape; this form: see DESIGN.md).
 // The hat weights and the intermediate sheet are rounded to bf16 (8 bits; random-sign errors over >= 10^4 pairs per cell).
-// One workgroup = (bag, head, chunk of keys); wave w owns the c1 block [32 w, 32 w + 32) of the 96 x 96 table and keeps its 32 x 96
+// One workgroup = (bag, head, chunk of keys); wave w owns the c0 block [32 w, 32 w + 32) of the 96 x 96 table and keeps its 96 x 32
 // part of the sum in 48 accumulator registers across the chunk's keys; the second product takes the first one's accumulators as its
-// B operand directly (register r <-> row x = acc_row(r, half): the A fragments of hat0 are read in the same order).
-// Per key the workgroup stages the sheet (coalesced 16-byte pieces of the [J][32] tile rows) and the two hat tables in LDS.
-// Requires Hh, Ww <= 128 (LDS: the sheet is padded to 16-row / 32-column blocks); other shapes take cpb_table_bwd_kernel's atomics.
+// B operand directly (register r <-> row y = acc_row(r, half): the A fragments of hat1 are read in the same order).
+// Per key the workgroup stages the sheet (coalesced 16-byte pieces of the [J][32] tile rows; linear in q, so a row's 8 consecutive x
+// of an A fragment are two 8-byte LDS reads when Ww % 4 == 0, eight 2-byte reads otherwise) and the two hat tables in LDS.
+// Requires Hh, Ww <= 128 (LDS: the sheet is padded to 32-row / 16-column blocks); other shapes take cpb_table_bwd_kernel's atomics.
 // ------------------------------------------------------------------------------------------------
-constexpr int TGW = 3;                       // waves per workgroup = 32-wide c1 blocks of the 96-point table
+constexpr int TGW = 3;                       // waves per workgroup = 32-wide c0 blocks of the 96-point table
 constexpr int HATLD = 128 + 8;               // halves per row of a hat table (272-byte rows)
 constexpr int TABLE_GRID_MAX = 128;          // largest grid side of the fast path
 constexpr int TABLE_GRID_KEYS = 32;          // keys per workgroup
 __host__ __device__ inline int table_sheet_halves(int Hh, int Ww) {     // LDS halves of one key's padded sheet
-  return (((Hh + 15) / 16) * 16 - 1) * Ww + ((Ww + 31) / 32) * 32 + 8;
+  return (((Hh + 31) / 32) * 32 - 1) * Ww + ((Ww + 15) / 16) * 16 + 8;
 }
-template <int TG>
+template <int TG, bool ALIGNED>
 __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
     const u16* __restrict__ dLT, const float* __restrict__ VS, const float* __restrict__ GQ, TabCfg tc, float* __restrict__ hist_slab,
     int N, int J, int H, int G, int NST, int Hh, int Ww) {
-  static_assert(TG == 32 * TGW, "one wave per 32 table rows");
+  static_assert(TG == 32 * TGW, "one wave per 32 table columns");
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   __bf16* dbs = reinterpret_cast<__bf16*>(dyn_lds);                    // the key's sheet, linear in q (zero beyond N)
   __shared__ __attribute__((aligned(16))) __bf16 hat1[TG * HATLD];     // [c1][y]
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
   const int b = blockIdx.z, h = blockIdx.y;
   const int o = H / G, g = h / o;
   const int k0 = blockIdx.x * TABLE_GRID_KEYS, k1 = min(k0 + TABLE_GRID_KEYS, J);
-  const int nxb = (Ww + 31) / 32, nsy = (Hh + 15) / 16;
+  const int nyb = (Hh + 31) / 32, nsx = (Ww + 15) / 16;
   const int sheet = table_sheet_halves(Hh, Ww);
   const int nchunk = ((N + 31) / 32) * 4;            // 16-byte pieces of the tile rows that hold queries
   for (int i = nchunk * 8 + tid; i < sheet; i += 64 * TGW) dbs[i] = (__bf16)0.f;     // never written again
@@ -1145,16 +1147,23 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
       *reinterpret_cast<bf16x8*>(&(which ? hat0 : hat1)[row * HATLD + p8]) = cvt8<__bf16>(hv);
     }
     __syncthreads();
-    for (int xb = 0; xb < nxb; ++xb) {
+    for (int yb = 0; yb < nyb; ++yb) {
+      // first product: out1[y][c0] = sum_x DB[y][x] hat0[c0][x] for the 32 rows y of block yb (lane = y) and this wave's 32 columns c0
       floatx16 out1 = {0};
-      const __bf16* ap = dbs + (8 * hf) * Ww + 32 * xb + c;
-      const __bf16* bp = hat1 + (32 * wave + c) * HATLD + 8 * hf;
-      for (int st = 0; st < nsy; ++st) {
+      const __bf16* ap = dbs + (32 * yb + c) * Ww + 8 * hf;
+      const __bf16* bp = hat0 + (32 * wave + c) * HATLD + 8 * hf;
+      for (int st = 0; st < nsx; ++st) {
         bf16x8 a1;
+        if (ALIGNED) {                               // Ww % 4 == 0: every row starts on an 8-byte boundary
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ap + 16 * st), hi = *reinterpret_cast<const bf16x4*>(ap + 16 * st + 4);
+          a1 = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a1[j] = ap[(16 * st + j) * Ww];
+          for (int j = 0; j < 8; ++j) a1[j] = ap[16 * st + j];
+        }
         out1 = mfma16b(a1, *reinterpret_cast<const bf16x8*>(bp + 16 * st), out1);
       }
+      // second product: d table[c1][c0] += sum_y hat1[c1][y] out1[y][c0]
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float o8[8];
@@ -1163,7 +1172,7 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
         const bf16x8 b2 = cvt8<__bf16>(o8);
 #pragma unroll
         for (int cb = 0; cb < 3; ++cb) {
-          const __bf16* hp = hat0 + (32 * cb + c) * HATLD + 32 * xb + 16 * kb + 4 * hf;
+          const __bf16* hp = hat1 + (32 * cb + c) * HATLD + 32 * yb + 16 * kb + 4 * hf;
           const bf16x4 lo = *reinterpret_cast<const bf16x4*>(hp), hi = *reinterpret_cast<const bf16x4*>(hp + 8);
           const bf16x8 a2 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           acc2[cb] = mfma16b(a2, b2, acc2[cb]);
@@ -1171,12 +1180,12 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
       }
     }
   }
-  // this workgroup's partial table: lane <-> c1 = 32 wave + c, register r of block cb <-> c0 = 32 cb + acc_row(r, hf)
-  float* slab = hist_slab + (size_t)((((size_t)b * H + h) * gridDim.x) + blockIdx.x) * (TG * TG) + (size_t)(32 * wave + c) * TG;
+  // this workgroup's partial table: lane <-> c0 = 32 wave + c, register r of block cb <-> c1 = 32 cb + acc_row(r, hf)
+  float* slab = hist_slab + (size_t)((((size_t)b * H + h) * gridDim.x) + blockIdx.x) * (TG * TG) + 32 * wave + c;
 #pragma unroll
   for (int cb = 0; cb < 3; ++cb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slab[32 * cb + acc_row(r, hf)] = acc2[cb][r];
+    for (int r = 0; r < 16; ++r) slab[(size_t)(32 * cb + acc_row(r, hf)) * TG] = acc2[cb][r];
 }
 
 // d vs[(b, g)][j] = sum over the heads of the group and the S * TBW rows of each, in that fixed order
@@ -1495,10 +1504,14 @@ int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, c
       const size_t dyn = (((size_t)need_h * 2 + 15) / 16) * 16;
       static size_t dyn_set = 0;
       if (dyn > dyn_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_table_grid_bwd_kernel<TABLE_G2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_table_grid_bwd_kernel<TABLE_G2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_table_grid_bwd_kernel<TABLE_G2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         dyn_set = dyn;
       }
-      hipLaunchKernelGGL((cpb_table_grid_bwd_kernel<TABLE_G2>), dim3(wg_per_head, H, B), dim3(64 * TGW), dyn, st, dlogits16, vs, gq, tc, slab, N, J, H, G, nst, grid_h, grid_w);
+      if (grid_w % 4 == 0)
+        hipLaunchKernelGGL((cpb_table_grid_bwd_kernel<TABLE_G2, true>), dim3(wg_per_head, H, B), dim3(64 * TGW), dyn, st, dlogits16, vs, gq, tc, slab, N, J, H, G, nst, grid_h, grid_w);
+      else
+        hipLaunchKernelGGL((cpb_table_grid_bwd_kernel<TABLE_G2, false>), dim3(wg_per_head, H, B), dim3(64 * TGW), dyn, st, dlogits16, vs, gq, tc, slab, N, J, H, G, nst, grid_h, grid_w);
     } else if (posdim == 2)
       hipLaunchKernelGGL((cpb_table_bwd_kernel<2, TABLE_G2>), gt, bt, 0, st, dlogits16, vs, gq, tc, slab, rows, N, J, H, G, nst, S, tps);
     else

@@ -21,7 +21,9 @@ def newest(pattern):
 
 
 def short(name):
-    for key in ("cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel", "gemm_f32_fast_kernel",
+    if "deform16_fwd_kernel" in name and ("Li96E" in name or ", 96>" in name):
+        return "deform16_fwd_kernel (table)"
+    for key in ("cpb_table_grid_bwd_kernel", "cpb_table_bwd_kernel", "cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel", "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel", "gemm_f32_fast_kernel",
                 "gemm_bf3_kernel", "offsets_bwd", "offsets_fwd", "layernorm", "colsum", "attn16_fwd", "attn16_bwd_dq", "attn16_bwd_dkv"):
         if key in name:
             return key
@@ -41,7 +43,7 @@ def counters(path):
     return out
 
 
-KERNELS = ("cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel",
+KERNELS = ("deform16_fwd_kernel (table)", "cpb_table_grid_bwd_kernel", "cpb_table_bwd_kernel", "cpb16_bwd_kernel", "deform16_fwd_kernel", "deform16_bwd_dq_kernel", "deform16_bwd_dkv_kernel", "cpb_bwd_kernel", "deform_attn_fwd_kernel",
            "deform_attn_bwd_dq_kernel", "deform_attn_bwd_dkv_kernel")
 ks = newest(PROF + "/runc/*_kernel_stats.csv")
 if ks:
@@ -74,10 +76,10 @@ if f1 and f2:
         a, b = c1[k], c2[k]
         wc = mean(a["SQ_WAVE_CYCLES"])
         valu, mf = mean(a["SQ_INSTS_VALU"]), mean(b["SQ_INSTS_MFMA"])
-        lines.append(f"| {k} | {valu:.3e} | {mf:.3e} | {valu / mf:.1f} | {mean(b['SQ_INSTS_LDS']):.3e} | {mean(b['SQ_LDS_BANK_CONFLICT']) / max(mean(b['SQ_LDS_IDX_ACTIVE']), 1):.3f} | "
+        lines.append(f"| {k} | {valu:.3e} | {mf:.3e} | {(valu / mf) if mf else float('inf'):.1f} | {mean(b['SQ_INSTS_LDS']):.3e} | {mean(b['SQ_LDS_BANK_CONFLICT']) / max(mean(b['SQ_LDS_IDX_ACTIVE']), 1):.3f} | "
                      f"{mean(a['SQ_WAIT_ANY']) / wc:.2f} | {mean(a['SQ_WAIT_INST_ANY']) / wc:.2f} | {mean(a['SQ_ACTIVE_INST_ANY']) / wc:.2f} | {mean(a['SQ_VALU_MFMA_BUSY_CYCLES']):.3e} | "
                      f"{mean(a['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024 / (mean(a['GRBM_GUI_ACTIVE']) / 8):.3f} | "
-                     f"{(mean(a['SQ_VALU_MFMA_COEXEC_CYCLES']) / mean(a['SQ_VALU_MFMA_BUSY_CYCLES'])) if a['SQ_VALU_MFMA_COEXEC_CYCLES'] else float('nan'):.3f} | "
+                     f"{(mean(a['SQ_VALU_MFMA_COEXEC_CYCLES']) / mean(a['SQ_VALU_MFMA_BUSY_CYCLES'])) if (a['SQ_VALU_MFMA_COEXEC_CYCLES'] and mean(a['SQ_VALU_MFMA_BUSY_CYCLES'])) else float('nan'):.3f} | "
                      f"{mean(a['GRBM_GUI_ACTIVE']) / 8 / (mean(a['_ns']) if a['_ns'] else float('nan')):.2f} |")
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc_notes.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
