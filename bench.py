@@ -420,7 +420,8 @@ def main():
             "metric": "bags/sec fwd+bwd, DeformCrossTransMIL N=10k x 512",
             "value": world * B * a.steps / dt, "unit": "bags/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": (a.deform_dtype + (" (fused attention core" + (", tabulated position bias: approximate" if a.deform_table else "") + "); f32 elsewhere")) if a.deform_dtype else "f32",
+            "data": "synthetic",
             "config": {"workload": f"DeformCrossTransMIL training step (fwd + bwd + Adam), bag {N} x {in_dim} fp32, "
                                    f"token grid {S}x{S}, {J} sampled keys, path_dim 128, heads 8, CE + BatchLoss",
                        "bags_per_gpu": B, "global_batch": B * world, "instances": N, "feature_dim": in_dim,
