@@ -261,7 +261,14 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_t
     out = {"workload": f"the headline step with DeformCrossAttention2D(compute_dtype='{dtype}'): {B} bags of {N} x {in_dim} per step, "
                        f"fwd + bwd + Adam, CE + BatchLoss; parameters, inputs, outputs and gradients fp32 in memory",
            "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
-    if cpb_table:
+    if cpb_table == "forward":
+        out["workload"] += ("; the FORWARD takes the position bias from a table of the MLP (cpb_table='forward': evaluated once per call on a 96 x 96 grid, "
+                            "interpolated per pair, |error| <= ~1e-3 of the bias range); the backward differentiates the per-pair MLP itself (layer 2 recomputed): "
+                            "parity-grade at the 16-bit mode's tolerances (tests/test_gpu_deform16.py, tabfwd cases)")
+        if "deform_table_fwd" in kt:
+            n, ms, pairs = kt["deform_table_fwd"]
+            out["deform_table_fwd"] = {"avg_ms": ms, "launches": n, "pairs_per_launch": pairs}
+    elif cpb_table:
         out["workload"] += ("; position bias in TABLE mode (cpb_table=True: the MLP evaluated once per call on a 96 x 96 grid, interpolated per pair - an "
                             "APPROXIMATION of the reference's per-pair MLP, see tests/test_gpu_deform_table.py; not a parity-grade line)")
         out["approximate"] = True
@@ -295,8 +302,8 @@ def main():
     ap.add_argument("--grid", type=int, default=100, help="token grid side (N = grid^2)")
     ap.add_argument("--in-dim", type=int, default=512, help="bag feature width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--deform-table", action="store_true", help="measurement switch (with --deform-dtype): the headline step with the tabulated position "
-                    "bias (approximate mode; the default run reports it in the extra key `deform16_table`)")
+    ap.add_argument("--deform-table", nargs="?", const=True, default=False, help="measurement switch (with --deform-dtype): the headline step with the tabulated position "
+                    "bias (approximate mode; `--deform-table forward`: table in the forward only, exact backward; the default run reports both in the extra keys `deform16_table` / `deform16_tabfwd`)")
     ap.add_argument("--no-deform16", action="store_true", help="skip the 16-bit-compute-mode leg of the headline step (extra key `deform16`, not part of `value`)")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
@@ -420,7 +427,7 @@ def main():
             "metric": "bags/sec fwd+bwd, DeformCrossTransMIL N=10k x 512",
             "value": world * B * a.steps / dt, "unit": "bags/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": (a.deform_dtype + (" (fused attention core" + (", tabulated position bias: approximate" if a.deform_table else "") + "); f32 elsewhere")) if a.deform_dtype else "f32",
+            "dtype": (a.deform_dtype + (" (fused attention core" + (", forward bias from a table" if a.deform_table == "forward" else (", tabulated position bias: approximate" if a.deform_table else "")) + "); f32 elsewhere")) if a.deform_dtype else "f32",
             "data": "synthetic",
             "config": {"workload": f"DeformCrossTransMIL training step (fwd + bwd + Adam), bag {N} x {in_dim} fp32, "
                                    f"token grid {S}x{S}, {J} sampled keys, path_dim 128, heads 8, CE + BatchLoss",
@@ -444,6 +451,11 @@ def main():
                     out["deform16"]["speedup_vs_fp32_line"] = out["deform16"]["bags_per_s"] / out["value"]
                 except Exception as e:
                     out["deform16"] = {"error": f"{type(e).__name__}: {e}"}
+                try:        # the 16-bit step with the forward's bias from the table, exact per-pair backward (parity-grade; extra key)
+                    out["deform16_tabfwd"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3, cpb_table="forward")
+                    out["deform16_tabfwd"]["speedup_vs_fp32_line"] = out["deform16_tabfwd"]["bags_per_s"] / out["value"]
+                except Exception as e:
+                    out["deform16_tabfwd"] = {"error": f"{type(e).__name__}: {e}"}
                 try:        # the same step with the tabulated position bias (approximate mode; extra key, never part of `value`)
                     out["deform16_table"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3, cpb_table=True)
                     out["deform16_table"]["speedup_vs_fp32_line"] = out["deform16_table"]["bags_per_s"] / out["value"]

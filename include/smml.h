@@ -210,6 +210,10 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
                            float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
                            int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                            int dtype, void* ev_start, void* ev_stop, void* stream);
+/* relu_masks == NULL in smml_deform_attn16_bwd: the forward ran without the MLP (smml_deform_attn_table_fwd below) and saved no ReLU bits -
+ * the backward recomputes layer 2 per pair (one bf16 term) and differentiates the per-pair MLP exactly as with saved bits.  Tests: the next
+ * such call of this host thread also writes its layer-2 decisions to `out` (relu_masks' layout); NULL switches the export off. */
+void smml_deform_attn16_export_masks(unsigned short* out);
 /* Table mode of the 16-bit core (csrc/deform_attn16.hip, "table mode"): the continuous position bias CPB(slog(gq - vs)) of
  * models/DeformableAttention2D.py:120-157 / DeformableAttention1D.py:60-102 is ONE function of the posdim signed-log offsets for every
  * pair of a launch, so the caller evaluates the MLP once on a grid - `table` [H / G, points^posdim] fp32, point (i0, i1) at index

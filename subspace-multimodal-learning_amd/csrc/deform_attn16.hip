@@ -674,10 +674,14 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
 // bf16 d scores, chain 2 against ONE fp16 term of (W2 w3)^T and g = h1 . d bias as ONE bf16 term: 8 MFMAs per key
 // (1 + 1 layer 1, 2 mask transposition, 2 chain 2, 2 dW2) instead of 12, and none of the residual arithmetic of the splits.
 // ------------------------------------------------------------------------------------------------
-template <int PD>
+// RECOMP (the forward took its bias from the table - smml_deform_attn_table_fwd - and saved no ReLU bits): layer 2 of the MLP is recomputed
+// per key in the query-major layout, d = W2 relu(x1) + b2 as ONE bf16 term (2 MFMAs; b2 enters through the accumulator, read from LDS), and
+// its sign pattern becomes the mask operand directly (exact 0 / 1 fp16 values; the constants then carry no slot scale).  EXPORT (tests): the
+// decisions are also written out in the forward's bit layout (MKO), so that they can be imposed on the oracle.
+template <int PD, bool RECOMP = false, bool EXPORT = false>
 __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     const u16* __restrict__ dLT, const u16* __restrict__ MK, const float* __restrict__ VS, const float* __restrict__ GQ,
-    CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST) {
+    CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST, u16* __restrict__ MKO = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -694,8 +698,12 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
   float2* dvs_row = reinterpret_cast<float2*>(dvs_slab) + (size_t)(wg * WAVES + wave) * J;
   if (tid < 32) {                                           // tid = 16 half + r
     const int ch = acc_row(tid & 15, tid >> 4);
-    tab[(tid >> 4) * 32 + (tid & 15)] = cp.w1[ch * PD];
-    tab[(tid >> 4) * 32 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    if (RECOMP) {                                           // 2 b2 of the half's 16 output rows (the chain runs on 2 h1 = relu2)
+      tab[(tid >> 4) * 32 + (tid & 15)] = 2.f * cp.b2[ch];
+    } else {
+      tab[(tid >> 4) * 32 + (tid & 15)] = cp.w1[ch * PD];
+      tab[(tid >> 4) * 32 + 16 + (tid & 15)] = (PD == 2) ? cp.w1[ch * PD + 1] : 0.f;
+    }
   }
   const float* tabh = tab + hf * 32;
   const float gq0 = GQ[(size_t)qi * PD];
@@ -736,13 +744,23 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = acc_row(8 * kb + j, hf);
-        const float sc = (j & 1) ? 0.5f : 128.f;
+        const float sc = RECOMP ? 1.f : ((j & 1) ? 0.5f : 128.f);
         w2t[kb][j] = (_Float16)(cp.w2[ch * CH + c] * cp.w3[oi * CH + ch] * sc * lift2);
         idb[kb][j] = (ch == c) ? (_Float16)sc : (_Float16)0.0f;
       }
     }
   }
 
+  bf16x8 w2f[2];                       // RECOMP: W2 as the A operand of layer 2 - lane (out = c, half hf), K-block kb, element j <-> in = acc_row(8 kb + j, hf)
+  if (RECOMP) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = cp.w2[c * CH + acc_row(8 * kb + j, hf)];
+      w2f[kb] = cvt8<__bf16>(wv);
+    }
+  }
 #if SMML16_DP_MFMA
   bf16x8 a1d[2];                       // W1^T as an A operand: row 0 = w1x, row 1 = w1y over k = hidden channel acc_row(8 kb + j, hf); other rows zero
 #pragma unroll
@@ -769,8 +787,9 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
   unsigned db_n = dLTb[c];
-  const u16* MKb = MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
-  unsigned m16_n = MKb[c];
+  const u16* MKb = RECOMP ? nullptr : MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
+  u16* MKOb = (RECOMP && EXPORT) ? MKO + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32 : nullptr;
+  unsigned m16_n = RECOMP ? 0u : MKb[c];
 
   for (int j = 0; j < J; ++j) {
     const float vx = vx_n, vy = vy_n, dbias = qvalid ? tof<__bf16>(db_n) : 0.f;
@@ -780,7 +799,7 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
       vx_n = VSb[(size_t)jn * PD];
       if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
       db_n = dLTb[(size_t)jn * 32 + c];
-      m16_n = MKb[(size_t)jn * 64 + c];
+      if (!RECOMP) m16_n = MKb[(size_t)jn * 64 + c];
     }
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;
@@ -806,7 +825,35 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
 #endif
 
     half8 mk[2];
-    {
+    if constexpr (RECOMP) {
+      floatx16 d2;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 t = *reinterpret_cast<const float4*>(tabh + 4 * rg);
+        d2[4 * rg] = t.x; d2[4 * rg + 1] = t.y; d2[4 * rg + 2] = t.z; d2[4 * rg + 3] = t.w;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float hv[8];
+#pragma unroll
+        for (int jx = 0; jx < 8; ++jx) hv[jx] = relu2(xacc[8 * kb + jx]);
+        d2 = mfma16b(w2f[kb], cvt8<__bf16>(hv), d2);
+      }
+      float mbits = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        uint4v mw;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int r = 8 * kb + 2 * p;
+          const float m0 = fminf(fmaxf(d2[r] * big, 0.f), 1.f), m1 = fminf(fmaxf(d2[r + 1] * big, 0.f), 1.f);     // exact 0 / 1
+          mw[p] = pack2<_Float16>(m0, m1);
+          if (EXPORT) mbits = fmaf(m1, (float)(1u << ((14 + r) & 15)), fmaf(m0, (float)(1u << ((13 + r) & 15)), mbits));
+        }
+        mk[kb] = __builtin_bit_cast(half8, mw);
+      }
+      if (EXPORT) MKOb[(size_t)j * 64 + c] = (u16)(unsigned)mbits;
+    } else {
       const unsigned mm2 = m16 | (m16 << 16);
       uint4v w0, w1;
       w0[0] = mm2 & 0x40002000u;
@@ -1249,6 +1296,8 @@ void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float*
     hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
 }
 
+thread_local u16* g_export_masks = nullptr;      // smml_deform_attn16_export_masks: where the next recomputing backward of this thread writes its layer-2 decisions
+
 constexpr int TABLE_G2 = 96;      // grid points per axis of the 2-D table (36 KB in LDS: two forward workgroups per CU)
 constexpr int TABLE_G1 = 1024;    // points of the 1-D table
 
@@ -1348,9 +1397,9 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
   int rc = check16("smml_deform_attn16_bwd", B, N, J, H, G, posdim, dtype);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_bwd: dropout_p must be in [0, 1)");
-  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits16 && relu_masks &&
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits16 &&
                    dlogits16 && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
-               "smml_deform_attn16_bwd: null pointer");
+               "smml_deform_attn16_bwd: null pointer");        // relu_masks may be null: layer 2 is then recomputed (table-forward calls)
   SMML_REQUIRE(workspace_bytes >= smml_deform_attn_bwd_workspace_bytes(B, N, J, H),
                "smml_deform_attn16_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                smml_deform_attn_bwd_workspace_bytes(B, N, J, H));
@@ -1388,10 +1437,24 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     float* slab = wsf;
     const size_t lds = ((size_t)CPB2_TAB + WAVES * CPB2_WAVE_LDS + WAVES * CPB_SLAB) * sizeof(float);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
-    if (posdim == 2)
-      hipLaunchKernelGGL(cpb16_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
-    else
-      hipLaunchKernelGGL(cpb16_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
+    u16* mko = g_export_masks;
+    const dim3 gc(qtiles, H, B);
+    if (relu_masks) {
+      if (posdim == 2)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+      else
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+    } else if (mko) {
+      if (posdim == 2)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, true, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+      else
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, true, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+    } else {
+      if (posdim == 2)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, true, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+      else
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, true, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+    }
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/cpb");
     const int nwg = qtiles * H * B;
@@ -1407,6 +1470,10 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
   }
   return SMML_OK;
 }
+
+// tests: the next smml_deform_attn16_bwd call of this host thread that recomputes layer 2 (relu_masks == NULL) also writes its decisions to
+// `out` ([B, H, nst / 32, J, 2, 32] u16, the forward's layout); NULL switches the export off again
+void smml_deform_attn16_export_masks(unsigned short* out) { g_export_masks = out; }
 
 // ---- table mode (tabulated position bias): same contract as the two entry points above with `table` [o, table_g^posdim] in place of
 // the six MLP tensors and d table in place of their gradients

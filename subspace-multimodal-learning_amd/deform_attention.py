@@ -109,7 +109,7 @@ class DeformCrossAttention2D(nn.Module):
         self.compute_dtype = compute_dtype     # additive: None = the fp32-grade path, else the 16-bit compute mode of the fused core
         if cpb_table and compute_dtype is None:
             raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
-        self.cpb_table = bool(cpb_table)       # additive: position bias from a table of the MLP (functional.deform_attention)
+        self.cpb_table = cpb_table             # additive: False | True ('full') | 'forward' - position bias from a table of the MLP (functional.deform_attention)
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -175,7 +175,7 @@ class DeformCrossAttention2D(nn.Module):
             lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
             gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
             vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
-            tab = {"cpb_table": True, "cpb_table_pmax": None if self.consistent_grid_norm else Fh.table_pmax(gqb, vsb),   # None: from the data
+            tab = {"cpb_table": self.cpb_table, "cpb_table_pmax": None if self.consistent_grid_norm else Fh.table_pmax(gqb, vsb),   # None: from the data
                    "cpb_table_grid": (Hh, Ww)}                 # gq is a regular grid in both normalisations
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,
                                 compute_dtype=self.compute_dtype, fork=fork, **tab, **_dropout_args(self, q.device))
@@ -201,7 +201,7 @@ class DeformCrossAttention1D(nn.Module):
         self.compute_dtype = compute_dtype
         if cpb_table and compute_dtype is None:
             raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
-        self.cpb_table = bool(cpb_table)
+        self.cpb_table = cpb_table
         offset_scale = _default(offset_scale, downsample_factor)
         assert offset_kernel_size >= downsample_factor, \
             'offset kernel size must be greater than or equal to the downsample factor'
@@ -251,7 +251,7 @@ class DeformCrossAttention1D(nn.Module):
         tab = {}
         if self.cpb_table:
             t = vgrid.shape[-1]
-            tab = {"cpb_table": True, "cpb_table_pmax": Fh.table_pmax(1.0, 1.0 + 2.0 * self.offset_scale / max(t - 1, 1))}
+            tab = {"cpb_table": self.cpb_table, "cpb_table_pmax": Fh.table_pmax(1.0, 1.0 + 2.0 * self.offset_scale / max(t - 1, 1))}
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
                                 scale=self.scale, compute_dtype=self.compute_dtype, **tab, **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))

@@ -86,9 +86,9 @@ class DeformCrossTransMIL(nn.Module):
         self.args = args
         self.n_classes = n_classes
         # 'bf16' | 'fp16' runs the fused attention core and its output projection in the 16-bit compute mode
-        # `args.deform_cpb_table` (absent / False; with a 16-bit compute dtype only): position bias from a table of the MLP
+        # `args.deform_cpb_table` (absent / False | 'forward' | True; with a 16-bit compute dtype only): position bias from a table of the MLP
         self.layer3 = DeformCrossTransLayer(dim=args.path_dim, grid_hw=getattr(args, "grid_hw", None), compute_dtype=cd,
-                                            cpb_table=bool(getattr(args, "deform_cpb_table", False)))
+                                            cpb_table=getattr(args, "deform_cpb_table", False))
         self.norm = nn.LayerNorm(args.path_dim)
         self._fc2 = nn.Linear(args.path_dim, self.n_classes)
         self.pooler = Pooler(args.path_dim)

@@ -863,7 +863,7 @@ def _dtype16(compute_dtype):
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
-                compute_dtype=None, fork=None):
+                compute_dtype=None, fork=None, table_pmax_fwd=None):
         ctx.fork = fork
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
@@ -880,13 +880,28 @@ class _DeformAttn(torch.autograd.Function):
         lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad)
         logits = masks = None
+        tabfwd = table_pmax_fwd is not None           # 16-bit mode, forward bias from the table; the backward recomputes layer 2 (deform_attention)
+        ctx.export_masks = None
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
             # score-shaped tensors are stored per 32-query tile (include/smml.h): [B, H, nst / 32, J, 32] (+ the lane-half axis of the masks)
             logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32 if m16 is None else torch.float16)   # 16-bit mode: fp16 scores in both sub-modes
-            masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
+            if not tabfwd:
+                masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
+            elif DECISION_TAP is not None:            # tests: the backward writes the decisions it recomputed here
+                ctx.export_masks = torch.zeros(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)
         _set_seed_offset(L, seed_offset)
-        if m16 is None:
+        if tabfwd:
+            if m16 is None:
+                raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
+            points = L.smml_deform_attn_table_points(posdim)
+            with torch.no_grad():
+                table = cpb_table_fn(w1, b1, w2, b2, w3, b3, posdim=posdim, pmax=table_pmax_fwd, device=q.device)
+            capi.check(L.smml_deform_attn_table_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table),
+                                                    capi.fptr(out), capi.fptr(lse), capi.ptr(logits), B, N, J, heads, groups, posdim, points,
+                                                    float(table_pmax_fwd), float(scale), float(dropout_p), int(dropout_seed), m16[0],
+                                                    *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream()), "deform_attn_table_fwd")
+        elif m16 is None:
             capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                                   capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                                   capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
@@ -905,8 +920,8 @@ class _DeformAttn(torch.autograd.Function):
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         if DECISION_TAP is not None:
-            DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(), "masks2": masks,
-                                 "B": B, "N": N, "J": J, "heads": heads, "groups": groups})
+            DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(),
+                                 "masks2": masks if not tabfwd else ctx.export_masks, "B": B, "N": N, "J": J, "heads": heads, "groups": groups})
         return out
 
     @staticmethod
@@ -935,6 +950,8 @@ class _DeformAttn(torch.autograd.Function):
                 *TIMER.events("cpb_bwd", B * heads * N * J),
                 capi.stream()), "deform_attn_bwd")
         else:
+            if ctx.export_masks is not None:
+                L.smml_deform_attn16_export_masks(capi.ptr(ctx.export_masks))
             capi.check(L.smml_deform_attn16_bwd(
                 capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
                 capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
@@ -943,10 +960,12 @@ class _DeformAttn(torch.autograd.Function):
                 capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed, m16[0],
                 *TIMER.events("cpb16_bwd", B * heads * N * J),
                 capi.stream()), "deform_attn16_bwd")
+            if ctx.export_masks is not None:
+                L.smml_deform_attn16_export_masks(None)
         _set_seed_offset(L, None)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1091,14 +1110,21 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
     compute_dtype None: fp32-grade split products (csrc/deform_attn.hip); 'bf16' / 'fp16': the 16-bit compute mode
     (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32).
-    cpb_table (with a 16-bit compute_dtype): the position-bias MLP is evaluated once on a grid and interpolated per pair (include/smml.h,
-    "table mode"); cpb_table_pmax = half-width of the grid in signed-log units (table_pmax(); None: taken from the data, one host sync);
+    cpb_table (with a 16-bit compute_dtype): True / 'full' - the position-bias MLP is evaluated once on a grid and interpolated per pair,
+    forward and backward (include/smml.h, "table mode": approximate parameter gradients); 'forward' - only the forward takes its bias from the
+    table (|error| <= ~1e-3 of the bias range, below the 16-bit operand rounding), the backward differentiates the per-pair MLP itself, recomputing
+    layer 2 (parity-grade gradients at the 16-bit mode's tolerances); cpb_table_pmax = half-width of the grid in signed-log units (table_pmax(); None: taken from the data, one host sync);
     cpb_table_grid = (rows, cols) asserts that the queries sit on a regular grid, gq[y * cols + x] = (X[x], Y[y]) - the backward then
     builds d table on the matrix pipe instead of with LDS atomics."""
+    if cpb_table not in (False, True, None, "forward", "full"):
+        raise ValueError("cpb_table must be False, True / 'full' or 'forward'")
+    if cpb_table and cpb_table_pmax is None:
+        cpb_table_pmax = table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
+    if cpb_table == "forward":
+        return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
+                                 dropout_seed_offset, compute_dtype, fork, cpb_table_pmax)
     if cpb_table:
         posdim = vs.shape[-1]
-        if cpb_table_pmax is None:
-            cpb_table_pmax = table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
         table = cpb_table_fn(w1, b1, w2, b2, w3, b3, posdim=posdim, pmax=cpb_table_pmax, device=q.device)
         return _DeformAttnTable.apply(q, k, v, vs, gq, table, heads, groups, scale, dropout_p, dropout_seed, dropout_seed_offset,
                                       compute_dtype, fork, cpb_table_pmax, cpb_table_grid)

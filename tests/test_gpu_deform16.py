@@ -35,8 +35,9 @@ MLP_GRAD_TOL_SMALL = 6e-2      # position-bias MLP parameter gradients of the SM
 L2_MARGIN = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # layer-2 decisions: |pre-activation| of a flipped unit <= margin x sum |W2| |h1| (+ |b2|)
 
 
+@pytest.mark.parametrize("tabfwd", [False, True])
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-def test_fused_core16_random_shapes(cuda, mode):
+def test_fused_core16_random_shapes(cuda, mode, tabfwd):
     """The 16-bit fused core (forward + the three backward passes) on random ragged shapes - N, J off the 32 / 128 tiles, one or two
     heads per offset group, 1-D and 2-D positions, with and without dropout - against plain torch in fp64 with the kernels' own
     ReLU decisions and dropout mask imposed."""
@@ -61,8 +62,11 @@ def test_fused_core16_random_shapes(cuda, mode):
         seed = 170 + case
         smml.functional.DECISION_TAP = tapped = []
         try:
+            # tabfwd: the forward's bias comes from the table (cpb_table='forward'), the backward recomputes layer 2 (always one bf16 term) and
+            # exports the decisions it took - everything below then applies unchanged
+            tkw = dict(cpb_table="forward", cpb_table_pmax=Fh.table_pmax(1.0, 1.2)) if tabfwd else {}
             out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=p_drop,
-                                      dropout_seed=seed, compute_dtype=mode)
+                                      dropout_seed=seed, compute_dtype=mode, **tkw)
         finally:
             smml.functional.DECISION_TAP = None
         (out * wo.to(cuda)).sum().backward()
@@ -85,7 +89,7 @@ def test_fused_core16_random_shapes(cuda, mode):
             if flip.any():
                 ratio = float((x2.abs() / mag.clamp_min(1e-30))[flip].max())
                 worst["l2 flip / magnitude"] = max(worst.get("l2 flip / magnitude", 0.0), ratio)
-                assert ratio < L2_MARGIN[mode], f"case {case}: a layer-2 decision differs from fp64 at {ratio:.2e} of the unit's magnitude"
+                assert ratio < L2_MARGIN["bf16" if tabfwd else mode], f"case {case}: a layer-2 decision differs from fp64 at {ratio:.2e} of the unit's magnitude"
         tag = f"{mode} case {case}: B={B} N={N} J={J} G={groups} PD={PD} p={p_drop}"
         e = rel_err(out, o); worst["out"] = max(worst.get("out", 0.0), e)
         assert_close(tag + " out", out, o, FWD_TOL[mode])
@@ -98,18 +102,19 @@ def test_fused_core16_random_shapes(cuda, mode):
                 continue
             e = rel_err(g, g64); worst["d" + n] = max(worst.get("d" + n, 0.0), e)
             assert_close(tag + " d" + n, g, g64, MLP_GRAD_TOL_SMALL if n in ("w1", "b1", "w2", "b2", "w3") else GRAD_TOL[mode])
-    print(f"\n[deform16 {mode}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    print(f"\n[deform16 {mode}{' table forward' if tabfwd else ''}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
 
+@pytest.mark.parametrize("tabfwd", [False, True])
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("train", [False, True])
-def test_deform2d_16bit_vs_oracle(cuda, mode, train):
+def test_deform2d_16bit_vs_oracle(cuda, mode, train, tabfwd):
     """DeformCrossAttention2D(compute_dtype=...) on a 20 x 20 grid, eval and train (dropout 0.1 with the kernel's exported mask): output,
     vgrid (untouched by the mode: exact), input and parameter gradients against the fp64 oracle with the kernels' decisions imposed."""
     B, Hh, Ww, C = 2, 20, 20, 128
     N = Hh * Ww
     tag = f"d2d16:{mode}:{int(train)}"
-    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww), compute_dtype=mode)
+    mod = smml.DeformCrossAttention2D(dim=C, dropout=0.1, grid_hw=(Hh, Ww), compute_dtype=mode, cpb_table="forward" if tabfwd else False)
     params = params_for(mod, 31, tag)
     mod.load_state_dict(params)
     mod = mod.to(cuda).train(train)
