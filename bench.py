@@ -263,7 +263,7 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_t
            "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
     if cpb_table == "forward":
         out["workload"] += ("; the FORWARD takes the position bias from a table of the MLP (cpb_table='forward': evaluated once per call on a 96 x 96 grid, "
-                            "interpolated per pair, |error| <= ~1e-3 of the bias range); the backward differentiates the per-pair MLP itself (layer 2 recomputed): "
+                            "interpolated per pair, |error| <= ~1e-3 of the bias range); the backward differentiates the per-pair MLP itself (layer-2 decisions from a 1024 x 1024 mask table): "
                             "parity-grade at the 16-bit mode's tolerances (tests/test_gpu_deform16.py, tabfwd cases)")
         if "deform_table_fwd" in kt:
             n, ms, pairs = kt["deform_table_fwd"]

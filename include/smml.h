@@ -214,6 +214,15 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
  * the backward recomputes layer 2 per pair (one bf16 term) and differentiates the per-pair MLP exactly as with saved bits.  Tests: the next
  * such call of this host thread also writes its layer-2 decisions to `out` (relu_masks' layout); NULL switches the export off. */
 void smml_deform_attn16_export_masks(unsigned short* out);
+/* Mask table: instead of recomputing layer 2 per pair, a relu_masks == NULL backward can take the layer-2 decisions from a table of the sign
+ * pattern of W2 relu(W1 p + b1) + b2 at the centres of cells^posdim cells over [-pmax, pmax]^posdim (cells = smml_cpb_mask_table_cells(posdim):
+ * 1024 per axis in 2-D, 16384 in 1-D; `table` = cells^posdim 32-bit words = two u16 lane-half words in relu_masks' bit layout).  A pair's
+ * decision then differs from its own pre-activation's sign only where a layer-2 kink crosses its cell (|x2| <= |grad x2| x 1.8e-3), the size of the
+ * decision noise of the single-term bf16 product.  smml_deform_attn16_set_mask_table applies to the NEXT such backward of this host thread. */
+int smml_cpb_mask_table_cells(int posdim);
+int smml_cpb_mask_table(const float* w1, const float* b1, const float* w2, const float* b2, unsigned short* table, int posdim, float pmax,
+                        void* stream);
+void smml_deform_attn16_set_mask_table(const unsigned short* table, float pmax);
 /* Table mode of the 16-bit core (csrc/deform_attn16.hip, "table mode"): the continuous position bias CPB(slog(gq - vs)) of
  * models/DeformableAttention2D.py:120-157 / DeformableAttention1D.py:60-102 is ONE function of the posdim signed-log offsets for every
  * pair of a launch, so the caller evaluates the MLP once on a grid - `table` [H / G, points^posdim] fp32, point (i0, i1) at index

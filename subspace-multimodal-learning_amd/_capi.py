@@ -64,6 +64,9 @@ SIGNATURES = {
     "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
     "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
     "smml_deform_attn16_export_masks": (None, [_f]),
+    "smml_cpb_mask_table_cells": (_i, [_i]),
+    "smml_cpb_mask_table": (_i, [_f, _f, _f, _f, _f, _i, _fl, _f]),
+    "smml_deform_attn16_set_mask_table": (None, [_f, _fl]),
     "smml_deform_attn_table_points": (_i, [_i]),
     "smml_deform_attn_table_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "smml_deform_attn_table_fwd": (_i, [_f] * 9 + [_i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),

@@ -678,10 +678,22 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dkv_kernel(
 // per key in the query-major layout, d = W2 relu(x1) + b2 as ONE bf16 term (2 MFMAs; b2 enters through the accumulator, read from LDS), and
 // its sign pattern becomes the mask operand directly (exact 0 / 1 fp16 values; the constants then carry no slot scale).  EXPORT (tests): the
 // decisions are also written out in the forward's bit layout (MKO), so that they can be imposed on the oracle.
-template <int PD, bool RECOMP = false, bool EXPORT = false>
+// MSRC 2 (the default of table-forward calls): the layer-2 decisions come from a MASK TABLE instead - the sign pattern of W2 relu(W1 p + b1) + b2
+// evaluated in fp32 at the centres of a 1024 x 1024 (16384 in 1-D) grid of cells over the same [-pmax, pmax] range (cpb_mask_table_kernel, 4 MB:
+// L2-resident), one 16-bit gather per lane and key issued a key ahead.  A pair's decision can differ from its own pre-activation's sign only where
+// a layer-2 kink crosses its cell, |x2| <= |grad x2| . 1.8e-3: the size of the decision noise the single-term bf16 product of the other two forms
+// has anyway (tests/test_gpu_deform16.py asserts both against the same margin).
+struct MaskTab {
+  const u16* tab;          // [cells][2 lane halves], the forward's bit layout per half
+  float invh, off, imax;   // cell index along an axis = clamp(p * invh + off, 0, imax) truncated
+};
+template <int PD, int MSRC = 0, bool EXPORT = false>
 __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     const u16* __restrict__ dLT, const u16* __restrict__ MK, const float* __restrict__ VS, const float* __restrict__ GQ,
-    CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST, u16* __restrict__ MKO = nullptr) {
+    CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST, u16* __restrict__ MKO = nullptr,
+    MaskTab mt = MaskTab{}) {
+  constexpr bool RECOMP = MSRC == 1;
+  constexpr int MT_BITS = (PD == 2) ? 10 : 14;      // cells per axis of the mask table: 1024 (2-D), 16384 (1-D)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -787,25 +799,53 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
   float vx_n = VSb[0];
   float vy_n = (PD == 2) ? VSb[1] : 0.f;
   unsigned db_n = dLTb[c];
-  const u16* MKb = RECOMP ? nullptr : MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
-  u16* MKOb = (RECOMP && EXPORT) ? MKO + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32 : nullptr;
-  unsigned m16_n = RECOMP ? 0u : MKb[c];
+  const u16* MKb = (MSRC != 0) ? nullptr : MK + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32;
+  u16* MKOb = (MSRC != 0 && EXPORT) ? MKO + (((size_t)(b * H + h) * NST + q0) * J) * 2 + hf * 32 : nullptr;
+  // mask table: cell of (query, key) -> this lane half's 16 decisions
+  float p0_n = 0.f, p1_n = 0.f;                    // MSRC 2: the signed-log offsets of the NEXT key (computed for its lookup, reused as that key's p)
+  auto mask_lookup = [&](float vxk, float vyk) -> unsigned {
+    p0_n = slog1p(gq0 - vxk);
+    const int i0 = (int)__builtin_amdgcn_fmed3f(fmaf(p0_n, mt.invh, mt.off), 0.f, mt.imax);
+    int cell = i0;
+    if (PD == 2) {
+      p1_n = slog1p(gq1 - vyk);
+      cell |= ((int)__builtin_amdgcn_fmed3f(fmaf(p1_n, mt.invh, mt.off), 0.f, mt.imax)) << MT_BITS;
+    }
+    return mt.tab[(size_t)cell * 2 + hf];
+  };
+  float vx_nn = 0.f, vy_nn = 0.f;                  // MSRC 2: sample position two keys ahead (the gather of key j + 1 needs key j + 1's position a key early)
+  unsigned m16_n = (MSRC == 0) ? MKb[c] : 0u;
+  if (MSRC == 2) {
+    m16_n = mask_lookup(vx_n, vy_n);
+    const int j1 = min(1, J - 1);
+    vx_nn = VSb[(size_t)j1 * PD];
+    vy_nn = (PD == 2) ? VSb[(size_t)j1 * PD + 1] : 0.f;
+  }
 
   for (int j = 0; j < J; ++j) {
     const float vx = vx_n, vy = vy_n, dbias = qvalid ? tof<__bf16>(db_n) : 0.f;
     const unsigned m16 = m16_n;
+    const float p0_c = p0_n, p1_c = p1_n;           // MSRC 2: this key's offsets, from its lookup an iteration ago
     {
       const int jn = min(j + 1, J - 1);
-      vx_n = VSb[(size_t)jn * PD];
-      if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
+      if (MSRC == 2) {
+        vx_n = vx_nn; vy_n = vy_nn;                 // key j + 1, loaded an iteration ago
+        m16_n = mask_lookup(vx_n, vy_n);
+        const int jnn = min(j + 2, J - 1);
+        vx_nn = VSb[(size_t)jnn * PD];
+        if (PD == 2) vy_nn = VSb[(size_t)jnn * PD + 1];
+      } else {
+        vx_n = VSb[(size_t)jn * PD];
+        if (PD == 2) vy_n = VSb[(size_t)jn * PD + 1];
+      }
       db_n = dLTb[(size_t)jn * 32 + c];
-      if (!RECOMP) m16_n = MKb[(size_t)jn * 64 + c];
+      if (MSRC == 0) m16_n = MKb[(size_t)jn * 64 + c];
     }
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;
     const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = slog1p(d0);
-    const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
+    const float p0 = (MSRC == 2) ? p0_c : slog1p(d0);
+    const float p1 = (PD == 2) ? ((MSRC == 2) ? p1_c : slog1p(d1)) : 0.f;
 
     floatx16 xacc, ht;
     {
@@ -854,6 +894,7 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
       }
       if (EXPORT) MKOb[(size_t)j * 64 + c] = (u16)(unsigned)mbits;
     } else {
+      if (MSRC == 2 && EXPORT) MKOb[(size_t)j * 64 + c] = (u16)m16;
       const unsigned mm2 = m16 | (m16 << 16);
       uint4v w0, w1;
       w0[0] = mm2 & 0x40002000u;
@@ -1271,6 +1312,42 @@ __global__ void table_hist_reduce_kernel(const float* __restrict__ slab, float* 
   if (o > 1) atomicAdd(&dtab[NC + cell], s1);
 }
 
+// mask table of cpb16_bwd_kernel<PD, 2>: one thread per cell evaluates layers 1 and 2 of the MLP in plain fp32 at the cell's centre and packs the
+// 32 layer-2 signs into the two lane-half words of the forward's bit layout (hidden channel acc_row(r, half) at bit (13 + r) % 16).
+template <int PD>
+__global__ __launch_bounds__(256) void cpb_mask_table_kernel(CpbParams cp, u16* __restrict__ tab, int cells_per_axis, float pmax) {
+  __shared__ float w1s[CH * 2], b1s[CH], w2s[CH * CH], b2s[CH];
+  for (int i = threadIdx.x; i < CH * CH; i += 256) w2s[i] = cp.w2[i];
+  if (threadIdx.x < CH) {
+    w1s[threadIdx.x * 2] = cp.w1[threadIdx.x * PD];
+    w1s[threadIdx.x * 2 + 1] = (PD == 2) ? cp.w1[threadIdx.x * PD + 1] : 0.f;
+    b1s[threadIdx.x] = cp.b1[threadIdx.x];
+    b2s[threadIdx.x] = cp.b2[threadIdx.x];
+  }
+  __syncthreads();
+  const long long cell = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long ncell = (PD == 2) ? (long long)cells_per_axis * cells_per_axis : cells_per_axis;
+  if (cell >= ncell) return;
+  const float hcell = 2.f * pmax / (float)cells_per_axis;
+  const int i0 = (int)(cell % cells_per_axis), i1 = (int)(cell / cells_per_axis);
+  const float p0 = -pmax + ((float)i0 + 0.5f) * hcell, p1 = (PD == 2) ? -pmax + ((float)i1 + 0.5f) * hcell : 0.f;
+  float h1[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) h1[ch] = fmaxf(fmaf(w1s[2 * ch], p0, fmaf(w1s[2 * ch + 1], p1, b1s[ch])), 0.f);
+  unsigned words[2] = {0u, 0u};
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int out = acc_row(r, half);
+      float x2 = b2s[out];
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) x2 = fmaf(w2s[out * CH + ch], h1[ch], x2);
+      words[half] |= (x2 > 0.f ? 1u : 0u) << ((13 + r) & 15);
+    }
+  reinterpret_cast<unsigned*>(tab)[cell] = words[0] | (words[1] << 16);
+}
+
 int check16(const char* fn, int B, int N, int J, int H, int G, int posdim, int dtype) {
   SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0 && G > 0, "%s: non-positive dimension", fn);
   SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
@@ -1296,6 +1373,8 @@ void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float*
     hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
 }
 
+thread_local const u16* g_mask_table = nullptr;  // smml_deform_attn16_set_mask_table: mask table of the next recomputation-free table-forward backward
+thread_local float g_mask_table_pmax = 0.f;
 thread_local u16* g_export_masks = nullptr;      // smml_deform_attn16_export_masks: where the next recomputing backward of this thread writes its layer-2 decisions
 
 constexpr int TABLE_G2 = 96;      // grid points per axis of the 2-D table (36 KB in LDS: two forward workgroups per CU)
@@ -1444,16 +1523,31 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
         hipLaunchKernelGGL((cpb16_bwd_kernel<2>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
       else
         hipLaunchKernelGGL((cpb16_bwd_kernel<1>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
-    } else if (mko) {
-      if (posdim == 2)
-        hipLaunchKernelGGL((cpb16_bwd_kernel<2, true, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+    } else if (g_mask_table) {          // decisions from the mask table
+      const int cells = posdim == 2 ? 1024 : 16384;
+      MaskTab mt;
+      mt.tab = g_mask_table;
+      mt.invh = (float)((double)cells / (2.0 * (double)g_mask_table_pmax));
+      mt.off = 0.5f * (float)cells;
+      mt.imax = (float)cells - 0.5f;
+      if (posdim == 2 && mko)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, 2, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko, mt);
+      else if (posdim == 2)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, 2, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko, mt);
+      else if (mko)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, 2, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko, mt);
       else
-        hipLaunchKernelGGL((cpb16_bwd_kernel<1, true, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, 2, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko, mt);
+    } else if (mko) {                   // layer 2 recomputed per pair
+      if (posdim == 2)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, 1, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+      else
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, 1, true>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
     } else {
       if (posdim == 2)
-        hipLaunchKernelGGL((cpb16_bwd_kernel<2, true, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+        hipLaunchKernelGGL((cpb16_bwd_kernel<2, 1, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
       else
-        hipLaunchKernelGGL((cpb16_bwd_kernel<1, true, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+        hipLaunchKernelGGL((cpb16_bwd_kernel<1, 1, false>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
     }
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/cpb");
@@ -1470,6 +1564,26 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
   }
   return SMML_OK;
 }
+
+// mask table of the table-forward backward (include/smml.h): cells per axis, and the kernel that fills one
+int smml_cpb_mask_table_cells(int posdim) { return posdim == 2 ? 1024 : 16384; }
+int smml_cpb_mask_table(const float* w1, const float* b1, const float* w2, const float* b2, unsigned short* table, int posdim, float pmax,
+                        void* stream) {
+  SMML_REQUIRE(w1 && b1 && w2 && b2 && table, "smml_cpb_mask_table: null pointer");
+  SMML_REQUIRE(posdim == 1 || posdim == 2, "smml_cpb_mask_table: posdim must be 1 or 2 (got %d)", posdim);
+  SMML_REQUIRE(pmax > 0.f, "smml_cpb_mask_table: pmax must be positive");
+  CpbParams cp{w1, b1, w2, b2, nullptr, nullptr};
+  const int cpa = smml_cpb_mask_table_cells(posdim);
+  const long long ncell = posdim == 2 ? (long long)cpa * cpa : cpa;
+  const dim3 grid((unsigned)((ncell + 255) / 256));
+  if (posdim == 2) hipLaunchKernelGGL(cpb_mask_table_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, cp, table, cpa, pmax);
+  else hipLaunchKernelGGL(cpb_mask_table_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, cp, table, cpa, pmax);
+  SMML_LAUNCH_CHECK("smml_cpb_mask_table");
+  return SMML_OK;
+}
+// the next smml_deform_attn16_bwd call of this host thread with relu_masks == NULL takes its layer-2 decisions from `table` (filled by
+// smml_cpb_mask_table with the same pmax); NULL: such calls recompute layer 2 per pair
+void smml_deform_attn16_set_mask_table(const unsigned short* table, float pmax) { g_mask_table = table; g_mask_table_pmax = pmax; }
 
 // tests: the next smml_deform_attn16_bwd call of this host thread that recomputes layer 2 (relu_masks == NULL) also writes its decisions to
 // `out` ([B, H, nst / 32, J, 2, 32] u16, the forward's layout); NULL switches the export off again

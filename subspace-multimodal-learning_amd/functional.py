@@ -860,6 +860,10 @@ def _dtype16(compute_dtype):
     return _DTYPE16[key]
 
 
+# layer-2 decisions of a cpb_table='forward' backward: 'table' (mask table, include/smml.h) or 'recompute' (layer 2 per pair); measurement / test switch
+TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
+
+
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
@@ -880,7 +884,8 @@ class _DeformAttn(torch.autograd.Function):
         lse = torch.empty(B, heads, N, device=q.device, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad)
         logits = masks = None
-        tabfwd = table_pmax_fwd is not None           # 16-bit mode, forward bias from the table; the backward recomputes layer 2 (deform_attention)
+        tabfwd = table_pmax_fwd is not None           # 16-bit mode, forward bias from the table; the backward takes layer 2's decisions from a mask table
+        ctx.table_pmax = table_pmax_fwd               # (or recomputes layer 2 per pair: TABLE_FORWARD_MASKS)
         ctx.export_masks = None
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
@@ -952,6 +957,14 @@ class _DeformAttn(torch.autograd.Function):
         else:
             if ctx.export_masks is not None:
                 L.smml_deform_attn16_export_masks(capi.ptr(ctx.export_masks))
+            mtab = None
+            if masks is None and TABLE_FORWARD_MASKS == "table":
+                # table-forward call: layer-2 decisions from a mask table (include/smml.h) built from the current weights - one small launch
+                cells = L.smml_cpb_mask_table_cells(posdim)
+                mtab = torch.empty(cells ** posdim, device=q.device, dtype=torch.int32)
+                capi.check(L.smml_cpb_mask_table(capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.ptr(mtab), posdim,
+                                                 float(ctx.table_pmax), capi.stream()), "cpb_mask_table")
+                L.smml_deform_attn16_set_mask_table(capi.ptr(mtab), float(ctx.table_pmax))
             capi.check(L.smml_deform_attn16_bwd(
                 capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
                 capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
@@ -962,6 +975,8 @@ class _DeformAttn(torch.autograd.Function):
                 capi.stream()), "deform_attn16_bwd")
             if ctx.export_masks is not None:
                 L.smml_deform_attn16_export_masks(None)
+            if mtab is not None:
+                L.smml_deform_attn16_set_mask_table(None, 0.0)
         _set_seed_offset(L, None)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd

@@ -2,7 +2,7 @@
 # trip 16: table-forward variant of the 16-bit mode (recomputing backward): parity tests, bench legs
 set -u
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_deform16.py tests/test_gpu_deform_table.py -q -m gpu -s > gpurun_out/r4_tabfwd_pytest.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_deform16.py -q -m gpu -s > gpurun_out/r4_tabfwd_pytest.log 2>&1
 echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error|worst" gpurun_out/r4_tabfwd_pytest.log | cut -c1-700 | tail -14
 timeout -k 10 600 python bench.py --no-nystrom --no-cpu-baseline --no-traffic > gpurun_out/r4_bench_tabfwd.json 2> gpurun_out/r4_bench_tabfwd.err
 echo "bench rc=$?"; python - <<'PY'

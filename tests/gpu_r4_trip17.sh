@@ -1,14 +1,17 @@
 #!/bin/bash
-# trip 17: fused BatchLoss tail - parity tests that exercise it, then A/B on both bench lines
+# trip 17: the driver's default command, timed
 set -u
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_data_parallel.py tests/test_gpu_configs.py -q -m gpu -k "batch_loss or full_model or mil_branch or two_ranks or (cfg4 and 24)" > gpurun_out/r4_bl_tests.log 2>&1
-echo "tests rc=$?"; grep -E "passed|failed|FAILED|AssertionError" gpurun_out/r4_bl_tests.log | cut -c1-300 | tail -5
-for f in 1 0 1 0; do
-  SMML_BATCHLOSS_TAIL=$f timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --no-nystrom > gpurun_out/r4_bl_$f.log 2>&1 || { echo "bench tail=$f rc=$?"; tail -3 gpurun_out/r4_bl_$f.log; continue; }
-  python - <<PY
+t0=$(date +%s)
+timeout -k 10 900 python bench.py > gpurun_out/r4_bench_default2.json 2> gpurun_out/r4_bench_default2.err
+echo "bench rc=$? seconds=$(( $(date +%s) - t0 ))"
+python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r4_bl_$f.log").read().strip().splitlines()[-1])
-print("tail=$f fp32 ms/step", round(d["ms_per_step"],3), "bags/s", round(d["value"],1), "| deform16 ms", round(d["deform16"]["ms_per_step"],3), "bags/s", round(d["deform16"]["bags_per_s"],1))
+d = json.loads(open("gpurun_out/r4_bench_default2.json").read().strip().splitlines()[-1])
+print("value", d["value"], d["ms_per_step"], "roofline frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
+for k in ("deform16", "deform16_tabfwd", "deform16_table"):
+    x = d.get(k, {})
+    print(k, x.get("bags_per_s"), x.get("ms_per_step"), x.get("speedup_vs_fp32_line"), x.get("error"))
+print("cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("sample", "")[:80])
+print("nystrom", [(l.get("workload", "")[:40], round(l.get("ms_per_step", 0), 2)) for l in d.get("nystrom", {}).get("legs", [])] if isinstance(d.get("nystrom"), dict) else d.get("nystrom"))
 PY
-done

@@ -35,12 +35,14 @@ MLP_GRAD_TOL_SMALL = 6e-2      # position-bias MLP parameter gradients of the SM
 L2_MARGIN = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # layer-2 decisions: |pre-activation| of a flipped unit <= margin x sum |W2| |h1| (+ |b2|)
 
 
-@pytest.mark.parametrize("tabfwd", [False, True])
+@pytest.mark.parametrize("tabfwd", [False, "table", "recompute"])
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-def test_fused_core16_random_shapes(cuda, mode, tabfwd):
+def test_fused_core16_random_shapes(cuda, mode, tabfwd, monkeypatch):
     """The 16-bit fused core (forward + the three backward passes) on random ragged shapes - N, J off the 32 / 128 tiles, one or two
     heads per offset group, 1-D and 2-D positions, with and without dropout - against plain torch in fp64 with the kernels' own
-    ReLU decisions and dropout mask imposed."""
+    ReLU decisions and dropout mask imposed.  tabfwd: cpb_table='forward' with the layer-2 decisions of the backward from the mask table / recomputed."""
+    if tabfwd:
+        monkeypatch.setattr(Fh, "TABLE_FORWARD_MASKS", tabfwd)
     gen = torch.Generator().manual_seed(4321)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
     forced = [(1, 1, 65, 8, 1, 0.0), (2, 33, 5, 4, 2, 0.25), (1, 129, 33, 8, 2, 0.0), (1, 300, 1, 8, 2, 0.0)]
@@ -102,15 +104,17 @@ def test_fused_core16_random_shapes(cuda, mode, tabfwd):
                 continue
             e = rel_err(g, g64); worst["d" + n] = max(worst.get("d" + n, 0.0), e)
             assert_close(tag + " d" + n, g, g64, MLP_GRAD_TOL_SMALL if n in ("w1", "b1", "w2", "b2", "w3") else GRAD_TOL[mode])
-    print(f"\n[deform16 {mode}{' table forward' if tabfwd else ''}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    print(f"\n[deform16 {mode}{' table forward, masks: ' + tabfwd if tabfwd else ''}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
 
-@pytest.mark.parametrize("tabfwd", [False, True])
+@pytest.mark.parametrize("tabfwd", [False, "table", "recompute"])
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("train", [False, True])
-def test_deform2d_16bit_vs_oracle(cuda, mode, train, tabfwd):
+def test_deform2d_16bit_vs_oracle(cuda, mode, train, tabfwd, monkeypatch):
     """DeformCrossAttention2D(compute_dtype=...) on a 20 x 20 grid, eval and train (dropout 0.1 with the kernel's exported mask): output,
     vgrid (untouched by the mode: exact), input and parameter gradients against the fp64 oracle with the kernels' decisions imposed."""
+    if tabfwd:
+        monkeypatch.setattr(Fh, "TABLE_FORWARD_MASKS", tabfwd)
     B, Hh, Ww, C = 2, 20, 20, 128
     N = Hh * Ww
     tag = f"d2d16:{mode}:{int(train)}"
