@@ -239,8 +239,9 @@ def test_core16_dropout_decisions_ride_in_the_saved_scores(cuda):
 CFG4_GRAD_TOL = {"bf16": 2e-2, "fp16": 1e-2}
 
 
-@pytest.mark.parametrize("B,S,mode", [(2, 24, "bf16"), (1, 100, "bf16"), (2, 24, "fp16")])
-def test_cfg4_full_fusion_16bit(cuda, B, S, mode):
+@pytest.mark.parametrize("B,S,mode,table", [(2, 24, "bf16", False), (1, 100, "bf16", False), (2, 24, "fp16", False),
+                                              (2, 24, "bf16", "forward"), (1, 100, "bf16", "forward")])
+def test_cfg4_full_fusion_16bit(cuda, B, S, mode, table):
     """BASELINE config 4 as it is stated - full two-branch DeformPathomicNet on bags of 10 000 x 512 with the deformable attention computing
     in bf16 (args.deform_compute_dtype; fp32 master parameters, fp32 inputs / outputs / gradients) + cross-entropy + both BatchLosses + an
     OrthogonalLoss term: forward and every parameter gradient against the fp64 oracle with the kernels' decisions imposed (one oracle
@@ -248,7 +249,8 @@ def test_cfg4_full_fusion_16bit(cuda, B, S, mode):
     from oracle.losses import batch_loss, orthogonal_loss
     from oracle.mil import deform_pathomic_net
     from test_oracle_golden import ZERO_GRADS, pathomic_args
-    args = pathomic_args(input_path_dim=512, batch_size=B, deform_compute_dtype=mode)
+    # table = 'forward' (args.deform_cpb_table): the forward's position bias from the table, the backward's layer-2 decisions from the mask table
+    args = pathomic_args(input_path_dim=512, batch_size=B, deform_compute_dtype=mode, deform_cpb_table=table)
     net = smml.DeformPathomicNet(args)
     params = params_for(net, 17, "cfg4")
     net.load_state_dict(params)
@@ -275,7 +277,7 @@ def test_cfg4_full_fusion_16bit(cuda, B, S, mode):
     assert not odeform.DECISIONS
     o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
     o_loss.backward()
-    tag = f"cfg4/{mode} {B}x{S}x{S}"
+    tag = f"cfg4/{mode}{'/table-forward' if table else ''} {B}x{S}x{S}"
     for name, got, ref in (("features", feats, o_feats), ("haz", lg[2], o_lg[2]), ("vgrid_t", lg[4], o_lg[4]), ("vgrid_i", lg[6], o_lg[6]),
                            ("loss", loss, o_loss)):
         assert_close(f"{tag} {name}", got, ref, FWD_TOL[mode])
