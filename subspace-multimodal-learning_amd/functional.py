@@ -926,7 +926,8 @@ class _DeformAttn(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         if DECISION_TAP is not None:
             DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(),
-                                 "masks2": masks if not tabfwd else ctx.export_masks, "B": B, "N": N, "J": J, "heads": heads, "groups": groups})
+                                 "masks2": masks if not tabfwd else ctx.export_masks, "B": B, "N": N, "J": J, "heads": heads, "groups": groups,
+                                 "table_pmax": table_pmax_fwd})
         return out
 
     @staticmethod
@@ -1051,7 +1052,7 @@ class _DeformAttnTable(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, vs, gq, table, out, lse, logits)
         if DECISION_TAP is not None:       # no per-pair ReLU decisions in this mode: the MLP runs on grid points only
             DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "masks2": None, "B": B, "N": N, "J": J,
-                                 "heads": heads, "groups": groups})
+                                 "heads": heads, "groups": groups, "table_pmax": float(pmax)})
         return out
 
     @staticmethod

@@ -307,6 +307,30 @@ def test_deform1d_table_vs_oracle(cuda, mode):
         assert_close(tag + " d" + k, p.grad, pref[k].grad, TABLE_MLP_TOL if "rel_pos_bias" in k else GRAD_TOL)
 
 
+@pytest.mark.parametrize("shape", [(20, 20), (7, 33), (33, 7), (4, 4), (50, 4)])
+@pytest.mark.parametrize("which", ["forward", True])
+def test_module_table_range_covers_the_positions(cuda, shape, which):
+    """The tables span [-pmax, pmax] with pmax derived by the MODULE from the grids' shapes and tanh . offset_scale (no host sync); a position beyond
+    it would silently take the edge value.  For square, non-square (normalize_grid divides x by rows - 1: |gq| > 1) and tiny grids, with the
+    offsets network driven into saturation, every signed-log offset of the launch lies inside the range the module chose."""
+    Hh, Ww = shape
+    B, C, N = 2, 128, Hh * Ww
+    mod = smml.DeformCrossAttention2D(dim=C, grid_hw=(Hh, Ww), compute_dtype="bf16", cpb_table=which)
+    params = params_for(mod, 41, f"range:{Hh}x{Ww}")
+    params["to_offsets.2.weight"] = params["to_offsets.2.weight"] * 200.0          # tanh saturates: offsets reach +-offset_scale
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).eval()
+    x1 = synth.normal((B, C, N), 41, "range:x1") * 3.0; x2 = synth.normal((B, C, N), 41, "range:x2")
+    with decision_tap() as tap:
+        with torch.no_grad():
+            mod(x1.to(cuda), x2.to(cuda))
+    a = [e for e in tap.entries if e["kind"] == "attn"][0]
+    pos = a["gq"][None, :, None, :] - a["vs"][:, None, :, :]
+    pmax_seen = float(torch.log1p(pos.abs()).max())
+    assert a["table_pmax"] is not None and pmax_seen <= a["table_pmax"], f"{shape}: positions reach {pmax_seen:.4f}, the tables end at {a['table_pmax']:.4f}"
+    assert a["table_pmax"] < pmax_seen * 1.6 + 0.2, f"{shape}: the range {a['table_pmax']:.3f} wastes resolution (positions reach {pmax_seen:.3f})"
+
+
 def test_table_mode_needs_a_16bit_dtype():
     with pytest.raises(ValueError):
         smml.DeformCrossAttention2D(dim=128, cpb_table=True)
