@@ -1,7 +1,7 @@
 """Oracle (TEST INFRASTRUCTURE ONLY): co-attention returning raw scores, and the gated bilinear fusion.
 
 Plain PyTorch fp32 restatement of
-  models/MultiheadAttention.py:116-321  multi_head_attention_forward (need_raw path, no masks, dropout off)
+  models/MultiheadAttention.py:116-321  multi_head_attention_forward (need_raw path, optional masks, dropout off)
   models/fusion.py:6-63                 BilinearFusion (eval-mode BatchNorm / Dropout, or batch statistics)
 """
 from __future__ import annotations
@@ -14,8 +14,10 @@ import torch.nn.functional as F
 Params = Dict[str, torch.Tensor]
 
 
-def coattention(query, key, value, p: Params, num_heads: int = 1):
-    """query [L, B, E], key/value [S, B, E] -> (out [L, B, E], raw pre-softmax scores [B, h, L, S])."""
+def coattention(query, key, value, p: Params, num_heads: int = 1, key_padding_mask=None, attn_mask=None):
+    """query [L, B, E], key/value [S, B, E] -> (out [L, B, E], raw pre-softmax scores [B, h, L, S]).
+    Masks as in MultiheadAttention.py:284-298: bool attn_mask [L, S] / [B h, L, S] and key_padding_mask [B, S] fill with -inf, a float attn_mask is
+    added; the raw scores returned are the masked ones."""
     L, B, E = query.shape
     S = key.shape[0]
     hd = E // num_heads
@@ -27,6 +29,11 @@ def coattention(query, key, value, p: Params, num_heads: int = 1):
     kh = k.reshape(S, B * num_heads, hd).transpose(0, 1)
     vh = v.reshape(S, B * num_heads, hd).transpose(0, 1)
     raw = qh @ kh.transpose(1, 2)
+    if attn_mask is not None:
+        am = attn_mask.unsqueeze(0) if attn_mask.dim() == 2 else attn_mask
+        raw = raw.masked_fill(am, float("-inf")) if am.dtype == torch.bool else raw + am.to(raw.dtype)
+    if key_padding_mask is not None:
+        raw = raw.reshape(B, num_heads, L, S).masked_fill(key_padding_mask.view(B, 1, 1, S), float("-inf")).reshape(B * num_heads, L, S)
     o = torch.softmax(raw, dim=-1) @ vh
     o = o.transpose(0, 1).reshape(L, B, E)
     return o @ p["out_proj.weight"].t() + p["out_proj.bias"], raw.reshape(B, num_heads, L, S)

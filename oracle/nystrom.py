@@ -50,8 +50,10 @@ def nystrom_attention(
     residual_conv_kernel: int = 33,
     return_aux: bool = False,
     per_bag_pinv_scale: bool = False,
+    mask=None,
+    eps: float = 1e-8,
 ):
-    """x [B, n, dim] -> [B, n, dim]   (NystromAttention.py:74-157, mask=None, dropout off).
+    """x [B, n, dim] -> [B, n, dim]   (NystromAttention.py:74-157, dropout off; `mask` [B, n] bool as at :84,92-96,106-118,127-133).
 
     Parameters: 'to_qkv.weight' [3*inner, dim], 'to_out.0.weight' [dim, inner], 'to_out.0.bias',
     'res_conv.weight' [heads, 1, k, 1]."""
@@ -63,19 +65,35 @@ def nystrom_attention(
     pad = (m - n % m) % m
     if pad:
         x = F.pad(x, (0, 0, pad, 0))                       # zero rows in FRONT (:82)
+        if mask is not None:
+            mask = F.pad(mask, (pad, 0), value=False)
     npad = n + pad
 
     qkv = x @ p["to_qkv.weight"].t()
     q, k, v = (t.reshape(B, npad, heads, dim_head).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    if mask is not None:                                   # :92-96
+        mk = mask.to(torch.bool).reshape(B, 1, npad)
+        q, k, v = (t * mk[..., None].to(t.dtype) for t in (q, k, v))
     q = q * scale
 
     l = math.ceil(n / m)                                   # segment length (:102)
-    ql = q.reshape(B, heads, npad // l, l, dim_head).sum(dim=3) / l
-    kl = k.reshape(B, heads, npad // l, l, dim_head).sum(dim=3) / l
+    div = l
+    if mask is not None:                                   # masked mean (:106-118)
+        msum = mk.reshape(B, 1, npad // l, l).sum(dim=-1)
+        div = msum[..., None].to(q.dtype) + eps
+        mland = msum > 0
+    ql = q.reshape(B, heads, npad // l, l, dim_head).sum(dim=3) / div
+    kl = k.reshape(B, heads, npad // l, l, dim_head).sum(dim=3) / div
 
-    a1 = torch.softmax(q @ kl.transpose(-1, -2), dim=-1)   # [B, h, n', m]
-    a2 = torch.softmax(ql @ kl.transpose(-1, -2), dim=-1)  # [B, h, m, m]
-    a3 = torch.softmax(ql @ k.transpose(-1, -2), dim=-1)   # [B, h, m, n']
+    s1, s2, s3 = q @ kl.transpose(-1, -2), ql @ kl.transpose(-1, -2), ql @ k.transpose(-1, -2)
+    if mask is not None:                                   # :127-133
+        neg = -torch.finfo(q.dtype).max
+        s1 = s1.masked_fill(~(mk[..., None] & mland[..., None, :]), neg)
+        s2 = s2.masked_fill(~(mland[..., None] & mland[..., None, :]), neg)
+        s3 = s3.masked_fill(~(mland[..., None] & mk[..., None, :]), neg)
+    a1 = torch.softmax(s1, dim=-1)                         # [B, h, n', m]
+    a2 = torch.softmax(s2, dim=-1)                         # [B, h, m, m]
+    a3 = torch.softmax(s3, dim=-1)                         # [B, h, m, n']
     a2i = pinv_newton_schulz(a2, pinv_iterations, per_bag_pinv_scale)
 
     out = (a1 @ a2i) @ (a3 @ v)                            # :140

@@ -5,7 +5,7 @@ G_in_P_Att (models/model.py:748-750,809-818), always with embed_dim 256, one hea
 
 Same constructor, forward signature, return tuple and parameter names (in_proj_weight, in_proj_bias,
 out_proj.weight/bias).  In-projections, Q K^T, softmax, P V and the out-projection run on the HIP kernels.
-Not built (raise): key_padding_mask / attn_mask, add_bias_kv, add_zero_attn, kdim/vdim != embed_dim - no caller in
+Not built (raise): add_bias_kv, add_zero_attn, kdim/vdim != embed_dim - no caller in
 the reference uses them.  The reference's `torch.equal(query, key)` host sync (:126,130) only selects between
 algebraically identical in-projection paths and is not reproduced."""
 from __future__ import annotations
@@ -50,8 +50,6 @@ class MultiheadAttention(nn.Module):
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, need_raw=True, attn_mask=None):
         """query [L, B, E], key / value [S, B, E] (sequence first) -> (out [L, B, E], raw scores [B, h, L, S])."""
-        if key_padding_mask is not None or attn_mask is not None:
-            raise NotImplementedError("masks are not built on the HIP path (no caller in the reference passes one)")
         L, B, E = query.shape
         S = key.shape[0]
         h, hd = self.num_heads, self.head_dim
@@ -68,6 +66,26 @@ class MultiheadAttention(nn.Module):
         k = heads_first(Fh.linear(key.transpose(0, 1), wk, bk), S)
         v = heads_first(Fh.linear(value.transpose(0, 1), wv, bv), S)
         raw = Fh.matmul4(q, k, tb=True, alpha=scaling)                 # (q * scaling) k^T, :284
+        # masks (MultiheadAttention.py:206-227,284-296; no caller in the reference passes one): a bool attn_mask / the key_padding_mask fill with -inf, a
+        # float attn_mask is added; the returned raw scores are the MASKED ones (:298).  [B, h, L, S]-sized elementwise work, only on this branch
+        if attn_mask is not None:
+            am = attn_mask.to(torch.bool) if attn_mask.dtype == torch.uint8 else attn_mask
+            if am.dim() == 2:
+                if tuple(am.shape) != (L, S):
+                    raise RuntimeError("The size of the 2D attn_mask is not correct.")
+                am = am.view(1, 1, L, S)
+            elif am.dim() == 3:
+                if tuple(am.shape) != (B * h, L, S):
+                    raise RuntimeError("The size of the 3D attn_mask is not correct.")
+                am = am.view(B, h, L, S)
+            else:
+                raise RuntimeError(f"attn_mask's dimension {am.dim()} is not supported")
+            raw = raw.masked_fill(am, float("-inf")) if am.dtype == torch.bool else raw + am.to(raw.dtype)
+        if key_padding_mask is not None:
+            kpm = key_padding_mask.to(torch.bool)
+            if tuple(kpm.shape) != (B, S):
+                raise RuntimeError("key_padding_mask must be [batch, source length]")
+            raw = raw.masked_fill(kpm.view(B, 1, 1, S), float("-inf"))
         attn = Fh.softmax_rows(raw)
         if self.training and self.dropout > 0:
             attn = F.dropout(attn, p=self.dropout, training=True)

@@ -11,7 +11,7 @@ similarity products, the six Newton-Schulz iterations of the pseudo-inverse writ
 epilogues, (attn1 z)(attn3 v), output projection) runs on the matrix cores through smml_gemm_f32; softmax,
 landmark means, the 33-tap residual convolution and PPEG's merged 7x7 depthwise pass are HBM-bound kernels.
 Kept as in the reference: zero padding in FRONT of the sequence (:82), the batch-global max in the
-pseudo-inverse initialisation (:26).  Not built: the `mask` argument (no caller in the reference passes it).
+pseudo-inverse initialisation (:26).  The `mask` argument (no caller in the reference passes it) runs on the exact fp32 path only.
 
 16-bit compute mode (BASELINE configs 2 / 4 / 5 quote bf16 / fp16 bags): `compute_dtype` 'bf16' / 'fp16', or a bag that
 arrives in that dtype, routes the n'-sized contractions to the 16-bit matrix pipe with fp32 storage and accumulation:
@@ -175,29 +175,46 @@ class NystromAttention(nn.Module):
         return "f16" if mode == "fp16" else "bf16"
 
     def forward(self, x, mask=None, return_attn=False):
-        if mask is not None:
-            raise NotImplementedError("the mask argument is not built on the HIP path (no caller in the reference uses it)")
         b, n, dim = x.shape
         h, m, d = self.heads, self.num_landmarks, self.dim_head
         pipe = self.matrix_pipe(x.dtype, return_attn)
+        if mask is not None:
+            pipe = "f32"                                       # the masked form (no caller in the reference passes one) exists on the exact path only
+            x = x.float()
         if pipe != "f32":
             return self._forward16(x, pipe == "f16")
         pad = (m - n % m) % m
         if pad:
             x = F.pad(x, (0, 0, pad, 0), value=0)              # zero rows in FRONT (:82)
+            if mask is not None:
+                mask = F.pad(mask, (pad, 0), value=False)      # (:84)
         npad = n + pad
         l = math.ceil(n / m)
         # one projection GEMM for q, k and v (M = b n', N = 3 inner), then one strided copy into the head-major layout the
         # batched products read; the softmax scale (:98) rides on the three similarity products as alpha
         qkv = Fh.linear(x, self.to_qkv.weight)                                   # [b, n', 3 h d]
         q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)   # each [b, h, n', d]
+        fill = lambda t, keep: t
+        if mask is not None:
+            # NystromAttention.py:92-96,106-118,127-133: masked tokens are zeroed in q / k / v, landmarks are means over the UNMASKED tokens of a
+            # segment, and every similarity between a masked token / an all-masked landmark and anything else is set to -finfo.max before the
+            # softmax.  Elementwise work on n'-sized tensors, on this branch only
+            mk = mask.to(torch.bool).view(b, 1, npad)
+            q, k, v = (t * mk[..., None].to(t.dtype) for t in (q, k, v))
+            msum = mk.view(b, 1, npad // l, l).sum(dim=-1)                      # [b, 1, m] unmasked tokens per segment
+            mland = msum > 0
+            lscale = (float(l) / (msum.to(q.dtype) + self.eps))[..., None]     # segment_mean divides by l; the masked mean by (count + eps)
+            neg = -torch.finfo(q.dtype).max
+            fill = lambda t, keep: t.masked_fill(~keep, neg)
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)  # landmarks (:102-118); ql unscaled
+        if mask is not None:
+            ql, kl = ql * lscale, kl * lscale
         sc = self.scale
-        a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))      # [b, h, m, m]
+        a2 = Fh.softmax_rows(fill(Fh.matmul4(ql, kl, tb=True, alpha=sc), (mland[..., None] & mland[..., None, :]) if mask is not None else None))   # [b, h, m, m]
         fork = _PinvFork(a2)                                   # the pseudo-inverse runs beside the n'-sized products below
         z = fork.run(lambda t: moore_penrose_iter_pinv(t, self.pinv_iterations, self.per_bag_pinv_scale), a2)
-        a1 = Fh.softmax_rows(Fh.matmul4(q, kl, tb=True, alpha=sc))       # [b, h, n', m]
-        a3 = Fh.softmax_rows(Fh.matmul4(ql, k, tb=True, alpha=sc))       # [b, h, m, n']
+        a1 = Fh.softmax_rows(fill(Fh.matmul4(q, kl, tb=True, alpha=sc), (mk[..., None] & mland[..., None, :]) if mask is not None else None))       # [b, h, n', m]
+        a3 = Fh.softmax_rows(fill(Fh.matmul4(ql, k, tb=True, alpha=sc), (mland[..., None] & mk[..., None, :]) if mask is not None else None))       # [b, h, m, n']
         right = Fh.matmul4(a3, v)                              # [b, h, m, d]
         res = Fh.resconv(v, self.res_conv.weight) if self.residual else None
         fork.join(z)

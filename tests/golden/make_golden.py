@@ -230,6 +230,64 @@ def case_nystrom(check):
         report("pinv", pinv_newton_schulz(a2, 6), z)
 
 
+def option_masks(tag, *shape, frac=0.25):
+    """Deterministic bool mask with ~frac True entries (a portable function of the synth stream)."""
+    return synth.normal(shape, 42, tag) > 0.6745 * (1.0 if frac == 0.25 else 0.0)
+
+
+def case_options(check):
+    """Arguments of the path's modules that no caller in the reference passes, pinned by the reference all the same: the co-attention masks
+    (models/MultiheadAttention.py:206-227,284-296) and the NystromAttention mask (models/NystromAttention.py:84,92-96,106-118,127-133)."""
+    from models.MultiheadAttention import MultiheadAttention
+    from models.NystromAttention import NystromAttention
+    from oracle.coattn import coattention
+    from oracle.nystrom import nystrom_attention
+    tag, L, S, B = "coattn_masked_L37_S50", 37, 50, 2
+    mod = MultiheadAttention(embed_dim=256, num_heads=1).eval()
+    params = load_synth(mod, 42, tag)
+    q = synth.normal((L, B, 256), 42, tag + ":q").requires_grad_()
+    kv = synth.normal((S, B, 256), 42, tag + ":kv").requires_grad_()
+    w_o = synth.normal((L, B, 256), 42, tag + ":wo")
+    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[0, -7:] = True; kpm[1, :3] = True          # True = ignored key
+    am = option_masks(tag + ":am", L, S); am[:, 10] = False                                    # True = not allowed; no row is fully masked
+    out, raw = mod(q, kv, kv, key_padding_mask=kpm, attn_mask=am)
+    (out * w_o).sum().backward()
+    q64 = q.detach().double().requires_grad_(); kv64 = kv.detach().double().requires_grad_()
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    o64, r64 = coattention(q64, kv64, kv64, p64, key_padding_mask=kpm, attn_mask=am)
+    (o64 * w_o.double()).sum().backward()
+    fin = torch.isfinite(raw)
+    assert torch.equal(fin, torch.isfinite(r64)) and not bool(fin.all())
+    payload = {"out": summarize(out, o64), "raw_finite": summarize(torch.where(fin, raw, torch.zeros_like(raw)), torch.where(fin, r64, torch.zeros_like(r64))),
+               "masked_count": np.int64(int((~fin).sum())), "dq": summarize(q.grad, q64.grad), "dkv": summarize(kv.grad, kv64.grad)}
+    for k, g in grads_of(mod).items():
+        payload["grad:" + k] = summarize(g, p64[k].grad)
+    save(tag, payload)
+    if check:
+        report(tag + " out", o64.float(), out); report(tag + " dkv", kv64.grad.float(), kv.grad)
+    for tag, B, n, dim, dh, m in (("nystrom_masked_n37_m16", 2, 37, 64, 8, 16), ("nystrom_masked_n64_m16", 2, 64, 64, 8, 16)):
+        mod = NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, pinv_iterations=6, residual=True, dropout=0.1).eval()
+        params = load_synth(mod, 42, tag)
+        x = synth.normal((B, n, dim), 42, tag + ":x").requires_grad_()
+        w_out = synth.normal((B, n, dim), 42, tag + ":wout")
+        mask = ~option_masks(tag + ":mask", B, n)                   # True = token takes part
+        mask[0, :5] = False                                        # a whole segment of bag 0 masked out (an all-masked landmark)
+        out = mod(x, mask=mask)
+        (out * w_out).sum().backward()
+        payload = {"out": summarize(out), "dx": summarize(x.grad), "kept": np.int64(int(mask.sum()))}
+        for k, g in grads_of(mod).items():
+            payload["grad:" + k] = summarize(g)
+        save(tag, payload)
+        if check:
+            a = x.detach().clone().requires_grad_()
+            po = {k: v.clone().requires_grad_() for k, v in params.items()}
+            o2 = nystrom_attention(a, po, heads=8, dim_head=dh, num_landmarks=m, mask=mask)
+            (o2 * w_out).sum().backward()
+            report(tag + " out", o2, out); report(tag + " dx", a.grad, x.grad)
+            for k, g in grads_of(mod).items():
+                report(tag + " d" + k, po[k].grad, g)
+
+
 def case_translayer(check):
     from models.cmta_utils import TransLayer, PPEG
     from oracle.nystrom import trans_layer, ppeg
@@ -539,7 +597,7 @@ if __name__ == "__main__":
     install_stubs()
     cases = {"deform2d": case_deform2d, "deform1d": case_deform1d, "nystrom": case_nystrom,
              "translayer": case_translayer, "pathomic": case_pathomic, "losses": case_losses,
-             "coattn": case_coattn_fusion, "cmta": case_cmta, "gradmod": case_gradmod, "fixdim": case_fixdim}
+             "coattn": case_coattn_fusion, "cmta": case_cmta, "gradmod": case_gradmod, "fixdim": case_fixdim, "options": case_options}
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):
             continue

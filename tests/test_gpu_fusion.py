@@ -26,6 +26,42 @@ def test_coattention_golden(cuda, tag, L, S, B):
         g.check("grad:" + k, p.grad, what="d" + k)
 
 
+def test_coattention_masked_golden(cuda):
+    """key_padding_mask + bool attn_mask against the reference's own output (tests/golden/make_golden.py::case_options)."""
+    from test_oracle_golden import coattn_masks
+    tag, L, S, B = "coattn_masked_L37_S50", 37, 50, 2
+    g = Golden(tag)
+    mod = smml.MultiheadAttention(embed_dim=256, num_heads=1)
+    mod = _load(mod, params_for(mod, 42, tag), cuda)
+    q = synth.normal((L, B, 256), 42, tag + ":q").to(cuda).requires_grad_()
+    kv = synth.normal((S, B, 256), 42, tag + ":kv").to(cuda).requires_grad_()
+    w_o = synth.normal((L, B, 256), 42, tag + ":wo").to(cuda)
+    kpm, am = coattn_masks(tag, L, S, B)
+    out, raw = mod(q, kv, kv, key_padding_mask=kpm.to(cuda), attn_mask=am.to(cuda))
+    (out * w_o).sum().backward()
+    fin = torch.isfinite(raw)
+    assert int((~fin).sum()) == int(g.scalar("masked_count"))
+    g.check("out", out); g.check("raw_finite", torch.where(fin, raw, torch.zeros_like(raw))); g.check("dq", q.grad); g.check("dkv", kv.grad)
+    for k, p in mod.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
+def test_coattention_float_mask_and_multi_head_vs_torch(cuda):
+    """Additive float attn_mask, 3-D per-head mask and key_padding_mask with four heads against torch.nn.MultiheadAttention."""
+    torch.manual_seed(1)
+    ref = torch.nn.MultiheadAttention(64, 4)
+    mod = smml.MultiheadAttention(64, 4)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(cuda).eval()
+    L, S, B = 10, 33, 3
+    q, k = torch.randn(L, B, 64), torch.randn(S, B, 64)
+    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[:, -4:] = True
+    for am in (torch.randn(L, S), torch.randn(B * 4, L, S) > 1.0):
+        o_ref, w_ref = ref(q, k, k, need_weights=True, key_padding_mask=kpm, attn_mask=am)
+        o, w = mod(q.to(cuda), k.to(cuda), k.to(cuda), need_raw=False, key_padding_mask=kpm.to(cuda), attn_mask=am.to(cuda))
+        _assert_close("masked mha out", o, o_ref, 1e-5); _assert_close("masked mha weights", w, w_ref, 1e-5)
+
+
 def test_coattention_multi_head_vs_torch(cuda):
     torch.manual_seed(0)
     ref = torch.nn.MultiheadAttention(64, 4)

@@ -78,6 +78,24 @@ def test_nystrom_golden(cuda, tag, B, n, dim, dh, m):
         g.check("grad:" + k, p.grad, what="d" + k)
 
 
+@pytest.mark.parametrize("tag,B,n,dim,dh,m", [("nystrom_masked_n37_m16", 2, 37, 64, 8, 16), ("nystrom_masked_n64_m16", 2, 64, 64, 8, 16)])
+def test_nystrom_masked_golden(cuda, tag, B, n, dim, dh, m):
+    """The `mask` argument (models/NystromAttention.py:84,92-96,106-118,127-133) against the reference's own output; a bf16 bag with a mask takes
+    the exact path too."""
+    from test_oracle_golden import option_masks
+    g = Golden(tag)
+    mod = smml.NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, pinv_iterations=6, residual=True, dropout=0.1)
+    mod = _load(mod, params_for(mod, 42, tag), cuda)
+    x = synth.normal((B, n, dim), 42, tag + ":x").to(cuda).requires_grad_()
+    w_out = synth.normal((B, n, dim), 42, tag + ":wout").to(cuda)
+    mask = ~option_masks(tag + ":mask", B, n); mask[0, :5] = False
+    out = mod(x, mask=mask.to(cuda))
+    (out * w_out).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    for k, p in mod.named_parameters():
+        g.check("grad:" + k, p.grad, what="d" + k)
+
+
 def test_pinv_translayer_ppeg_golden(cuda):
     a2 = torch.softmax(synth.normal((2, 3, 16, 16), 42, "pinv:x"), dim=-1)
     Golden("pinv_m16").check("z", smml.moore_penrose_iter_pinv(a2.to(cuda), 6))

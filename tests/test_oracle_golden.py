@@ -95,6 +95,52 @@ def test_nystrom(tag, B, n, dim, dh, m):
     _check_grads(g, p)
 
 
+def option_masks(tag, *shape):
+    """The masks tests/golden/make_golden.py::case_options fed the reference (a portable function of the synth stream)."""
+    return synth.normal(shape, 42, tag) > 0.6745
+
+
+@pytest.mark.parametrize("tag,B,n,dim,dh,m", [("nystrom_masked_n37_m16", 2, 37, 64, 8, 16), ("nystrom_masked_n64_m16", 2, 64, 64, 8, 16)])
+def test_nystrom_masked(tag, B, n, dim, dh, m):
+    """NystromAttention's `mask` argument (models/NystromAttention.py:84,92-96,106-118,127-133; no caller in the reference passes it), incl. a
+    landmark whose whole segment is masked."""
+    g = Golden(tag)
+    p = _req(params_for(_NysShapes(dim, dh), 42, tag))
+    x = synth.normal((B, n, dim), 42, tag + ":x").requires_grad_()
+    w_out = synth.normal((B, n, dim), 42, tag + ":wout")
+    mask = ~option_masks(tag + ":mask", B, n); mask[0, :5] = False
+    assert int(mask.sum()) == int(g.scalar("kept"))
+    out = nystrom_attention(x, p, heads=8, dim_head=dh, num_landmarks=m, mask=mask)
+    (out * w_out).sum().backward()
+    g.check("out", out); g.check("dx", x.grad)
+    _check_grads(g, p)
+
+
+def coattn_masks(tag, L, S, B):
+    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[0, -7:] = True; kpm[1, :3] = True
+    am = option_masks(tag + ":am", L, S); am[:, 10] = False
+    return kpm, am
+
+
+def test_coattention_masked():
+    """key_padding_mask + bool attn_mask of the co-attention (models/MultiheadAttention.py:206-227,284-296); the raw scores returned are the masked
+    ones (-inf where masked)."""
+    from oracle.coattn import coattention
+    tag, L, S, B = "coattn_masked_L37_S50", 37, 50, 2
+    g = Golden(tag)
+    p = _req(params_for(smml.MultiheadAttention(256, 1), 42, tag))
+    q = synth.normal((L, B, 256), 42, tag + ":q").requires_grad_()
+    kv = synth.normal((S, B, 256), 42, tag + ":kv").requires_grad_()
+    w_o = synth.normal((L, B, 256), 42, tag + ":wo")
+    kpm, am = coattn_masks(tag, L, S, B)
+    out, raw = coattention(q, kv, kv, p, key_padding_mask=kpm, attn_mask=am)
+    (out * w_o).sum().backward()
+    fin = torch.isfinite(raw)
+    assert int((~fin).sum()) == int(g.scalar("masked_count"))
+    g.check("out", out); g.check("raw_finite", torch.where(fin, raw, torch.zeros_like(raw))); g.check("dq", q.grad); g.check("dkv", kv.grad)
+    _check_grads(g, p)
+
+
 def test_pinv_and_translayer_and_ppeg():
     a2 = torch.softmax(synth.normal((2, 3, 16, 16), 42, "pinv:x"), dim=-1)
     Golden("pinv_m16").check("z", pinv_newton_schulz(a2, 6))
