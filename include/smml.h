@@ -139,6 +139,11 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
  * its other consumer, the fused attention core) instead of overwriting it - one pass over the [B, N, 512] tensor instead of a store plus an
  * elementwise add; 0 (default) restores overwriting.  Thread-local, like smml_deform_attn_set_seed_offset. */
 void smml_offsets_bwd_accumulate_dq(int on);
+/* Position transform of the continuous position bias: log_distance = 0 makes the fused-attention launches (fp32-grade and 16-bit, forward, backward
+ * and smml_deform_attn_relu1_masks) of this host thread with posdim 1 feed the bias MLP the raw offset gq - vs instead of
+ * sign(d) log(|d| + 1) - DeformableAttention1D.py:92 with cpb_log_distance = False; 1 (default) restores the signed log.  posdim 2 has no such
+ * switch in the reference; the table modes are signed-log only. */
+void smml_deform_attn_set_log_distance(int log_distance);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear sampling = F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) of the

@@ -63,6 +63,7 @@ SIGNATURES = {
     "smml_deform_attn_bwd_f32": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
     "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
     "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
+    "smml_deform_attn_set_log_distance": (None, [_i]),
     "smml_deform_attn16_export_masks": (None, [_f]),
     "smml_cpb_mask_table_cells": (_i, [_i]),
     "smml_cpb_mask_table": (_i, [_f, _f, _f, _f, _f, _i, _fl, _f]),

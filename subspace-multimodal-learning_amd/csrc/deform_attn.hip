@@ -31,12 +31,14 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int PD, bool SAVE>
+template <int PDX, bool SAVE>
 __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ VS, const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O,
     float* __restrict__ LSE, float* __restrict__ LT, unsigned short* __restrict__ MK, int N, int J, int H, int G, int NST,
     float scale, DropCfg dc_in) {
+  constexpr int PD = PosCfg<PDX>::PD;
+  constexpr bool RAW = PosCfg<PDX>::RAW;
   const DropCfg dc = drop_resolve(dc_in);
 #if SMML_FWD_QK16
   __shared__ __attribute__((aligned(16))) _Float16 Kp[2][KT * FRLD];         // K tile, fp16 hi / lo planes, row image (A operand of S^T)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
     // fewest vector instructions: b2 rides in as the chain's initial accumulator, no register copies.
     const int nk = min(KT, J - j0);
     auto bias_chain = [&](int jj, bool store_mask) {
-      const float p0 = slog1p(gq0 - vsl[jj][0]);
+      const float p0 = pos_of<RAW>(gq0 - vsl[jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[jj][1]) : 0.f;
       floatx16 d = b2acc;
       // layer 1 on the matrix pipe, ReLU, fp16 hi / lo split, five MFMAs per K-block
@@ -729,12 +731,14 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
 // fixed order (deterministic).   slab layout: dW2[1024] | dW1[32*2] | db1[32] | db2[32] | dW3[32] | db3[1]  (+pad)
 // ------------------------------------------------------------------------------------------------
 
-template <int PD>
+template <int PDX>
 __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     const float* __restrict__ dLT, const unsigned short* __restrict__ MK, const float* __restrict__ LT,
     const float* __restrict__ LSE, const float* __restrict__ RHO, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H,
     int G, int NST) {
+  constexpr int PD = PosCfg<PDX>::PD;
+  constexpr bool RAW = PosCfg<PDX>::RAW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // layout: tab[2][2][16] | per wave: xq[2][32], stg[16][65] float2 | red[CPB_SLAB]
   // d vs: every wave writes the sums over its 32 queries, 16 keys at a time, to its own slab row [wg * WAVES + wave][J][2];
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;                                          // for the channel-major stage (both halves store the same value)
     const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = slog1p(d0);
+    const float p0 = pos_of<RAW>(d0);
     const float p1 = (PD == 2) ? slog1p(d1) : 0.f;
 
     // ---- layer 1 on the matrix pipe, in both layouts ----
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
       // reference's gradient vanish where a query sits exactly on a sample position (DeformableAttention2D.py:148 through
       // torch.sign / torch.abs).  Kept: [x != 0] as clamp(|x| 2^100), one fast-class multiply (subnormal distances aside).
       float2 v;
-      v.x = -(dp0v[0] + dp0v[1]) * dbl * (srcp(fabsf(d0) + 1.f) * fminf(fmaxf(fabsf(d0) * big, 0.f), 1.f));
+      v.x = -(dp0v[0] + dp0v[1]) * dbl * dpos_of<RAW>(d0, big);
       v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbl * (srcp(fabsf(d1) + 1.f) * fminf(fmaxf(fabsf(d1) * big, 0.f), 1.f)) : 0.f;
       stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
     }
@@ -1076,10 +1080,12 @@ __global__ __launch_bounds__(256, 2) void cpb_bwd_kernel(
 // backward evaluate them, in the bit layout of the saved layer-2 masks (hidden channel acc_row(r, half) at bit (13 + r) % 16):
 // masks [B * G, J, 2, NST] uint16.  Parity tests impose these decisions (and the saved layer-2 bits) on the fp64 oracle, so that
 // a gradient comparison no longer depends on which way a rounding-level tie of a pre-activation fell.
-template <int PD>
+template <int PDX>
 __global__ __launch_bounds__(256) void relu1_masks_kernel(const float* __restrict__ VS, const float* __restrict__ GQ,
                                                           const float* __restrict__ w1, const float* __restrict__ b1,
                                                           unsigned short* __restrict__ MK, int N, int J, int G, int NST) {
+  constexpr int PD = PosCfg<PDX>::PD;
+  constexpr bool RAW = PosCfg<PDX>::RAW;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int b = blockIdx.z, g = blockIdx.y;
   const int q0 = blockIdx.x * (QT * WAVES) + wave * QT;
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(256) void relu1_masks_kernel(const float* __restric
   const float* VSb = VS + (size_t)(b * G + g) * J * PD;
   unsigned short* MKb = MK + ((size_t)(b * G + g) * J * 2 + hf) * NST;
   for (int j = 0; j < J; ++j) {
-    const float p0 = slog1p(gq0 - VSb[(size_t)j * PD]);
+    const float p0 = pos_of<RAW>(gq0 - VSb[(size_t)j * PD]);
     const float p1 = (PD == 2) ? slog1p(gq1 - VSb[(size_t)j * PD + 1]) : 0.f;
     const floatx16 xacc = cpb_layer1_q(a1, cpb_split_pos(p0, p1), hf, b1acc);
     unsigned m = 0;
@@ -1119,6 +1125,8 @@ __global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long to
 // seed offset of the calling host thread's next launches (read by make_drop in deform_common.h, also from deform_attn16.hip)
 static thread_local const unsigned long long* t_seed_offset = nullptr;
 const unsigned long long* smml_internal_seed_offset() { return t_seed_offset; }
+static thread_local int t_raw_distance = 0;       // smml_deform_attn_set_log_distance
+int smml_internal_pdx(int posdim) { return posdim == 2 ? 2 : (t_raw_distance ? 3 : 1); }
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -1130,6 +1138,9 @@ extern "C" {
 int smml_deform_attn_nst(int N) { return (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
 
 void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset) { t_seed_offset = device_offset; }
+// log_distance = 0: the fused-attention launches of this host thread with posdim 1 feed the bias MLP the RAW offset gq - vs instead of its signed
+// log (DeformableAttention1D.py:92, cpb_log_distance = False); 1 (default): the signed log.  posdim 2 has no such switch in the reference.
+void smml_deform_attn_set_log_distance(int log_distance) { t_raw_distance = log_distance ? 0 : 1; }
 
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
                                       void* stream) {
@@ -1150,6 +1161,8 @@ int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* 
   const int nst = smml_deform_attn_nst(N);
   if (posdim == 2)
     hipLaunchKernelGGL(relu1_masks_kernel<2>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
+  else if (smml_internal_pdx(posdim) == 3)
+    hipLaunchKernelGGL(relu1_masks_kernel<3>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
   else
     hipLaunchKernelGGL(relu1_masks_kernel<1>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
   SMML_LAUNCH_CHECK("smml_deform_attn_relu1_masks");
@@ -1193,6 +1206,12 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
                        relu_masks, N, J, H, G, nst, scale, dc);
   else if (posdim == 2)
     hipLaunchKernelGGL((deform_attn_fwd_kernel<2, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
+  else if (smml_internal_pdx(posdim) == 3 && relu_masks)         // 1-D, raw offsets (cpb_log_distance = False)
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<3, true>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
+                       relu_masks, N, J, H, G, nst, scale, dc);
+  else if (smml_internal_pdx(posdim) == 3)
+    hipLaunchKernelGGL((deform_attn_fwd_kernel<3, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
                        relu_masks, N, J, H, G, nst, scale, dc);
   else if (relu_masks)
     hipLaunchKernelGGL((deform_attn_fwd_kernel<1, true>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
@@ -1257,6 +1276,9 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
     if (posdim == 2)
       hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
+                         wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
+    else if (smml_internal_pdx(posdim) == 3)
+      hipLaunchKernelGGL(cpb_bwd_kernel<3>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
                          wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
     else
       hipLaunchKernelGGL(cpb_bwd_kernel<1>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,

@@ -109,11 +109,13 @@ struct TabCfg {
 };
 template <int PD, int TG> constexpr int tab_cells() { return TG <= 0 ? 1 : (PD == 2 ? TG * TG : TG); }
 
-template <int PD, bool SAVE, typename T, int TG = 0>
+template <int PDX, bool SAVE, typename T, int TG = 0>
 __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, float* __restrict__ O, float* __restrict__ LSE, u16* __restrict__ LT,
     u16* __restrict__ MK, int N, int J, int H, int G, int NST, float scale, DropCfg dc_in, TabCfg tc = TabCfg{}) {
+  constexpr int PD = PosCfg<PDX>::PD;
+  constexpr bool RAW = PosCfg<PDX>::RAW;           // table modes (TG > 0) are built for the signed-log form only
   typedef typename Vec8<T>::type vec8;
   const DropCfg dc = drop_resolve(dc_in);
   __shared__ float tabl[tab_cells<PD, TG>()];                          // table mode: this head's bias table
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, SMML16_FWD_WPS) void deform16_fwd_kernel(
     // keys per trip so that the scheduler can fill one chain's MFMA latencies with the other's vector work (padded keys of a ragged tile
     // compute on zero positions; only their mask store is guarded)
     auto bias_chain = [&](int jj, bool store_mask) {
-      const float p0 = slog1p(gq0 - vsl[buf][jj][0]);
+      const float p0 = pos_of<RAW>(gq0 - vsl[buf][jj][0]);
       const float p1 = (PD == 2) ? slog1p(gq1 - vsl[buf][jj][1]) : 0.f;
       floatx16 d = b2acc;
       const floatx16 xacc = cpb_layer1_q(a1, cpb_split_pos(p0, p1), hf, b1acc);
@@ -687,11 +689,13 @@ struct MaskTab {
   const u16* tab;          // [cells][2 lane halves], the forward's bit layout per half
   float invh, off, imax;   // cell index along an axis = clamp(p * invh + off, 0, imax) truncated
 };
-template <int PD, int MSRC = 0, bool EXPORT = false>
+template <int PDX, int MSRC = 0, bool EXPORT = false>
 __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     const u16* __restrict__ dLT, const u16* __restrict__ MK, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, float* __restrict__ slab, float* __restrict__ dvs_slab, int N, int J, int H, int G, int NST, u16* __restrict__ MKO = nullptr,
     MaskTab mt = MaskTab{}) {
+  constexpr int PD = PosCfg<PDX>::PD;
+  constexpr bool RAW = PosCfg<PDX>::RAW;           // raw offsets: with saved masks (MSRC 0) only - the table-forward modes are signed-log
   constexpr bool RECOMP = MSRC == 1;
   constexpr int MT_BITS = (PD == 2) ? 10 : 14;      // cells per axis of the mask table: 1024 (2-D), 16384 (1-D)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
     float* xb = xq + (j & 1) * 32;
     xb[c] = dbias;
     const float d0 = gq0 - vx, d1 = gq1 - vy;
-    const float p0 = (MSRC == 2) ? p0_c : slog1p(d0);
+    const float p0 = (MSRC == 2) ? p0_c : pos_of<RAW>(d0);
     const float p1 = (PD == 2) ? ((MSRC == 2) ? p1_c : slog1p(d1)) : 0.f;
 
     floatx16 xacc, ht;
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(256, SMML16_CPB_WPS) void cpb16_bwd_kernel(
       dp0v[0] = dpa[0]; dp1v[0] = dpa[1];
 #endif
       float2 v;
-      v.x = -(dp0v[0] + dp0v[1]) * dbl * (srcp(fabsf(d0) + 1.f) * fminf(fmaxf(fabsf(d0) * big, 0.f), 1.f));
+      v.x = -(dp0v[0] + dp0v[1]) * dbl * dpos_of<RAW>(d0, big);
       v.y = (PD == 2) ? -(dp1v[0] + dp1v[1]) * dbl * (srcp(fabsf(d1) + 1.f) * fminf(fmaxf(fabsf(d1) * big, 0.f), 1.f)) : 0.f;
       stg[(j & (CPB2_STG_KEYS - 1)) * 65 + lane] = v;
     }
@@ -1367,6 +1371,10 @@ void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float*
     hipLaunchKernelGGL((deform16_fwd_kernel<2, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else if (posdim == 2)
     hipLaunchKernelGGL((deform16_fwd_kernel<2, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+  else if (smml_internal_pdx(posdim) == 3 && save)              // 1-D, raw offsets (cpb_log_distance = False)
+    hipLaunchKernelGGL((deform16_fwd_kernel<3, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
+  else if (smml_internal_pdx(posdim) == 3)
+    hipLaunchKernelGGL((deform16_fwd_kernel<3, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else if (save)
     hipLaunchKernelGGL((deform16_fwd_kernel<1, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else
@@ -1426,6 +1434,7 @@ TableWorkspace table_workspace(int B, int N, int J, int H, int cells) {
   return w;
 }
 int check_table(const char* fn, int posdim, int table_g, float pmax) {
+  SMML_REQUIRE(smml_internal_pdx(posdim) != 3, "%s: the table modes are built for the signed-log position transform (log_distance) only", fn);
   SMML_REQUIRE(table_g == (posdim == 2 ? TABLE_G2 : TABLE_G1), "%s: the table kernels are built for %d grid points per axis with posdim %d (got %d)",
                fn, posdim == 2 ? TABLE_G2 : TABLE_G1, posdim, table_g);
   SMML_REQUIRE(pmax > 0.f, "%s: table_pmax must be positive", fn);
@@ -1521,6 +1530,8 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     if (relu_masks) {
       if (posdim == 2)
         hipLaunchKernelGGL((cpb16_bwd_kernel<2>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
+      else if (smml_internal_pdx(posdim) == 3)
+        hipLaunchKernelGGL((cpb16_bwd_kernel<3>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
       else
         hipLaunchKernelGGL((cpb16_bwd_kernel<1>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
     } else if (g_mask_table) {          // decisions from the mask table

@@ -102,6 +102,18 @@ __device__ __forceinline__ float srcp(float x) { return 1.0f / x; }
 // tests/microbench/valu_mix_probe.hip; the factor 2 is folded into the constants downstream (powers of two: exact).
 __device__ __forceinline__ float relu2(float x) { return x + __builtin_fabsf(x); }
 
+// Position transform of the bias MLP's input.  The kernels' position-dimension template argument PDX is 1 or 2 (signed-log offsets, the
+// reference's default) or 3 = one dimension with the RAW offset (DeformableAttention1D.py:92 with cpb_log_distance = False; the 2-D module has
+// no such switch): PD = dimensions, RAW = no log.  A template value, so the default path's instruction stream does not change.
+template <int PDX> struct PosCfg {
+  static constexpr int PD = (PDX == 3) ? 1 : PDX;
+  static constexpr bool RAW = (PDX == 3);
+};
+template <bool RAW> __device__ __forceinline__ float pos_of(float d) { return RAW ? d : slog1p(d); }
+// d pos / d d (times the [d != 0] factor autograd's sign() gives the log form); `big` = 2^100
+template <bool RAW> __device__ __forceinline__ float dpos_of(float d, float big) {
+  return RAW ? 1.f : srcp(fabsf(d) + 1.f) * fminf(fmaxf(fabsf(d) * big, 0.f), 1.f);
+}
 constexpr int DH = 64;       // head dim (fixed: dim_head = 64 in both reference modules)
 constexpr int CH = 32;       // CPB hidden width = dim // 4 with dim = 128
 constexpr int QT = 32;       // queries per wave
@@ -471,6 +483,7 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
 // defined in deform_attn.hip): read into the launch's DropCfg, never dereferenced on the host.
 }  // namespace
 const unsigned long long* smml_internal_seed_offset();
+int smml_internal_pdx(int posdim);       // posdim (1 | 2) -> PDX (PosCfg), from the host thread's log-distance switch (deform_attn.hip)
 namespace {
 DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg dc;

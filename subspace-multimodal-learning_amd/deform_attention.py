@@ -208,8 +208,9 @@ class DeformCrossAttention1D(nn.Module):
         assert (offset_kernel_size - downsample_factor) % 2 == 0
         offset_groups = _default(offset_groups, heads)
         assert heads % offset_groups == 0
-        if not cpb_log_distance:
-            raise NotImplementedError("the HIP position-bias kernels implement the log-distance form only")
+        if not cpb_log_distance and cpb_table:
+            raise NotImplementedError("the table modes are built for the log-distance form of the position bias only")
+        self.cpb_log_distance = bool(cpb_log_distance)
         inner_dim = dim_head * heads
         self.scale = dim_head ** -0.5
         self.heads, self.offset_groups = heads, offset_groups
@@ -253,7 +254,8 @@ class DeformCrossAttention1D(nn.Module):
             t = vgrid.shape[-1]
             tab = {"cpb_table": self.cpb_table, "cpb_table_pmax": Fh.table_pmax(1.0, 1.0 + 2.0 * self.offset_scale / max(t - 1, 1))}
         o = Fh.deform_attention(q, k, v, vs, seq.contiguous(), *self.rel_pos_bias.tensors(), heads=H, groups=G,
-                                scale=self.scale, compute_dtype=self.compute_dtype, **tab, **_dropout_args(self, q.device))
+                                scale=self.scale, compute_dtype=self.compute_dtype, log_distance=self.cpb_log_distance, **tab,
+                                **_dropout_args(self, q.device))
         out = Fh.linear(o, self.to_out.weight.reshape(self.dim, -1), self.to_out.bias, residual=residual, prec=Fh.prec16(self.compute_dtype))
         return (out, vgrid) if return_vgrid else out
 

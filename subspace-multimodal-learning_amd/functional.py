@@ -71,14 +71,18 @@ def relu_masks_rows(masks):
     return masks.permute(0, 1, 3, 4, 2, 5).reshape(B, H, J, 2, NT * 32)
 
 
-def relu1_masks(vs, gq, w1, b1, *, B: int, N: int, J: int, groups: int):
+def relu1_masks(vs, gq, w1, b1, *, B: int, N: int, J: int, groups: int, log_distance: bool = True):
     """Layer-1 ReLU decisions of the position-bias MLP as the kernels evaluate them: int16 [(B G), J, 2, nst] in the bit order of the
     saved layer-2 masks (include/smml.h smml_deform_attn_relu1_masks).  Tests only."""
     L = capi.lib()
     nst = L.smml_deform_attn_nst(N)
     out = torch.empty(B * groups, J, 2, nst, device=vs.device, dtype=torch.int16)
-    capi.check(L.smml_deform_attn_relu1_masks(capi.fptr(_c(vs)), capi.fptr(_c(gq)), capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.ptr(out),
-                                              B, N, J, groups, vs.shape[-1], capi.stream()), "relu1_masks")
+    L.smml_deform_attn_set_log_distance(int(bool(log_distance)))
+    try:
+        capi.check(L.smml_deform_attn_relu1_masks(capi.fptr(_c(vs)), capi.fptr(_c(gq)), capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.ptr(out),
+                                                  B, N, J, groups, vs.shape[-1], capi.stream()), "relu1_masks")
+    finally:
+        L.smml_deform_attn_set_log_distance(1)
     return out
 
 
@@ -867,8 +871,11 @@ TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
-                compute_dtype=None, fork=None, table_pmax_fwd=None):
+                compute_dtype=None, fork=None, table_pmax_fwd=None, log_distance=True):
         ctx.fork = fork
+        ctx.log_distance = bool(log_distance)
+        if not log_distance and (vs.shape[-1] != 1 or table_pmax_fwd is not None):
+            raise NotImplementedError("the raw-offset position transform (cpb_log_distance=False) exists for 1-D positions without the table modes")
         q, k, v, vs, gq = _c(q), _c(k), _c(v), _c(vs), _c(gq)
         w1, b1, w2, b2, w3, b3 = (_c(t) for t in (w1, b1, w2, b2, w3, b3))
         B, N, HD = q.shape
@@ -896,6 +903,7 @@ class _DeformAttn(torch.autograd.Function):
             elif DECISION_TAP is not None:            # tests: the backward writes the decisions it recomputed here
                 ctx.export_masks = torch.zeros(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)
         _set_seed_offset(L, seed_offset)
+        L.smml_deform_attn_set_log_distance(int(ctx.log_distance))
         if tabfwd:
             if m16 is None:
                 raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
@@ -921,13 +929,14 @@ class _DeformAttn(torch.autograd.Function):
                                                 *TIMER.events("deform16_fwd", B * heads * N * J), capi.stream()),
                        "deform_attn16_fwd")
         _set_seed_offset(L, None)
+        L.smml_deform_attn_set_log_distance(1)
         ctx.seed_offset = seed_offset           # a device int64 [1] owned by this call (hipGraph replays: deform_attention)
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
         if DECISION_TAP is not None:
             DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(),
                                  "masks2": masks if not tabfwd else ctx.export_masks, "B": B, "N": N, "J": J, "heads": heads, "groups": groups,
-                                 "table_pmax": table_pmax_fwd})
+                                 "table_pmax": table_pmax_fwd, "log_distance": ctx.log_distance})
         return out
 
     @staticmethod
@@ -946,6 +955,7 @@ class _DeformAttn(torch.autograd.Function):
         wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
         _set_seed_offset(L, ctx.seed_offset)
+        L.smml_deform_attn_set_log_distance(int(ctx.log_distance))
         if m16 is None:
             capi.check(L.smml_deform_attn_bwd_f32(
                 capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
@@ -979,9 +989,10 @@ class _DeformAttn(torch.autograd.Function):
             if mtab is not None:
                 L.smml_deform_attn16_set_mask_table(None, 0.0)
         _set_seed_offset(L, None)
+        L.smml_deform_attn_set_log_distance(1)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1120,12 +1131,13 @@ def graph_seed_offset(device, allocate_only: bool = False):
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
                      dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None,
-                     cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None):
+                     cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None, log_distance: bool = True):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
     compute_dtype None: fp32-grade split products (csrc/deform_attn.hip); 'bf16' / 'fp16': the 16-bit compute mode
     (csrc/deform_attn16.hip: single-term 16-bit MFMA operands, 16-bit score storage; inputs, outputs and gradients stay fp32).
+    log_distance False (1-D positions only): the bias MLP reads the raw offset gq - vs (DeformableAttention1D.py:92, cpb_log_distance=False).
     cpb_table (with a 16-bit compute_dtype): True / 'full' - the position-bias MLP is evaluated once on a grid and interpolated per pair,
     forward and backward (include/smml.h, "table mode": approximate parameter gradients); 'forward' - only the forward takes its bias from the
     table (|error| <= ~1e-3 of the bias range, below the 16-bit operand rounding), the backward differentiates the per-pair MLP itself, recomputing
@@ -1136,6 +1148,8 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
         raise ValueError("cpb_table must be False, True / 'full' or 'forward'")
     if cpb_table and cpb_table_pmax is None:
         cpb_table_pmax = table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
+    if cpb_table and not log_distance:
+        raise NotImplementedError("the table modes are built for the signed-log position transform only")
     if cpb_table == "forward":
         return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
                                  dropout_seed_offset, compute_dtype, fork, cpb_table_pmax)
@@ -1145,7 +1159,7 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
         return _DeformAttnTable.apply(q, k, v, vs, gq, table, heads, groups, scale, dropout_p, dropout_seed, dropout_seed_offset,
                                       compute_dtype, fork, cpb_table_pmax, cpb_table_grid)
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
-                             dropout_seed_offset, compute_dtype, fork)
+                             dropout_seed_offset, compute_dtype, fork, None, log_distance)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):

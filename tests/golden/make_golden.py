@@ -237,7 +237,8 @@ def option_masks(tag, *shape, frac=0.25):
 
 def case_options(check):
     """Arguments of the path's modules that no caller in the reference passes, pinned by the reference all the same: the co-attention masks
-    (models/MultiheadAttention.py:206-227,284-296) and the NystromAttention mask (models/NystromAttention.py:84,92-96,106-118,127-133)."""
+    (models/MultiheadAttention.py:206-227,284-296), the NystromAttention mask (models/NystromAttention.py:84,92-96,106-118,127-133) and the raw-offset
+    position bias of the 1-D deformable attention (cpb_log_distance=False)."""
     from models.MultiheadAttention import MultiheadAttention
     from models.NystromAttention import NystromAttention
     from oracle.coattn import coattention
@@ -265,6 +266,37 @@ def case_options(check):
     save(tag, payload)
     if check:
         report(tag + " out", o64.float(), out); report(tag + " dkv", kv64.grad.float(), kv.grad)
+    # DeformCrossAttention1D(cpb_log_distance=False): the bias MLP reads the raw offset (models/DeformableAttention1D.py:92,118,148)
+    from models.DeformableAttention1D import DeformCrossAttention1D
+    from oracle.deform import deform_cross_attention_1d
+    for tag, B, C, n in (("deform1d_rawdist_n40", 2, 128, 40), ("deform1d_rawdist_n300", 1, 128, 300)):
+        mod = DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, cpb_log_distance=False).eval()
+        params = load_synth(mod, 42, tag)
+        x1 = synth.normal((B, C, n), 42, tag + ":x1").requires_grad_()
+        x2 = synth.normal((B, C, n), 42, tag + ":x2").requires_grad_()
+        w_out = synth.normal((B, C, n), 42, tag + ":wout")
+        out, vgrid = mod(x1, x2, return_vgrid=True)
+        w_vg = synth.normal(tuple(vgrid.shape), 42, tag + ":wvg")
+        loss = (out * w_out).sum() + (vgrid * w_vg).sum()
+        loss.backward()
+        a64 = x1.detach().double().requires_grad_(); b64 = x2.detach().double().requires_grad_()
+        p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+        with natural_scales() as ns:
+            o64, vg64 = deform_cross_attention_1d(a64, b64, p64, offset_scale=2.0, cpb_log_distance=False)
+            ((o64 * w_out.double()).sum() + (vg64 * w_vg.double()).sum()).backward()
+        payload = {"out": summarize(out, o64), "vgrid": summarize(vgrid, vg64), "loss": np.float64(loss.item()),
+                   "dx1": summarize(x1.grad, a64.grad), "dx2": summarize(x2.grad, b64.grad), **ns.payload(p64)}
+        for k, g in grads_of(mod).items():
+            payload["grad:" + k] = summarize(g, p64[k].grad)
+        save(tag, payload)
+        if check:
+            a = x1.detach().clone().requires_grad_(); b = x2.detach().clone().requires_grad_()
+            po = {k: v.clone().requires_grad_() for k, v in params.items()}
+            o2, vg2 = deform_cross_attention_1d(a, b, po, offset_scale=2.0, cpb_log_distance=False)
+            ((o2 * w_out).sum() + (vg2 * w_vg).sum()).backward()
+            report(tag + " out", o2, out); report(tag + " dx1", a.grad, x1.grad)
+            for k, g in grads_of(mod).items():
+                report(tag + " d" + k, po[k].grad, g)
     for tag, B, n, dim, dh, m in (("nystrom_masked_n37_m16", 2, 37, 64, 8, 16), ("nystrom_masked_n64_m16", 2, 64, 64, 8, 16)):
         mod = NystromAttention(dim=dim, dim_head=dh, heads=8, num_landmarks=m, pinv_iterations=6, residual=True, dropout=0.1).eval()
         params = load_synth(mod, 42, tag)

@@ -187,7 +187,7 @@ class Decisions:
         self.m1 = self.m2 = None
         if a["masks2"] is None:           # table mode of the 16-bit core: the MLP runs on grid points only, no per-pair ReLU decisions
             return
-        self.m1 = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G).cpu()          # int16 [(B G), J, 2, nst]
+        self.m1 = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G, log_distance=a.get("log_distance", True)).cpu()          # int16 [(B G), J, 2, nst]
         o = H // G                                                    # the heads of a group share layers 1 and 2: take the first
         self.m2 = Fh.relu_masks_rows(a["masks2"])[:, ::o].reshape(B * G, J, 2, -1).cpu()                    # int16 [(B G), J, 2, nst]
 

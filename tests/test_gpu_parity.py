@@ -385,6 +385,44 @@ def test_deform1d_golden(cuda, tag, B, n):
             g.check("grad:" + k, p.grad, what="d" + k)
 
 
+@pytest.mark.parametrize("tag,B,n", [("deform1d_rawdist_n40", 2, 40), ("deform1d_rawdist_n300", 1, 300)])
+@pytest.mark.parametrize("mode", [None, "bf16"])
+def test_deform1d_raw_distance_golden(cuda, tag, B, n, mode):
+    """DeformCrossAttention1D(cpb_log_distance=False) - the bias MLP reads the raw offset - against the reference's own output (fp32-grade path, the
+    golden's tolerance) and, in the 16-bit compute mode, against the fp64 oracle with the kernels' decisions imposed (that mode's tolerances)."""
+    C = 128
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, cpb_log_distance=False, compute_dtype=mode)
+    params = params_for(mod, 42, tag)
+    mod = _load(mod, params, cuda)
+    x1h = synth.normal((B, C, n), 42, tag + ":x1"); x2h = synth.normal((B, C, n), 42, tag + ":x2")
+    x1 = x1h.to(cuda).requires_grad_(); x2 = x2h.to(cuda).requires_grad_()
+    w_out = synth.normal((B, C, n), 42, tag + ":wout")
+    with decision_tap() as tap:
+        out, vgrid = mod(x1, x2, return_vgrid=True)
+    w_vg = synth.normal(tuple(vgrid.shape), 42, tag + ":wvg")
+    ((out * w_out.to(cuda)).sum() + (vgrid * w_vg.to(cuda)).sum()).backward()
+    if mode is None:
+        g = Golden(tag)
+        g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+        for k, p in mod.named_parameters():
+            if k.endswith(ZERO_GRADS):
+                assert_zero_grad(f"{g.name}:d{k}", p.grad, g.scalar("natural:" + k))
+            else:
+                g.check("grad:" + k, p.grad, what="d" + k)
+        return
+    dt = torch.float64
+    pref = {k: v.clone().to(dt).requires_grad_() for k, v in params.items()}
+    a, b = x1h.clone().to(dt).requires_grad_(), x2h.clone().to(dt).requires_grad_()
+    odeform.DECISIONS = tap.decisions()
+    o_ref, vg_ref = deform_cross_attention_1d(a, b, pref, downsample_factor=4, offset_scale=2, offset_kernel_size=6, cpb_log_distance=False)
+    ((o_ref * w_out.to(dt)).sum() + (vg_ref * w_vg.to(dt)).sum()).backward()
+    _assert_close(tag + " bf16 out", out, o_ref, 1.5e-2); _assert_close(tag + " bf16 dx1", x1.grad, a.grad, 3e-2); _assert_close(tag + " bf16 dx2", x2.grad, b.grad, 3e-2)
+    for k, p in mod.named_parameters():
+        if k.endswith(ZERO_GRADS) or pref[k].grad is None:
+            continue
+        _assert_close(f"{tag} bf16 d{k}", p.grad, pref[k].grad, 6e-2 if "rel_pos_bias" in k else 3e-2)
+
+
 def test_batch_loss_vs_oracle(cuda):
     B = 4
     g = Golden("batchloss_b4")

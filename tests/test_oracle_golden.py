@@ -73,6 +73,23 @@ def test_deform1d(tag, B, n):
     _check_grads(g, p)
 
 
+@pytest.mark.parametrize("tag,B,n", [("deform1d_rawdist_n40", 2, 40), ("deform1d_rawdist_n300", 1, 300)])
+def test_deform1d_raw_distance(tag, B, n):
+    """DeformCrossAttention1D(cpb_log_distance=False): the bias MLP reads the raw offset (DeformableAttention1D.py:92; no caller in the reference)."""
+    g = Golden(tag)
+    C = 128
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, cpb_log_distance=False)
+    p = _req(params_for(mod, 42, tag))
+    x1 = synth.normal((B, C, n), 42, tag + ":x1").requires_grad_()
+    x2 = synth.normal((B, C, n), 42, tag + ":x2").requires_grad_()
+    w_out = synth.normal((B, C, n), 42, tag + ":wout")
+    out, vgrid = deform_cross_attention_1d(x1, x2, p, offset_scale=2.0, cpb_log_distance=False)
+    w_vg = synth.normal(tuple(vgrid.shape), 42, tag + ":wvg")
+    ((out * w_out).sum() + (vgrid * w_vg).sum()).backward()
+    g.check("out", out); g.check("vgrid", vgrid); g.check("dx1", x1.grad); g.check("dx2", x2.grad)
+    _check_grads(g, p)
+
+
 class _NysShapes(torch.nn.Module):
     def __init__(self, dim, dh, heads=8, k=33):
         super().__init__()
