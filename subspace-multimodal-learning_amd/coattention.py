@@ -5,7 +5,7 @@ G_in_P_Att (models/model.py:748-750,809-818), always with embed_dim 256, one hea
 
 Same constructor, forward signature, return tuple and parameter names (in_proj_weight, in_proj_bias,
 out_proj.weight/bias).  In-projections, Q K^T, softmax, P V and the out-projection run on the HIP kernels.
-Not built (raise): add_bias_kv, add_zero_attn, kdim/vdim != embed_dim - no caller in
+Not built (raise): kdim/vdim != embed_dim - no caller in
 the reference uses them.  The reference's `torch.equal(query, key)` host sync (:126,130) only selects between
 algebraically identical in-projection paths and is not reproduced."""
 from __future__ import annotations
@@ -26,8 +26,8 @@ class MultiheadAttention(nn.Module):
         self.kdim = kdim if kdim is not None else embed_dim
         self.vdim = vdim if vdim is not None else embed_dim
         self._qkv_same_embed_dim = self.kdim == embed_dim and self.vdim == embed_dim
-        if not self._qkv_same_embed_dim or add_bias_kv or add_zero_attn:
-            raise NotImplementedError("kdim/vdim != embed_dim, add_bias_kv and add_zero_attn are not built on the HIP path")
+        if not self._qkv_same_embed_dim:
+            raise NotImplementedError("kdim/vdim != embed_dim is not built on the HIP path")
         self.num_heads = num_heads
         self.dropout = dropout
         self.head_dim = embed_dim // num_heads
@@ -38,7 +38,11 @@ class MultiheadAttention(nn.Module):
         else:
             self.register_parameter('in_proj_bias', None)
         self.out_proj = nn.modules.linear.NonDynamicallyQuantizableLinear(embed_dim, embed_dim)
-        self.bias_k = self.bias_v = None
+        if add_bias_kv:                       # MultiheadAttention.py:393-397 (no caller in the reference asks for it)
+            self.bias_k = nn.Parameter(torch.empty(1, 1, embed_dim))
+            self.bias_v = nn.Parameter(torch.empty(1, 1, embed_dim))
+        else:
+            self.bias_k = self.bias_v = None
         self.add_zero_attn = add_zero_attn
         self._reset_parameters()
 
@@ -47,6 +51,9 @@ class MultiheadAttention(nn.Module):
         if self.in_proj_bias is not None:
             constant_(self.in_proj_bias, 0.)
             constant_(self.out_proj.bias, 0.)
+        if self.bias_k is not None:
+            nn.init.xavier_normal_(self.bias_k)
+            nn.init.xavier_normal_(self.bias_v)
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, need_raw=True, attn_mask=None):
         """query [L, B, E], key / value [S, B, E] (sequence first) -> (out [L, B, E], raw scores [B, h, L, S])."""
@@ -63,8 +70,22 @@ class MultiheadAttention(nn.Module):
             return t.reshape(B, 1, n, E) if h == 1 else t.reshape(B, n, h, hd).permute(0, 2, 1, 3)
 
         q = heads_first(Fh.linear(query.transpose(0, 1), wq, bq), L)
-        k = heads_first(Fh.linear(key.transpose(0, 1), wk, bk), S)
-        v = heads_first(Fh.linear(value.transpose(0, 1), wv, bv), S)
+        kp, vp = Fh.linear(key.transpose(0, 1), wk, bk), Fh.linear(value.transpose(0, 1), wv, bv)      # [B, S, E]
+        pad_cols = 0
+        if self.bias_k is not None:           # one learned key / value row appended (:236-243); masks grow by an unmasked column
+            kp = torch.cat((kp, self.bias_k.expand(B, 1, E)), dim=1)
+            vp = torch.cat((vp, self.bias_v.expand(B, 1, E)), dim=1)
+            S += 1; pad_cols += 1
+        k, v = heads_first(kp, S), heads_first(vp, S)
+        if self.add_zero_attn:                # a zero key / value row per head (:271-279)
+            zrow = torch.zeros(B, h, 1, hd, dtype=k.dtype, device=k.device)
+            k, v = torch.cat((k, zrow), dim=2), torch.cat((v, zrow), dim=2)
+            S += 1; pad_cols += 1
+        if pad_cols:
+            if attn_mask is not None:
+                attn_mask = F.pad(attn_mask, (0, pad_cols))
+            if key_padding_mask is not None:
+                key_padding_mask = F.pad(key_padding_mask, (0, pad_cols))
         raw = Fh.matmul4(q, k, tb=True, alpha=scaling)                 # (q * scaling) k^T, :284
         # masks (MultiheadAttention.py:206-227,284-296; no caller in the reference passes one): a bool attn_mask / the key_padding_mask fill with -inf, a
         # float attn_mask is added; the returned raw scores are the MASKED ones (:298).  [B, h, L, S]-sized elementwise work, only on this branch

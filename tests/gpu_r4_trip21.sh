@@ -1,5 +1,5 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "deform1d" > gpurun_out/r4_rawdist_pytest.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_fusion.py -q -m gpu > gpurun_out/r4_rawdist_pytest.log 2>&1
 echo "pytest rc=$?"; grep -E "passed|failed|FAILED|AssertionError|Error" gpurun_out/r4_rawdist_pytest.log | cut -c1-300 | tail -12

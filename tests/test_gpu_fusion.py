@@ -62,6 +62,35 @@ def test_coattention_float_mask_and_multi_head_vs_torch(cuda):
         _assert_close("masked mha out", o, o_ref, 1e-5); _assert_close("masked mha weights", w, w_ref, 1e-5)
 
 
+@pytest.mark.parametrize("bias_kv,zero_attn", [(True, False), (False, True), (True, True)])
+def test_coattention_bias_kv_and_zero_attn_vs_torch(cuda, bias_kv, zero_attn):
+    """add_bias_kv / add_zero_attn (MultiheadAttention.py:236-243,271-279 - the reference's file is a copy of torch's functional form, so
+    torch.nn.MultiheadAttention is the pin), with masks, four heads: outputs, averaged weights and every gradient."""
+    torch.manual_seed(2)
+    ref = torch.nn.MultiheadAttention(64, 4, add_bias_kv=bias_kv, add_zero_attn=zero_attn)
+    mod = smml.MultiheadAttention(64, 4, add_bias_kv=bias_kv, add_zero_attn=zero_attn)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(cuda).eval()
+    L, S, B = 9, 21, 3
+    q, k = torch.randn(L, B, 64), torch.randn(S, B, 64)
+    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[:, -3:] = True
+    am = torch.randn(L, S) > 1.0
+    wo = torch.randn(L, B, 64)
+    qr, kr = q.clone().requires_grad_(), k.clone().requires_grad_()
+    o_ref, w_ref = ref(qr, kr, kr, need_weights=True, key_padding_mask=kpm, attn_mask=am)
+    (o_ref * wo).sum().backward()
+    qd, kd = q.to(cuda).requires_grad_(), k.to(cuda).requires_grad_()
+    o, w = mod(qd, kd, kd, need_raw=False, key_padding_mask=kpm.to(cuda), attn_mask=am.to(cuda))
+    (o * wo.to(cuda)).sum().backward()
+    _assert_close("out", o, o_ref, 1e-5); _assert_close("weights", w, w_ref, 1e-5)
+    _assert_close("dq", qd.grad, qr.grad, 1e-5); _assert_close("dk", kd.grad, kr.grad, 1e-5)
+    rp = dict(ref.named_parameters())
+    for name, p in mod.named_parameters():
+        _assert_close("d" + name, p.grad, rp[name].grad, 1e-5)
+    _, raw = mod(qd, kd, kd, key_padding_mask=kpm.to(cuda), attn_mask=am.to(cuda))
+    assert raw.shape == (B, 4, L, S + int(bias_kv) + int(zero_attn))
+
+
 def test_coattention_multi_head_vs_torch(cuda):
     torch.manual_seed(0)
     ref = torch.nn.MultiheadAttention(64, 4)
