@@ -12,7 +12,11 @@ continuous position bias over a 100 x 100 token grid / 625 sampled keys -> poole
 BatchLoss (gathered over ranks), backward, gradient all-reduce (RCCL), Adam step.  Inputs are resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0.
 After the timed region, at N = 1 only: `roofline.traffic` from two child runs of this script under rocprofv3 --pmc (FETCH_SIZE,
-WRITE_SIZE; --no-traffic skips them), the Nystrom legs (extra key `nystrom`; --no-nystrom) and the CPU baseline (--no-cpu-baseline).
+WRITE_SIZE; --no-traffic skips them), the Nystrom legs (extra key `nystrom`; --no-nystrom), the CPU baseline (--no-cpu-baseline) and three more
+legs of the SAME step with the fused attention core in its 16-bit compute mode (--no-deform16 skips them; none is part of `value`):
+  `deform16`         bf16 compute mode, per-pair position-bias MLP (parity-grade)
+  `deform16_tabfwd`  + the forward's position bias from a table of the MLP, per-pair MLP backward with mask-table decisions (parity-grade)
+  `deform16_table`   forward and backward through the table (approximate: `"approximate": true`)
 """
 from __future__ import annotations
 
