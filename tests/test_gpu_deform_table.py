@@ -9,7 +9,9 @@ Two statements are tested, separately:
  (A) the kernels compute the INTERPOLATED function and its adjoint correctly - against plain torch in fp64 evaluating the same
      interpolant (fp64 table, same grid): tolerances of the 16-bit compute mode (tests/test_gpu_deform16.py) - forward bf16 1.5e-2 /
      fp16 4e-3, gradients 3e-2 - and the six MLP gradients at the SAME 3e-2 (no per-pair 16-bit products in their path here, where the
-     MLP mode needs 6e-2 on small problems);
+     MLP mode needs 6e-2 on small problems).  d vs is the one output whose integrand is discontinuous in the position (the interpolant's
+     slope jumps at cell boundaries, as the per-pair MLP's does at a ReLU kink): a pair within fp32 rounding of a boundary is assigned to
+     either cell, so d vs is held to 1e-2 in relative l2 and 1e-1 in the max norm in the fuzz test;
  (B) how far the interpolant is from the per-pair MLP (the reference's function; fp64): forward values and the q / k / v gradients stay
      within the SAME 16-bit bounds (the interpolation error of the bias, <= ~1e-3 of its range, is below the operand rounding).  The
      gradients that pass through the interpolant's cells - d vs and the six MLP tensors - are the INTERPOLANT's own: exact for the function
@@ -78,10 +80,11 @@ def _interp_reference(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, sc
 def test_table_core_random_shapes(cuda, mode):
     """Forward + backward of the table-mode core on random ragged shapes (N, J off the tiles, one or two heads per group, 1-D and 2-D,
     with and without dropout) against (A) the fp64 interpolant and (B) the fp64 per-pair MLP."""
-    gen = torch.Generator().manual_seed(2468)
+    import os
+    gen = torch.Generator().manual_seed(int(os.environ.get("SMML_FUZZ_SEED", "2468")))      # soak: SMML_FUZZ_CASES=60 SMML_FUZZ_SEED=7 pytest -k table_core_random
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
     forced = [(1, 1, 65, 8, 1, 0.0), (2, 33, 5, 4, 2, 0.25), (1, 129, 33, 8, 2, 0.0), (1, 300, 1, 8, 2, 0.0), (2, 290, 130, 8, 2, 0.0)]
-    nrand = 8
+    nrand = int(os.environ.get("SMML_FUZZ_CASES", "8"))
     worst = {}
     names = ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")
     for case in range(nrand + len(forced)):
@@ -128,11 +131,38 @@ def test_table_core_random_shapes(cuda, mode):
                     assert e < TABLE_MLP_TOL, f"{tag} (B) d{n}: relative l2 error {e:.3e} > {TABLE_MLP_TOL}"
                     continue
                 e = rel_err(g, g64); worst[f"{which} d{n}"] = max(worst.get(f"{which} d{n}", 0.0), e)
-                assert_close(f"{tag} ({which}) d{n}", g, g64, GRAD_TOL)
+                if which == "A" and n == "vs":
+                    # the interpolant's slope jumps at cell boundaries: a pair whose position lies within fp32 rounding of one is assigned to either
+                    # cell (soak seed 31, case 26: ONE element of d vs off by 3.1e-2 of the tensor's scale, the same in both modes, rms 1.4e-3)
+                    el2 = l2_err(g, g64); worst["A dvs (l2)"] = max(worst.get("A dvs (l2)", 0.0), el2)
+                    assert el2 < 1e-2 and e < 1e-1, f"{tag} (A) dvs: relative l2 error {el2:.3e} (bound 1e-2), max {e:.3e} (bound 1e-1: isolated cell-boundary pairs)"
+                    continue
+                # the six MLP gradients are sums over all pairs of (bf16-stored) d bias terms that cancel to a small fraction of their summed
+                # magnitude (d bias sums to zero per query); on the smallest problems one tensor's own scale can be a few rounding errors of its
+                # terms (soak seed 31, case 33: 5 860 pairs per head, d w3 off by 7.8e-2 of ITS scale) - per tensor 1e-1 there, and always the
+                # six tensors together in relative l2 (below)
+                small = n in ("w1", "b1", "w2", "b2", "w3") and B * N * J < 20000
+                assert_close(f"{tag} ({which}) d{n}", g, g64, 1e-1 if small else GRAD_TOL)
+            if which == "A":
+                ga = torch.cat([dev[n].grad.flatten().double() for n in ("w1", "b1", "w2", "b2", "w3")])
+                gr = torch.cat([r[n].grad.flatten() for n in ("w1", "b1", "w2", "b2", "w3")])
+                if float(gr.abs().max()) > 1e-9:
+                    el2 = l2_err(ga, gr); worst["A dMLP (l2, all six)"] = max(worst.get("A dMLP (l2, all six)", 0.0), el2)
+                    assert el2 < GRAD_TOL, f"{tag} (A) MLP gradients together: relative l2 error {el2:.3e} > {GRAD_TOL}"
     print(f"\n[deform table {mode}] worst relative errors over the fuzz cases: " + ", ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
 
 
-@pytest.mark.parametrize("shape", [(20, 20), (7, 33), (16, 32), (100, 3), (1, 50), (37, 128)])
+def _grid_shapes():
+    import os
+    shapes = [(20, 20), (7, 33), (16, 32), (100, 3), (1, 50), (37, 128)]
+    n = int(os.environ.get("SMML_FUZZ_GRIDS", "0"))                  # soak: extra random grids (both sides <= 128)
+    g = torch.Generator().manual_seed(int(os.environ.get("SMML_FUZZ_SEED", "2468")))
+    for _ in range(n):
+        shapes.append((int(torch.randint(1, 129, (1,), generator=g)), int(torch.randint(1, 129, (1,), generator=g))))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _grid_shapes())
 def test_table_core_grid_queries(cuda, shape):
     """Queries on a regular grid (cpb_table_grid): d table comes from the two dense products per key on the matrix pipe instead of the
     LDS atomics - against (A) the fp64 interpolant, and against the atomics path of the same launch (every other output is bit-identical:
