@@ -5,7 +5,7 @@ G_in_P_Att (models/model.py:748-750,809-818), always with embed_dim 256, one hea
 
 Same constructor, forward signature, return tuple and parameter names (in_proj_weight, in_proj_bias,
 out_proj.weight/bias).  In-projections, Q K^T, softmax, P V and the out-projection run on the HIP kernels.
-Not built (raise): kdim/vdim != embed_dim - no caller in
+Every constructor option of the reference's class runs - no caller in
 the reference uses them.  The reference's `torch.equal(query, key)` host sync (:126,130) only selects between
 algebraically identical in-projection paths and is not reproduced."""
 from __future__ import annotations
@@ -26,13 +26,20 @@ class MultiheadAttention(nn.Module):
         self.kdim = kdim if kdim is not None else embed_dim
         self.vdim = vdim if vdim is not None else embed_dim
         self._qkv_same_embed_dim = self.kdim == embed_dim and self.vdim == embed_dim
-        if not self._qkv_same_embed_dim:
-            raise NotImplementedError("kdim/vdim != embed_dim is not built on the HIP path")
         self.num_heads = num_heads
         self.dropout = dropout
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == self.embed_dim, "embed_dim must be divisible by num_heads"
-        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        if self._qkv_same_embed_dim:
+            self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+            self.register_parameter('q_proj_weight', None)
+            self.register_parameter('k_proj_weight', None)
+            self.register_parameter('v_proj_weight', None)
+        else:                                 # MultiheadAttention.py:372-379 (no caller in the reference asks for it): separate projections
+            self.q_proj_weight = nn.Parameter(torch.empty(embed_dim, embed_dim))
+            self.k_proj_weight = nn.Parameter(torch.empty(embed_dim, self.kdim))
+            self.v_proj_weight = nn.Parameter(torch.empty(embed_dim, self.vdim))
+            self.register_parameter('in_proj_weight', None)
         if bias:
             self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
         else:
@@ -47,7 +54,10 @@ class MultiheadAttention(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
-        xavier_uniform_(self.in_proj_weight)
+        if self._qkv_same_embed_dim:
+            xavier_uniform_(self.in_proj_weight)
+        else:
+            xavier_uniform_(self.q_proj_weight); xavier_uniform_(self.k_proj_weight); xavier_uniform_(self.v_proj_weight)
         if self.in_proj_bias is not None:
             constant_(self.in_proj_bias, 0.)
             constant_(self.out_proj.bias, 0.)
@@ -61,7 +71,10 @@ class MultiheadAttention(nn.Module):
         S = key.shape[0]
         h, hd = self.num_heads, self.head_dim
         scaling = float(hd) ** -0.5
-        wq, wk, wv = self.in_proj_weight.chunk(3, dim=0)
+        if self._qkv_same_embed_dim:
+            wq, wk, wv = self.in_proj_weight.chunk(3, dim=0)
+        else:
+            wq, wk, wv = self.q_proj_weight, self.k_proj_weight, self.v_proj_weight
         bq = bk = bv = None
         if self.in_proj_bias is not None:
             bq, bk, bv = self.in_proj_bias.chunk(3, dim=0)

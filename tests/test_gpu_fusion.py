@@ -91,6 +91,30 @@ def test_coattention_bias_kv_and_zero_attn_vs_torch(cuda, bias_kv, zero_attn):
     assert raw.shape == (B, 4, L, S + int(bias_kv) + int(zero_attn))
 
 
+def test_coattention_separate_kv_dims_vs_torch(cuda):
+    """kdim / vdim != embed_dim (separate q / k / v projection weights, MultiheadAttention.py:372-379) against torch.nn.MultiheadAttention."""
+    torch.manual_seed(3)
+    ref = torch.nn.MultiheadAttention(64, 2, kdim=48, vdim=80)
+    mod = smml.MultiheadAttention(64, 2, kdim=48, vdim=80)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(cuda).eval()
+    L, S, B = 7, 19, 2
+    q, k, v = torch.randn(L, B, 64), torch.randn(S, B, 48), torch.randn(S, B, 80)
+    wo = torch.randn(L, B, 64)
+    qr, kr, vr = (t.clone().requires_grad_() for t in (q, k, v))
+    o_ref, w_ref = ref(qr, kr, vr, need_weights=True)
+    (o_ref * wo).sum().backward()
+    qd, kd, vd = (t.to(cuda).requires_grad_() for t in (q, k, v))
+    o, w = mod(qd, kd, vd, need_raw=False)
+    (o * wo.to(cuda)).sum().backward()
+    _assert_close("out", o, o_ref, 1e-5); _assert_close("weights", w, w_ref, 1e-5)
+    for a, b, n in ((qd, qr, "dq"), (kd, kr, "dk"), (vd, vr, "dv")):
+        _assert_close(n, a.grad, b.grad, 1e-5)
+    rp = dict(ref.named_parameters())
+    for name, p in mod.named_parameters():
+        _assert_close("d" + name, p.grad, rp[name].grad, 1e-5)
+
+
 def test_coattention_multi_head_vs_torch(cuda):
     torch.manual_seed(0)
     ref = torch.nn.MultiheadAttention(64, 4)
