@@ -1089,24 +1089,28 @@ __global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
   const float* VSb = VS + ((size_t)(b * G + g) * J + keyc) * PD;
   const float vs0 = VSb[0], vs1 = (PD == 2) ? VSb[1] : 0.f;
   float acc0 = 0.f, acc1 = 0.f;
+  int run_idx = 0;                                    // HIST: the lane's current cell and its corner sums
+  float run_w[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntq = (N + 31) / 32;
   const int t_end = min((sl + 1) * tiles_per_slice, ntq);
   for (int t = sl * tiles_per_slice + wave; t < t_end; t += TBW) {
     const int q0 = t * 32, nq = min(32, N - q0);
+    const uint4v* rp = reinterpret_cast<const uint4v*>(dLT + (((size_t)(b * H + h) * NST + q0) * J + (size_t)keyc * 32));
     uint4v rw[4];
-    {
-      const uint4v* rp = reinterpret_cast<const uint4v*>(dLT + (((size_t)(b * H + h) * NST + q0) * J + (size_t)keyc * 32));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rw[i] = kvalid ? rp[i] : (uint4v){0u, 0u, 0u, 0u};
-    }
+    for (int i = 0; i < 4; ++i) rw[i] = kvalid ? rp[i] : (uint4v){0u, 0u, 0u, 0u};
     // the tile's query positions: one coalesced load (lane l holds float l of the tile's 32 x PD block), read back per query with
     // v_readlane - no memory wait inside the query loop, and no branch: queries past the bag's end run on a clamped position with d bias = 0
     const float gqv = GQ[min((size_t)q0 * PD + lane, (size_t)N * PD - 1)];
+    // eight queries per trip of a four-trip loop (kept rolled: with the run-length branches of the histogram a fully unrolled body costs 176 spills)
+#pragma unroll 1
+    for (int g8 = 0; g8 < 4; ++g8) {
+      const uint4v w4 = (g8 == 0) ? rw[0] : (g8 == 1) ? rw[1] : (g8 == 2) ? rw[2] : rw[3];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      {
-        const unsigned w = rw[i >> 3][(i >> 1) & 3];
-        const float db = (i < nq) ? ((i & 1) ? bf_hi(w) : bf_lo(w)) : 0.f;
+      for (int ii = 0; ii < 8; ++ii) {
+        const int i = 8 * g8 + ii;
+        const unsigned w = w4[ii >> 1];
+        const float db = (i < nq) ? ((ii & 1) ? bf_hi(w) : bf_lo(w)) : 0.f;
         const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gqv), i * PD)) - vs0;
         const float a0 = fabsf(d0) + 1.0f;
         const float u0r = fmaf(copysignf(__builtin_amdgcn_logf(a0) * 0.6931471805599453f, d0), tc.invh, tc.off);
@@ -1129,22 +1133,35 @@ __global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
           acc0 = fmaf(-dbh * sx, srcp(a0), acc0);
           acc1 = fmaf(-dbh * sy, srcp(a1), acc1);
           if (HIST) {
+            // run-length accumulation: consecutive queries of a key mostly fall into the same cell (a lane keeps the four corner sums of its
+            // current cell in registers and issues the four LDS atomics only when the cell changes - executed under the mask of the lanes that
+            // moved: the atomics' cost goes with the active lanes)
             const float w1x = db * f0, w0x = db - w1x;
             const float h01 = w0x * f1, h11 = w1x * f1;
-            atomicAdd(&hist[idx], w0x - h01);
-            atomicAdd(&hist[idx + 1], w1x - h11);
-            atomicAdd(&hist[idx + TG], h01);
-            atomicAdd(&hist[idx + TG + 1], h11);
+            if (idx != run_idx) {
+              atomicAdd(&hist[run_idx], run_w[0]);
+              atomicAdd(&hist[run_idx + 1], run_w[1]);
+              atomicAdd(&hist[run_idx + TG], run_w[2]);
+              atomicAdd(&hist[run_idx + TG + 1], run_w[3]);
+              run_idx = idx;
+              run_w[0] = run_w[1] = run_w[2] = run_w[3] = 0.f;
+            }
+            run_w[0] += w0x - h01; run_w[1] += w1x - h11; run_w[2] += h01; run_w[3] += h11;
           }
         } else {
           const int idx = (int)u0;
           const float t0 = tabl[idx], t1 = tabl[idx + 1];
           const float sx = (u0r == u0) ? (t1 - t0) : 0.f;
           acc0 = fmaf(-db * tc.invh * sx, srcp(a0), acc0);
-          if (HIST) {
+          if (HIST) {           // run-length accumulation (see the 2-D branch); in 1-D a key's cell index is monotonic in the query index
             const float w1x = db * f0;
-            atomicAdd(&hist[idx], db - w1x);
-            atomicAdd(&hist[idx + 1], w1x);
+            if (idx != run_idx) {
+              atomicAdd(&hist[run_idx], run_w[0]);
+              atomicAdd(&hist[run_idx + 1], run_w[1]);
+              run_idx = idx;
+              run_w[0] = run_w[1] = 0.f;
+            }
+            run_w[0] += db - w1x; run_w[1] += w1x;
           }
         }
       }
@@ -1152,6 +1169,12 @@ __global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
   }
   if (kvalid) dvs_rows[((size_t)((b * H + h) * S + sl) * TBW + wave) * J + key] = make_float2(acc0, acc1);
   if (HIST) {
+    atomicAdd(&hist[run_idx], run_w[0]);              // the last run of every lane (zeros if it never started)
+    atomicAdd(&hist[run_idx + 1], run_w[1]);
+    if (PD == 2) {
+      atomicAdd(&hist[run_idx + TG], run_w[2]);
+      atomicAdd(&hist[run_idx + TG + 1], run_w[3]);
+    }
     __syncthreads();
     float* slab = hist_slab + (size_t)((((size_t)b * H + h) * gridDim.x) + blockIdx.x) * NC;
     for (int i = tid; i < NC; i += 64 * TBW) slab[i] = hist[i];
