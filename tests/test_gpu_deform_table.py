@@ -361,6 +361,26 @@ def test_module_table_range_covers_the_positions(cuda, shape, which):
     assert a["table_pmax"] < pmax_seen * 1.6 + 0.2, f"{shape}: the range {a['table_pmax']:.3f} wastes resolution (positions reach {pmax_seen:.3f})"
 
 
+@pytest.mark.parametrize("n", [37, 120, 1000])
+@pytest.mark.parametrize("which", ["forward", True])
+def test_module_table_range_covers_the_positions_1d(cuda, n, which):
+    """The same property for the 1-D module (tables over [-pmax, pmax] from the sequence length and tanh . offset_scale)."""
+    B, C = 2, 128
+    mod = smml.DeformCrossAttention1D(dim=C, downsample_factor=4, offset_scale=2, offset_kernel_size=6, compute_dtype="bf16", cpb_table=which)
+    params = params_for(mod, 43, f"range1d:{n}")
+    params["to_offsets.2.weight"] = params["to_offsets.2.weight"] * 200.0
+    mod.load_state_dict(params)
+    mod = mod.to(cuda).eval()
+    x1 = synth.normal((B, C, n), 43, "range1d:x1") * 3.0; x2 = synth.normal((B, C, n), 43, "range1d:x2")
+    with decision_tap() as tap:
+        with torch.no_grad():
+            mod(x1.to(cuda), x2.to(cuda))
+    a = [e for e in tap.entries if e["kind"] == "attn"][0]
+    pos = a["gq"][None, :, None, :] - a["vs"][:, None, :, :]
+    pmax_seen = float(torch.log1p(pos.abs()).max())
+    assert a["table_pmax"] is not None and pmax_seen <= a["table_pmax"], f"n = {n}: positions reach {pmax_seen:.4f}, the tables end at {a['table_pmax']:.4f}"
+
+
 def test_table_mode_needs_a_16bit_dtype():
     with pytest.raises(ValueError):
         smml.DeformCrossAttention2D(dim=128, cpb_table=True)
