@@ -51,13 +51,17 @@ class _Bucket:
 
 
 class BagDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, bucket_bytes: int = 512 << 10, process_group=None, broadcast: bool = True):
+    def __init__(self, module: nn.Module, bucket_bytes: int = 512 << 10, process_group=None, broadcast: bool = True,
+                 collectives_at_world_1: bool = False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # tests: run the whole reducer (hooks, buckets, the backend's all-reduce with its averaging op, the end-of-backward wait) in a ONE-rank group -
+        # the only way to put RCCL under this code on a one-GPU box (RCCL refuses two ranks per device); the average over one rank is the identity
+        self._reduce_at_1 = bool(collectives_at_world_1 and dist.is_initialized() and self.world == 1)
         params = [p for p in module.parameters() if p.requires_grad]
-        if self.world > 1 and broadcast:
+        if (self.world > 1 or self._reduce_at_1) and broadcast:
             # rank 0's state at wrap time, parameters AND buffers - as DDP's constructor does whatever `broadcast_buffers` says (that flag,
             # False at main.py:119, only stops the per-forward re-broadcast).  Buffers matter with fusion_type 'pofusion': main.py:118
             # converts BilinearFusion's BatchNorm1d to SyncBatchNorm, whose running statistics must start equal on every rank
@@ -85,7 +89,7 @@ class BagDataParallel(nn.Module):
         self.stats = {"buckets": len(self._buckets), "launched_in_backward": 0, "skipped": 0, "steps": 0, "hook_host_ms": 0.0,
                       "used_mismatch": 0}
         self._hook_s = 0.0                    # host time spent inside the gradient hooks of the current backward
-        if self.world > 1:
+        if self.world > 1 or self._reduce_at_1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -191,7 +195,7 @@ class BagDataParallel(nn.Module):
                     p.grad = v
         if not self._known:
             used = [bool(r and p.grad is not None) for b in self._buckets for p, r in zip(b.params, b.ready)]
-            if self.world > 1:
+            if self.world > 1 or self._reduce_at_1:
                 # the grad-less set decides how many all-reduces a step issues: it must be the same on every rank, or the job
                 # hangs in the collective with no diagnostic.  Ranks exchange their sets once (MAX = union, MIN =
                 # intersection); where they differ the union is taken - every rank then launches the same buckets, a rank

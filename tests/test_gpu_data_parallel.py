@@ -128,6 +128,57 @@ def test_two_ranks_over_rccl(cuda, smml):
     _run_two_ranks(smml, "nccl")
 
 
+def _worker_rccl_one_rank(port, q):
+    import importlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    smml = importlib.import_module("subspace-multimodal-learning_amd")
+    B, S, in_dim = 2, 16, 64
+    out = {}
+    for wrapped in (False, True):
+        mil = _build(smml, S, in_dim)
+        model = smml.BagDataParallel(mil, bucket_bytes=1 << 18, collectives_at_world_1=True) if wrapped else mil
+        bl = smml.BatchLoss(B, 1)
+        path, omic, label = _data(smml, 0, B, S, in_dim)
+        for step in range(2):
+            mil.zero_grad(set_to_none=True)
+            loss = _loss(smml, model, bl, path, omic, label)
+            loss.backward()
+        out[wrapped] = ({k: p.grad.detach().cpu() for k, p in mil.named_parameters() if p.grad is not None}, float(loss),
+                        dict(model.stats) if wrapped else None)
+    # the gather layer of BatchLoss over RCCL (all_gather + its own-rank backward)
+    t = torch.randn(3, 5, device="cuda", requires_grad=True)
+    g, = smml.losses.GatherLayer.apply(t)
+    (g * 2.0).sum().backward()
+    gather_ok = bool(torch.equal(g.detach(), t.detach())) and bool(torch.equal(t.grad, torch.full_like(t, 2.0)))
+    # two runs of the same step differ in the last bits of the weight gradients that are reduced with float atomics: compared
+    # to 1e-5 of each tensor's scale, not bit for bit
+    worst = max(float((out[True][0][k] - v).abs().max() / v.abs().max().clamp_min(1e-30)) for k, v in out[False][0].items()
+                if not k.endswith("rel_pos_bias.mlp.2.bias"))
+    same = worst <= 1e-5 and set(out[True][0]) == set(out[False][0])
+    q.put((same, out[True][1], out[False][1], out[True][2], gather_ok, dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_over_rccl_one_rank(cuda, smml):
+    """RCCL under the data-parallel reducer on a one-GPU box: a ONE-rank nccl group (`init_process_group(device_id=...)`), parameters and buffers
+    broadcast, every bucket all-reduced with ReduceOp.AVG from the gradient hooks while backward runs, the grad-less-set exchange, the
+    end-of-backward wait, and BatchLoss's GatherLayer - the average over one rank is the identity, so the gradients must equal the unwrapped
+    model's (to the run-to-run noise of the atomically reduced weight gradients).  (Two ranks over RCCL need two devices: test_two_ranks_over_rccl.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), q))
+    p.start()
+    same, l_wrapped, l_plain, st, gather_ok, backend = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl"
+    assert same and l_wrapped == l_plain, "the one-rank RCCL reducer changed the gradients"
+    assert st["buckets"] >= 3 and st["launched_in_backward"] == st["buckets"] - st["skipped"] >= 2, st
+    assert gather_ok
+
+
 # ------------------------------------------------------------------------------------------------
 # SyncBatchNorm + BagDataParallel (reference: main.py:118-119 converts BN to SyncBN, then wraps) - only reached with
 # fusion_type 'pofusion' (BilinearFusion's two BatchNorm1d, models/fusion.py:44-45)
