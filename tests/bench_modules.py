@@ -46,6 +46,9 @@ for (N, S, dim) in ((2500, 50, 1024), (10000, 100, 512)):
     if N == 10000:          # BASELINE config 4 as stated: the deformable path in bf16 compute (args.deform_compute_dtype)
         net = smml.DeformPathomicNet(pathomic_args(input_path_dim=dim, batch_size=B, deform_compute_dtype="bf16")).to(dev).train()
         timeit(f"  the same with deform_compute_dtype='bf16', {B} x {N} x {dim}", f2, steps=5, warm=2)
+        for tab in ("forward", True):       # the table modes of the 16-bit core: 'forward' parity-grade, True approximate
+            net = smml.DeformPathomicNet(pathomic_args(input_path_dim=dim, batch_size=B, deform_compute_dtype="bf16", deform_cpb_table=tab)).to(dev).train()
+            timeit(f"  the same with deform_compute_dtype='bf16', deform_cpb_table={tab!r}, {B} x {N} x {dim}", f2, steps=5, warm=2)
 
 args = argparse.Namespace(label_dim=4, path_dim=128, input_path_dim=1024)
 tm = smml.TransMIL(args).to(dev).train()
