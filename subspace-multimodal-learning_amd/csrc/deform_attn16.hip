@@ -1193,11 +1193,12 @@ __global__ __launch_bounds__(64 * TBW, 1) void cpb_table_bwd_kernel(
 // part of the sum in 48 accumulator registers across the chunk's keys; the second product takes the first one's accumulators as its
 // B operand directly (register r <-> row y = acc_row(r, half): the A fragments of hat1 are read in the same order).
 // Per key the workgroup stages the sheet (coalesced 16-byte pieces of the [J][32] tile rows; linear in q, so a row's 8 consecutive x
-// of an A fragment are two 8-byte LDS reads when Ww % 4 == 0, eight 2-byte reads otherwise) and the two hat tables in LDS.
+// of an A fragment are two 8-byte LDS reads when Ww % 4 == 0, eight 2-byte reads otherwise) and the key's 2 x 128 cell coordinates in LDS;
+// the hat fragments are formed in registers from the coordinates when an MFMA needs them (a first version kept both hat tables in LDS:
+// 52 KB per workgroup, two workgroups per CU, 0.85 ms; this form 0.53 ms).
 // Requires Hh, Ww <= 128 (LDS: the sheet is padded to 32-row / 16-column blocks); other shapes take cpb_table_bwd_kernel's atomics.
 // ------------------------------------------------------------------------------------------------
 constexpr int TGW = 3;                       // waves per workgroup = 32-wide c0 blocks of the 96-point table
-constexpr int HATLD = 128 + 8;               // halves per row of a hat table (272-byte rows)
 constexpr int TABLE_GRID_MAX = 128;          // largest grid side of the fast path
 constexpr int TABLE_GRID_KEYS = 32;          // keys per workgroup
 __host__ __device__ inline int table_sheet_halves(int Hh, int Ww) {     // LDS halves of one key's padded sheet
@@ -1210,8 +1211,6 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
   static_assert(TG == 32 * TGW, "one wave per 32 table columns");
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   __bf16* dbs = reinterpret_cast<__bf16*>(dyn_lds);                    // the key's sheet, linear in q (zero beyond N)
-  __shared__ __attribute__((aligned(16))) __bf16 hat1[TG * HATLD];     // [c1][y]
-  __shared__ __attribute__((aligned(16))) __bf16 hat0[TG * HATLD];     // [c0][x]
   __shared__ __attribute__((aligned(16))) float u0s[TABLE_GRID_MAX], u1s[TABLE_GRID_MAX];
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1225,8 +1224,19 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
   floatx16 acc2[3] = {{0}, {0}, {0}};
   const float* VSb = VS + (size_t)(b * G + g) * J * 2;
   const u16* Lb = dLT + (size_t)(b * H + h) * NST * J;
+  // eight hat weights hat(row; u[p .. p + 7]) as one bf16 fragment, straight from the cell coordinates in LDS (two 16-byte broadcast reads):
+  // the hat tables themselves are never materialised - 52 KB of LDS less per workgroup (two -> five workgroups per CU) and one barrier less per key
+  auto hat8 = [&](const float* us, float rowf) -> bf16x8 {
+    const float4 ua = *reinterpret_cast<const float4*>(us), ub = *reinterpret_cast<const float4*>(us + 4);
+    const float hv[8] = {__builtin_amdgcn_fmed3f(1.f - fabsf(ua.x - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.y - rowf), 0.f, 1.f),
+                         __builtin_amdgcn_fmed3f(1.f - fabsf(ua.z - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.w - rowf), 0.f, 1.f),
+                         __builtin_amdgcn_fmed3f(1.f - fabsf(ub.x - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.y - rowf), 0.f, 1.f),
+                         __builtin_amdgcn_fmed3f(1.f - fabsf(ub.z - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.w - rowf), 0.f, 1.f)};
+    return cvt8<__bf16>(hv);
+  };
+  const float c0f = (float)(32 * wave + c);
   for (int key = k0; key < k1; ++key) {
-    __syncthreads();                                 // the previous key's tables have been consumed
+    __syncthreads();                                 // the previous key's sheet and coordinates have been consumed
     const float vs0 = VSb[(size_t)key * 2], vs1 = VSb[(size_t)key * 2 + 1];
     for (int i = tid; i < 2 * TABLE_GRID_MAX; i += 64 * TGW) {
       const int a = i & (TABLE_GRID_MAX - 1);
@@ -1248,49 +1258,46 @@ __global__ __launch_bounds__(64 * TGW) void cpb_table_grid_bwd_kernel(
       *reinterpret_cast<uint4v*>(&dbs[q]) = w;
     }
     __syncthreads();
-    // hat tables: groups of 8 positions per table row
-    for (int gi = tid; gi < 2 * TG * (TABLE_GRID_MAX / 8); gi += 64 * TGW) {
-      const int which = gi / (TG * (TABLE_GRID_MAX / 8)), r = gi - which * (TG * (TABLE_GRID_MAX / 8));
-      const int row = r >> 4, p8 = (r & 15) * 8;
-      const float* us = which ? u0s : u1s;
-      const float4 ua = *reinterpret_cast<const float4*>(us + p8), ub = *reinterpret_cast<const float4*>(us + p8 + 4);
-      const float cf = (float)row;
-      const float hv[8] = {__builtin_amdgcn_fmed3f(1.f - fabsf(ua.x - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.y - cf), 0.f, 1.f),
-                           __builtin_amdgcn_fmed3f(1.f - fabsf(ua.z - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.w - cf), 0.f, 1.f),
-                           __builtin_amdgcn_fmed3f(1.f - fabsf(ub.x - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.y - cf), 0.f, 1.f),
-                           __builtin_amdgcn_fmed3f(1.f - fabsf(ub.z - cf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.w - cf), 0.f, 1.f)};
-      *reinterpret_cast<bf16x8*>(&(which ? hat0 : hat1)[row * HATLD + p8]) = cvt8<__bf16>(hv);
-    }
-    __syncthreads();
+    // B fragments of the first product for this wave's 32 columns c0: hat0[c0][x], x = 16 st + 8 hf + j (the same for every row block)
+    bf16x8 b1f[TABLE_GRID_MAX / 16];
+#pragma unroll
+    for (int st = 0; st < TABLE_GRID_MAX / 16; ++st)
+      if (st < nsx) b1f[st] = hat8(u0s + 16 * st + 8 * hf, c0f);
     for (int yb = 0; yb < nyb; ++yb) {
       // first product: out1[y][c0] = sum_x DB[y][x] hat0[c0][x] for the 32 rows y of block yb (lane = y) and this wave's 32 columns c0
       floatx16 out1 = {0};
       const __bf16* ap = dbs + (32 * yb + c) * Ww + 8 * hf;
-      const __bf16* bp = hat0 + (32 * wave + c) * HATLD + 8 * hf;
-      for (int st = 0; st < nsx; ++st) {
-        bf16x8 a1;
-        if (ALIGNED) {                               // Ww % 4 == 0: every row starts on an 8-byte boundary
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ap + 16 * st), hi = *reinterpret_cast<const bf16x4*>(ap + 16 * st + 4);
-          a1 = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a1[j] = ap[16 * st + j];
+      for (int st = 0; st < TABLE_GRID_MAX / 16; ++st) {
+        if (st < nsx) {
+          bf16x8 a1;
+          if (ALIGNED) {                             // Ww % 4 == 0: every row starts on an 8-byte boundary
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ap + 16 * st), hi = *reinterpret_cast<const bf16x4*>(ap + 16 * st + 4);
+            a1 = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a1[j] = ap[16 * st + j];
+          }
+          out1 = mfma16b(a1, b1f[st], out1);
         }
-        out1 = mfma16b(a1, *reinterpret_cast<const bf16x8*>(bp + 16 * st), out1);
       }
-      // second product: d table[c1][c0] += sum_y hat1[c1][y] out1[y][c0]
+      // second product: d table[c1][c0] += sum_y hat1[c1][y] out1[y][c0]; A fragment of k-block kb: y = 32 yb + acc_row(8 kb + j, hf)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float o8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = out1[8 * kb + j];
         const bf16x8 b2 = cvt8<__bf16>(o8);
+        const float* up = u1s + 32 * yb + 16 * kb + 4 * hf;
+        const float4 ua = *reinterpret_cast<const float4*>(up), ub = *reinterpret_cast<const float4*>(up + 8);
 #pragma unroll
         for (int cb = 0; cb < 3; ++cb) {
-          const __bf16* hp = hat1 + (32 * cb + c) * HATLD + 32 * yb + 16 * kb + 4 * hf;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(hp), hi = *reinterpret_cast<const bf16x4*>(hp + 8);
-          const bf16x8 a2 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          acc2[cb] = mfma16b(a2, b2, acc2[cb]);
+          const float rowf = (float)(32 * cb + c);
+          const float hv[8] = {__builtin_amdgcn_fmed3f(1.f - fabsf(ua.x - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.y - rowf), 0.f, 1.f),
+                               __builtin_amdgcn_fmed3f(1.f - fabsf(ua.z - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ua.w - rowf), 0.f, 1.f),
+                               __builtin_amdgcn_fmed3f(1.f - fabsf(ub.x - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.y - rowf), 0.f, 1.f),
+                               __builtin_amdgcn_fmed3f(1.f - fabsf(ub.z - rowf), 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - fabsf(ub.w - rowf), 0.f, 1.f)};
+          acc2[cb] = mfma16b(cvt8<__bf16>(hv), b2, acc2[cb]);
         }
       }
     }
