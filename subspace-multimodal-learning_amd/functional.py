@@ -600,14 +600,15 @@ def attention16_queries_long(qkv, kl, w, residual=None, *, heads: int, scale: fl
 
 
 class _HeadMajorQKV(torch.autograd.Function):
-    """qkv [b, n, 3 h d] (bf16, token-major: what the projection writes) -> q, k, v fp32 [b, h, n, d], three slices of one buffer filled by
-    ONE strided copy; backward writes the three gradients into one bf16 token-major buffer (no stack / cat of fp32 head-major pieces)."""
+    """qkv [b, n, 3 h d] (bf16 or fp32, token-major: what the projection writes) -> q, k, v fp32 [b, h, n, d], three slices of one buffer filled by
+    ONE strided copy; backward writes the three gradients into one token-major buffer of the input's dtype (no stack / cat of head-major pieces)."""
 
     @staticmethod
     def forward(ctx, qkv, heads):
         b, n, c = qkv.shape
         d = c // (3 * heads)
         ctx.shape = (b, n, heads, d)
+        ctx.in_dtype = qkv.dtype                  # bf16 (the bf16 projections) or fp32 (exact path, fp16 mode): the gradient buffer follows it
         buf = torch.empty(3, b, heads, n, d, device=qkv.device, dtype=torch.float32)
         buf.copy_(qkv.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4))
         return buf[0], buf[1], buf[2]
@@ -615,7 +616,7 @@ class _HeadMajorQKV(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dq, dk, dv):
         b, n, h, d = ctx.shape
-        dqkv = torch.empty(b, n, 3, h, d, device=dq.device, dtype=torch.bfloat16)
+        dqkv = torch.empty(b, n, 3, h, d, device=dq.device, dtype=ctx.in_dtype)
         view = dqkv.permute(2, 0, 3, 1, 4)
         for i, g in enumerate((dq, dk, dv)):
             if g is None:

@@ -193,7 +193,7 @@ class NystromAttention(nn.Module):
         # one projection GEMM for q, k and v (M = b n', N = 3 inner), then one strided copy into the head-major layout the
         # batched products read; the softmax scale (:98) rides on the three similarity products as alpha
         qkv = Fh.linear(x, self.to_qkv.weight)                                   # [b, n', 3 h d]
-        q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)   # each [b, h, n', d]
+        q, k, v = Fh.head_major_qkv(qkv, h)                                      # each [b, h, n', d]: one strided copy, one gradient buffer
         fill = lambda t, keep: t
         if mask is not None:
             # NystromAttention.py:92-96,106-118,127-133: masked tokens are zeroed in q / k / v, landmarks are means over the UNMASKED tokens of a
@@ -267,7 +267,7 @@ class NystromAttention(nn.Module):
             # gradients without a loss scale).  Round 3 kept the fp16 mode's projections exact: 3 ms of its 5.2 ms step
             gm = 4 if fp16 else 3
             qkv = Fh.linear(x, self.to_qkv.weight, prec=gm)
-            q, k, v = qkv.view(b, npad, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().unbind(0)     # each [b, h, n', d]
+            q, k, v = Fh.head_major_qkv(qkv, h)                                                    # each [b, h, n', d]
         ql, kl = Fh.segment_mean(q, l), Fh.segment_mean(k, l)
         a2 = Fh.softmax_rows(Fh.matmul4(ql, kl, tb=True, alpha=sc))                            # [b, h, m, m], exact fp32
         fork = _PinvFork(a2)                                                                   # beside attn3 v and the residual convolution
