@@ -438,6 +438,7 @@ def main():
                        "bags_per_gpu": B, "global_batch": B * world, "instances": N, "feature_dim": in_dim,
                        "parallelism": f"dp{world} (whole bags per rank, RCCL gradient all-reduce)" + (", step replayed from one hipGraph" if use_graph else "")},
         }
+        out["kernel_events"] = {k: {"launches": v[0], "avg_ms": v[1], "pairs_per_launch": v[2]} for k, v in kt.items()}   # HIP events on the launch stream
         if "cpb_bwd" in kt:
             n, ms, pairs = kt["cpb_bwd"]
             flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops (4480 per pair), recompute not counted

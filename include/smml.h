@@ -193,6 +193,35 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
                              void* ev_start, void* ev_stop, void* stream);
+/* The same fused core with the position bias evaluated EXACTLY PER LINEAR REGION of its MLP (csrc/cpb_regions.h; round 5).  The MLP of
+ * models/DeformableAttention2D.py:129-152 is piecewise affine in the signed-log offsets (:148): smml_cpb_regions_build tabulates, for the
+ * current parameters, which linear piece every cell of [-pmax, pmax]^2 lies in (cells a ReLU kink crosses carry the kink's line, cells
+ * several kinks cross are refined once, what is left evaluates the MLP itself), and the forward / backward below replace the per-pair MLP
+ * by a lookup + 2 FMAs, resp. by three fixed-point moment sums per region from which all six parameter gradients follow linearly.
+ * Results are those of smml_deform_attn_fwd_f32 / _bwd_f32 to fp32 rounding (no tolerance added: tests/test_gpu_parity.py runs both);
+ * posdim = 2, signed-log offsets, one head per offset group (G = H), J <= 1024.
+ *   tables: caller-allocated scratch of smml_cpb_regions_bytes() bytes, 256-byte aligned; built per forward call (the parameters change
+ *           every step), handed unchanged to the backward of the same call.  pmax >= max |slog(gq - vs)| for speed only: pairs
+ *           outside the square evaluate the MLP.
+ *   region_ids [B, H, nst / 32, J, 32] uint16: the linear piece of every pair (0xFFFF: none), saved in place of relu_masks.
+ *   workspace of the backward: smml_deform_attn_region_bwd_workspace_bytes, 256-byte aligned.
+ * Every output is run-to-run identical (slab sums in a fixed order; the region moments are integer sums). */
+size_t smml_cpb_regions_bytes(void);
+int smml_cpb_regions_build(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                           float pmax, void* tables, size_t tables_bytes, void* stream);
+int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, const void* tables, float* out, float* lse, float* logits_t,
+                                    unsigned short* region_ids, int B, int N, int J, int H, float scale, float dropout_p,
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
+size_t smml_deform_attn_region_bwd_workspace_bytes(int B, int N, int J, int H);
+int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, const void* tables, const float* out, const float* dout, const float* lse,
+                                    const float* logits_t, const unsigned short* region_ids, float* dlogits_t, float* dq, float* dk,
+                                    float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                                    void* workspace, size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
 /* 16-bit compute mode of the same fused core (csrc/deform_attn16.hip; BASELINE config 4 names bf16, config 5 fp16): the op sequence of
  * smml_deform_attn_fwd_f32 / _bwd_f32 (models/DeformableAttention2D.py:120-157,284-312; DeformableAttention1D.py:60-102,205-232) with
  * single-term 16-bit operands on the matrix pipe - dtype 0 = bf16, 1 = fp16 for forward-range operands (q, k, v, probabilities, the

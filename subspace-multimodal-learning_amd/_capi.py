@@ -61,6 +61,11 @@ SIGNATURES = {
     "smml_deform_attn_relu1_masks": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "smml_deform_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "smml_deform_attn_bwd_f32": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
+    "smml_cpb_regions_bytes": (_sz, []),
+    "smml_cpb_regions_build": (_i, [_f] * 6 + [_fl, _f, _sz, _f]),
+    "smml_deform_attn_region_fwd_f32": (_i, [_f] * 16 + [_i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
+    "smml_deform_attn_region_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "smml_deform_attn_region_bwd_f32": (_i, [_f] * 28 + [_f, _sz, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
     "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
     "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
     "smml_deform_attn_set_log_distance": (None, [_i]),

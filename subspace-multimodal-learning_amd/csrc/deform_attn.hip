@@ -24,6 +24,7 @@
 // up (tests/microbench/overlap_probe.hip), so the kernels minimise both instruction counts; results are fp32-grade
 // (DESIGN.md section 4 for the error bounds and the measurements behind them).
 #include "deform_common.h"
+#include "cpb_regions.h"
 
 namespace {
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, SMML_FWD_WPS) void deform_attn_fwd_kernel(
 __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ LT,
-    float* __restrict__ dLT, float* __restrict__ dQ, float* __restrict__ RHO, int N, int J, int H, int NST,
+    float* __restrict__ dLT, float* __restrict__ dQ, float* __restrict__ RHO, unsigned* __restrict__ AMAX, int N, int J, int H, int NST,
     float scale, DropCfg dc_in) {
   const DropCfg dc = drop_resolve(dc_in);
   __shared__ __attribute__((aligned(16))) __bf16 Vp[2][3][KT * VBLD];
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   const float nl = prob_bias(LSE[(size_t)(b * H + h) * N + qi]);
 
   floatx16 dq0 = {0}, dq1 = {0};
+  float amax = 0.f;      // max |d scores| of this lane (region backward: scale of its fixed-point moment sums); AMAX may be null
   float rho = 0.f;       // sum over keys of this query's d scores: 0 in exact arithmetic, ~1e-7 |dO||O| with delta = rowsum(dO . O)
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         dLTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = v;
         ds[r] = v;
         rho += v;
+        amax = fmaxf(amax, fabsf(v));
       }
     } else {
 #pragma unroll
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         }
         ds[r] = v;
         rho += v;
+        amax = fmaxf(amax, fabsf(v));
       }
     }
     // dQ^T[d, query] += K^T . dS^T: accumulator register 8 kb + j of dS^T is element j of K-block kb (keys 16 kb + 4 hf + 0..3
@@ -540,6 +544,10 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
   }
   rho = xhalf_sum(rho);
   if (qvalid && hf == 0) RHO[(size_t)(b * H + h) * N + qi] = rho;
+  if (AMAX) {                                               // non-negative floats order like their bit patterns
+    amax = wave_max_all(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(AMAX, __float_as_uint(amax));
+  }
   if (qvalid) {
     float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
 #pragma unroll
@@ -1253,7 +1261,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
   const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
   float* wsf = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t,
-                     dlogits_t, dq, wsf + wsl.rho, N, J, H, nst, scale, dc);
+                     dlogits_t, dq, wsf + wsl.rho, (unsigned*)nullptr, N, J, H, nst, scale, dc);
   SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/dq");
   // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
   {
@@ -1297,6 +1305,178 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     hipLaunchKernelGGL(cpb_final_kernel, dim3((CPB_SLAB + 255) / 256), dim3(256), 0, st, wsf + wsl.partial, nchunks, H / G,
                        dw1, db1, dw2, db2, dw3, db3, posdim);
     SMML_LAUNCH_CHECK("smml_deform_attn_bwd_f32/reduce");
+  }
+  return SMML_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// position bias per linear region (cpb_regions.h): exact, 2-D signed-log offsets, one head per offset group
+// ------------------------------------------------------------------------------------------------
+static int ceil_log2_u64(unsigned long long x) { int k = 0; while ((1ull << k) < x && k < 63) ++k; return k; }
+struct RegionBwdPlan {
+  int chunks, tiles_per_chunk, nkb, wpk, kbits, shift;
+  size_t amax, hist, grad, dvs, part, total;       // byte offsets behind the dq / dkv workspace
+};
+static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
+  RegionBwdPlan p;
+  const int ntq = (N + QT - 1) / QT;
+  p.chunks = (512 + B * H - 1) / (B * H);
+  if (p.chunks < 1) p.chunks = 1;
+  if (p.chunks > ntq) p.chunks = ntq;
+  p.tiles_per_chunk = (ntq + p.chunks - 1) / p.chunks;
+  p.chunks = (ntq + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+  p.nkb = (J + 63) / 64;
+  p.wpk = p.nkb <= 16 ? 16 / p.nkb : 0;
+  if (p.wpk > p.tiles_per_chunk) p.wpk = p.tiles_per_chunk;
+  // fixed point: |d bias (1, p0, p1)| <= 4 amax (|p| <= log(1 + |d|) < 4 for any reachable offset); a workgroup adds at most
+  // tiles_per_chunk 32 J values into an LDS accumulator, the launch at most B H N J into a global one - both stay below 2^62
+  const int kl = 60 - ceil_log2_u64((unsigned long long)p.tiles_per_chunk * QT * J) - 2;
+  const int kg = 60 - ceil_log2_u64((unsigned long long)B * H * N * J) - 2;
+  p.kbits = kl < 38 ? kl : 38;
+  const int kgl = kg < p.kbits ? kg : p.kbits;
+  p.shift = p.kbits - kgl;
+  size_t o = (bwd_workspace(B, N, J, H).total * sizeof(float) + 255) & ~(size_t)255;
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+  p.amax = take(256);
+  p.hist = take((size_t)RG_RCAP * 3 * 8);
+  p.grad = take((size_t)RG_GRAD * 8);
+  p.dvs = take((size_t)p.chunks * B * H * J * 2 * sizeof(float));
+  p.part = take((size_t)(RG_RCAP / RG_FIN) * RG_GRAD * 8);
+  p.total = o;
+  return p;
+}
+
+size_t smml_cpb_regions_bytes(void) { return region_layout().total; }
+
+int smml_cpb_regions_build(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                           float pmax, void* tables, size_t tables_bytes, void* stream) {
+  SMML_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && tables, "smml_cpb_regions_build: null pointer");
+  SMML_REQUIRE(pmax > 0.f && pmax < 16.f, "smml_cpb_regions_build: pmax must be in (0, 16) (got %g)", (double)pmax);
+  SMML_REQUIRE(tables_bytes >= region_layout().total, "smml_cpb_regions_build: table buffer too small (%zu < %zu)", tables_bytes,
+               region_layout().total);
+  SMML_REQUIRE((reinterpret_cast<size_t>(tables) & 255) == 0, "smml_cpb_regions_build: table buffer must be 256-byte aligned");
+  region_build_launch(CpbParams{w1, b1, w2, b2, w3, b3}, pmax, tables, (hipStream_t)stream);
+  SMML_LAUNCH_CHECK("smml_cpb_regions_build");
+  return SMML_OK;
+}
+
+static int check_region(const char* fn, int B, int N, int J, int H) {
+  int rc = check_common(fn, B, N, J, H, H, 2);
+  if (rc) return rc;
+  SMML_REQUIRE(J <= 1024, "%s: the region kernels take at most 1024 keys (got %d)", fn, J);
+  return SMML_OK;
+}
+
+int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, const void* tables, float* out, float* lse, float* logits_t,
+                                    unsigned short* region_ids, int B, int N, int J, int H, float scale, float dropout_p,
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+  int rc = check_region("smml_deform_attn_region_fwd_f32", B, N, J, H);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_region_fwd_f32: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && tables && out && lse,
+               "smml_deform_attn_region_fwd_f32: null pointer");
+  SMML_REQUIRE((logits_t == nullptr) == (region_ids == nullptr),
+               "smml_deform_attn_region_fwd_f32: logits_t and region_ids are saved together (training) or not at all");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  const RegionView rv = region_view(const_cast<void*>(tables));
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B), block(256);
+  const int nst = smml_deform_attn_nst(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (region_ids)
+    hipLaunchKernelGGL(deform_region_fwd_kernel<true>, grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits_t, region_ids, N, J,
+                       H, nst, scale, dc);
+  else
+    hipLaunchKernelGGL(deform_region_fwd_kernel<false>, grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits_t, region_ids, N, J,
+                       H, nst, scale, dc);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK("smml_deform_attn_region_fwd_f32");
+  return SMML_OK;
+}
+
+size_t smml_deform_attn_region_bwd_workspace_bytes(int B, int N, int J, int H) {
+  if (B <= 0 || N <= 0 || J <= 0 || H <= 0) return 0;
+  return region_bwd_plan(B, N, J, H).total;
+}
+
+int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                    const float* b3, const void* tables, const float* out, const float* dout, const float* lse,
+                                    const float* logits_t, const unsigned short* region_ids, float* dlogits_t, float* dq, float* dk,
+                                    float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                                    void* workspace, size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+  int rc = check_region("smml_deform_attn_region_bwd_f32", B, N, J, H);
+  if (rc) return rc;
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_region_bwd_f32: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && tables && out && dout && lse && logits_t && region_ids &&
+                   dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
+               "smml_deform_attn_region_bwd_f32: null pointer");
+  const RegionBwdPlan pl = region_bwd_plan(B, N, J, H);
+  SMML_REQUIRE(workspace_bytes >= pl.total, "smml_deform_attn_region_bwd_f32: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 255) == 0, "smml_deform_attn_region_bwd_f32: workspace must be 256-byte aligned");
+  SMML_REQUIRE(pl.wpk >= 1, "smml_deform_attn_region_bwd_f32: too many keys (%d)", J);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  hipStream_t st = (hipStream_t)stream;
+  const int nst = smml_deform_attn_nst(N);
+  const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
+  dim3 block(256);
+  const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
+  float* wsf = reinterpret_cast<float*>(workspace);
+  char* wsb = reinterpret_cast<char*>(workspace);
+  unsigned* amax = reinterpret_cast<unsigned*>(wsb + pl.amax);
+  unsigned long long* hist = reinterpret_cast<unsigned long long*>(wsb + pl.hist);
+  unsigned long long* grad = reinterpret_cast<unsigned long long*>(wsb + pl.grad);
+  // the accumulators of this launch: amax | hist | grad are contiguous
+  (void)hipMemsetAsync(wsb + pl.amax, 0, pl.dvs - pl.amax, st);
+  // pass 1: dS^T, dQ, max |dS|
+  hipLaunchKernelGGL(deform_attn_bwd_dq_kernel, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits_t, dlogits_t, dq,
+                     wsf + wsl.rho, amax, N, J, H, nst, scale, dc);
+  SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/dq");
+  // pass 2: dK, dV
+  {
+    const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+    const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
+    const int nslices = parts * H * B;
+    hipLaunchKernelGGL(deform_attn_bwd_dkv_kernel, dim3(((nslices + 7) / 8) * 8 * nkg), block, 0, st, q, dout, lse, logits_t, dlogits_t,
+                       wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/dkv");
+    const size_t n4 = (size_t)B * J * H * DH / 4;
+    hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st, reinterpret_cast<const float4*>(wsf + wsl.dkp),
+                       reinterpret_cast<const float4*>(wsf + wsl.dvp), reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts,
+                       scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/dkv_reduce");
+  }
+  // pass 3: position bias - d vs per pair, region moments, then the dense pass to the six parameter gradients
+  {
+    const RegionTables rt = region_tables(const_cast<void*>(tables));
+    const RegionView rv = region_view(const_cast<void*>(tables));
+    float* dvs_slab = reinterpret_cast<float*>(wsb + pl.dvs);
+    double* part = reinterpret_cast<double*>(wsb + pl.part);
+    {   // 89 KB of dynamic LDS: above the 64 KB a kernel gets without asking (a host-side attribute of the function: cheap, idempotent)
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_region_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(RegionBwdLds));
+      SMML_REQUIRE(e == hipSuccess, "smml_deform_attn_region_bwd_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+    hipLaunchKernelGGL(cpb_region_bwd_kernel, dim3(pl.chunks, H, B), dim3(64 * pl.nkb * pl.wpk), sizeof(RegionBwdLds), st, dlogits_t,
+                       region_ids, vs, gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.wpk, pl.tiles_per_chunk, pl.kbits,
+                       pl.shift);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/cpb");
+    const size_t n = (size_t)B * H * J;
+    hipLaunchKernelGGL(region_dvs_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float2*>(dvs_slab), reinterpret_cast<float2*>(dvs), n, pl.chunks);
+    const int groups = RG_RCAP / RG_FIN;
+    hipLaunchKernelGGL(region_final1_kernel, dim3(groups), dim3(256), 0, st, rt, hist, part);
+    hipLaunchKernelGGL(region_final2_kernel, dim3((RG_GRAD + 255) / 256), dim3(256), 0, st, part, groups, grad, amax, pl.kbits - pl.shift, dw1,
+                       db1, dw2, db2, dw3, db3);
+    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/final");
   }
   return SMML_OK;
 }

@@ -169,12 +169,14 @@ class DeformCrossAttention2D(nn.Module):
         k = Fh.grouped_pointwise(kv, self.to_k.weight, gk)
         v = Fh.grouped_pointwise(kv, self.to_v.weight, gk)
         tab = {}
+        # |gq|, |vs| are bounded by the grids' shapes and tanh . offset_scale (normalize_grid divides x by rows - 1, y by cols - 1)
+        th, tw = vgrid.shape[-2:]
+        lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
+        gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
+        vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
+        if self.compute_dtype is None and not self.consistent_grid_norm:
+            tab = {"cpb_region_pmax": Fh.table_pmax(gqb, vsb)}      # the square the region tables of the position bias cover (no host sync)
         if self.cpb_table:
-            # |gq|, |vs| are bounded by the grids' shapes and tanh . offset_scale (normalize_grid divides x by rows - 1, y by cols - 1)
-            th, tw = vgrid.shape[-2:]
-            lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
-            gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
-            vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
             tab = {"cpb_table": self.cpb_table, "cpb_table_pmax": None if self.consistent_grid_norm else Fh.table_pmax(gqb, vsb),   # None: from the data
                    "cpb_table_grid": (Hh, Ww)}                 # gq is a regular grid in both normalisations
         o = Fh.deform_attention(q, k, v, vs, gq, *self.rel_pos_bias.tensors(), heads=H, groups=G, scale=self.scale,

@@ -869,10 +869,64 @@ def _dtype16(compute_dtype):
 TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
 
 
+# fp32-grade path, 2-D positions: the position bias per LINEAR REGION of its MLP (csrc/cpb_regions.h, include/smml.h) - exact, and the
+# default wherever it applies (signed-log offsets, one head per offset group, J <= 1024).  SMML_CPB_REGIONS=0 keeps the per-pair MLP
+# kernels (the cross-check of tests/test_gpu_regions.py, and the path of every other configuration).
+CPB_REGIONS = __import__("os").environ.get("SMML_CPB_REGIONS", "1") != "0"
+REGION_MAX_KEYS = 1024
+
+
+REGION_GRID, REGION_SUB, REGION_SUBCAP, REGION_EDGECAP, REGION_RCAP = 1024, 8, 16384, 1 << 18, 4096     # csrc/cpb_regions.h
+
+
+def region_tables_view(tables: torch.Tensor):
+    """Views into a region-table buffer (tests / diagnostics; layout: region_layout() of csrc/cpb_regions.h): header counters,
+    (a0, a1, c) per region, ReLU patterns (D1 | D2 << 32), first-level cells, sub-cells, single-kink records."""
+    o = [0]
+
+    def take(nbytes):
+        at = o[0]
+        o[0] += (nbytes + 255) & ~255
+        return at
+    G, SUB = REGION_GRID, REGION_SUB
+    hdr_o, reg_o, pat_o = take(256), take(REGION_RCAP * 16), take(REGION_RCAP * 8)
+    t0_o, t1_o, edge_o = take(G * G * 4), take(REGION_SUBCAP * SUB * SUB * 4), take(REGION_EDGECAP * 16)
+    hdr = tables[hdr_o:hdr_o + 256].view(torch.int32)
+    n_sub, n_edge, n_regions = int(hdr[0]), int(hdr[1]), int(hdr[3])
+    return {"n_sub": n_sub, "n_edge": n_edge, "n_cand": int(hdr[2]), "n_regions": n_regions, "n_keys": int(hdr[4]), "overflow": int(hdr[5]),
+            "pmax": float(hdr[6:7].view(torch.float32)), "cs": float(hdr[7:8].view(torch.float32)), "co": float(hdr[8:9].view(torch.float32)),
+            "reg": tables[reg_o:reg_o + REGION_RCAP * 16].view(torch.float32).view(REGION_RCAP, 4)[:n_regions],
+            "pat": tables[pat_o:pat_o + REGION_RCAP * 8].view(torch.int64)[:n_regions],
+            "t0": tables[t0_o:t0_o + G * G * 4].view(torch.int32).view(G, G),
+            "t1": tables[t1_o:t1_o + REGION_SUBCAP * SUB * SUB * 4].view(torch.int32).view(REGION_SUBCAP, SUB * SUB)[:min(n_sub, REGION_SUBCAP)],
+            "edge": tables[edge_o:edge_o + REGION_EDGECAP * 16].view(torch.float32).view(REGION_EDGECAP, 4)[:min(n_edge, REGION_EDGECAP)]}
+
+
+def region_patterns(region_ids: torch.Tensor, tables: torch.Tensor):
+    """(D1, D2) int64 words of the linear piece of every pair of `region_ids` (tests: the ReLU decisions the region kernels stand for);
+    pairs without a region (0xFFFF: they evaluated the MLP itself) get -1."""
+    pat = region_tables_view(tables)["pat"]
+    ids = region_ids.to(torch.int64) & 0xFFFF
+    none = ids == 0xFFFF
+    p = pat[ids.clamp_max(max(pat.numel() - 1, 0))] if pat.numel() else torch.zeros_like(ids)
+    d1, d2 = p & 0xFFFFFFFF, (p >> 32) & 0xFFFFFFFF
+    return torch.where(none, torch.full_like(d1, -1), d1), torch.where(none, torch.full_like(d2, -1), d2)
+
+
+def cpb_regions_build(w1, b1, w2, b2, w3, b3, pmax: float) -> torch.Tensor:
+    """The region tables of the position-bias MLP with these parameters over [-pmax, pmax]^2 (uint8 scratch owned by the caller)."""
+    L = capi.lib()
+    nbytes = L.smml_cpb_regions_bytes()
+    tables = torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
+    capi.check(L.smml_cpb_regions_build(capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.fptr(_c(w2)), capi.fptr(_c(b2)), capi.fptr(_c(w3)),
+                                        capi.fptr(_c(b3)), float(pmax), capi.ptr(tables), nbytes, capi.stream()), "cpb_regions_build")
+    return tables
+
+
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
-                compute_dtype=None, fork=None, table_pmax_fwd=None, log_distance=True):
+                compute_dtype=None, fork=None, table_pmax_fwd=None, log_distance=True, region_pmax=None):
         ctx.fork = fork
         ctx.log_distance = bool(log_distance)
         if not log_distance and (vs.shape[-1] != 1 or table_pmax_fwd is not None):
@@ -895,6 +949,32 @@ class _DeformAttn(torch.autograd.Function):
         tabfwd = table_pmax_fwd is not None           # 16-bit mode, forward bias from the table; the backward takes layer 2's decisions from a mask table
         ctx.table_pmax = table_pmax_fwd               # (or recomputes layer 2 per pair: TABLE_FORWARD_MASKS)
         ctx.export_masks = None
+        regions = (region_pmax is not None and m16 is None and not tabfwd and posdim == 2 and log_distance and heads == groups
+                   and J <= REGION_MAX_KEYS and tuple(w3.shape) == (1, 32))
+        ctx.regions = regions
+        if regions:
+            tables = cpb_regions_build(w1, b1, w2, b2, w3, b3, region_pmax)
+            rid = None
+            if need_grad:
+                nst = L.smml_deform_attn_nst(N)
+                logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32)
+                rid = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.int16)      # the linear piece of every pair
+            _set_seed_offset(L, seed_offset)
+            capi.check(L.smml_deform_attn_region_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                                         capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                                         capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.fptr(logits),
+                                                         capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
+                                                         *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream()),
+                       "deform_attn_region_fwd")
+            _set_seed_offset(L, None)
+            ctx.seed_offset = seed_offset
+            ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
+            ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, rid, tables)
+            if DECISION_TAP is not None:
+                DECISION_TAP.append({"kind": "attn", "vs": vs.detach(), "gq": gq.detach(), "w1": w1.detach(), "b1": b1.detach(),
+                                     "w2": w2.detach(), "b2": b2.detach(), "masks2": None, "region_ids": rid, "tables": tables,
+                                     "B": B, "N": N, "J": J, "heads": heads, "groups": groups, "table_pmax": None, "log_distance": True})
+            return out
         if need_grad:
             nst = L.smml_deform_attn_nst(N)
             # score-shaped tensors are stored per 32-query tile (include/smml.h): [B, H, nst / 32, J, 32] (+ the lane-half axis of the masks)
@@ -942,6 +1022,8 @@ class _DeformAttn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.regions:
+            return _DeformAttn._backward_regions(ctx, dout)
         q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks = ctx.saved_tensors
         heads, groups, scale, dropout_p, dropout_seed, m16 = ctx.cfg
         B, N, _ = q.shape
@@ -993,7 +1075,34 @@ class _DeformAttn(torch.autograd.Function):
         L.smml_deform_attn_set_log_distance(1)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_regions(ctx, dout):
+        q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, rid, tables = ctx.saved_tensors
+        heads, groups, scale, dropout_p, dropout_seed, _ = ctx.cfg
+        B, N, _ = q.shape
+        J = k.shape[1]
+        L = capi.lib()
+        dout = _c(dout)
+        dlogits = torch.empty_like(logits)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dvs = torch.empty_like(vs)
+        dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
+        wsb = L.smml_deform_attn_region_bwd_workspace_bytes(B, N, J, heads)
+        ws = torch.empty(wsb, device=q.device, dtype=torch.uint8)
+        _set_seed_offset(L, ctx.seed_offset)
+        capi.check(L.smml_deform_attn_region_bwd_f32(
+            capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1), capi.fptr(w2),
+            capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
+            capi.fptr(logits), capi.ptr(rid), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+            capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3), capi.ptr(ws), wsb,
+            B, N, J, heads, scale, dropout_p, dropout_seed, *TIMER.events("cpb_region_bwd", B * heads * N * J), capi.stream()),
+            "deform_attn_region_bwd")
+        _set_seed_offset(L, None)
+        if ctx.fork is not None and ctx.needs_input_grad[0]:
+            ctx.fork.dq = dq.view(B, N, -1)
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1132,7 +1241,8 @@ def graph_seed_offset(device, allocate_only: bool = False):
 
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
                      dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None,
-                     cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None, log_distance: bool = True):
+                     cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None, log_distance: bool = True,
+                     cpb_regions=None, cpb_region_pmax=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
@@ -1159,8 +1269,15 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
         table = cpb_table_fn(w1, b1, w2, b2, w3, b3, posdim=posdim, pmax=cpb_table_pmax, device=q.device)
         return _DeformAttnTable.apply(q, k, v, vs, gq, table, heads, groups, scale, dropout_p, dropout_seed, dropout_seed_offset,
                                       compute_dtype, fork, cpb_table_pmax, cpb_table_grid)
+    # fp32-grade path: the position bias per linear region of its MLP wherever that applies (see CPB_REGIONS); cpb_regions False / True
+    # overrides the default, cpb_region_pmax = half-width of the tabulated square in signed-log units (None: from the data, one host sync)
+    use_regions = CPB_REGIONS if cpb_regions is None else bool(cpb_regions)
+    region_pmax = None
+    if (use_regions and compute_dtype is None and log_distance and vs.shape[-1] == 2 and heads == groups and k.shape[1] <= REGION_MAX_KEYS
+            and tuple(w3.shape) == (1, 32)):
+        region_pmax = cpb_region_pmax if cpb_region_pmax is not None else table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
-                             dropout_seed_offset, compute_dtype, fork, None, log_distance)
+                             dropout_seed_offset, compute_dtype, fork, None, log_distance, region_pmax)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):

@@ -185,6 +185,15 @@ class Decisions:
         assert a["vs"].shape[0] == BG == B * G and a["J"] == J
         self.N = N
         self.m1 = self.m2 = None
+        self.regions = None
+        if a.get("region_ids") is not None:   # region kernels (csrc/cpb_regions.h): a pair's decisions are the ReLU patterns of its linear piece
+            rid = a["region_ids"]
+            nst = rid.shape[2] * 32
+            self.regions = {"rid": (rid.view(B, H, nst // 32, J, 32).permute(0, 1, 3, 2, 4).reshape(B * H, J, nst)).cpu(),
+                            "pat": Fh.region_tables_view(a["tables"])["pat"].cpu(),
+                            "w": [a[k].detach().double().cpu() for k in ("w1", "b1", "w2", "b2")], "vs": a["vs"].detach().double().cpu(),
+                            "gq": a["gq"].detach().double().cpu()}
+            return
         if a["masks2"] is None:           # table mode of the 16-bit core: the MLP runs on grid points only, no per-pair ReLU decisions
             return
         self.m1 = Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G, log_distance=a.get("log_distance", True)).cpu()          # int16 [(B G), J, 2, nst]
@@ -204,9 +213,47 @@ class Decisions:
         return out
 
     def relu_masks(self, i0, i1, device="cpu"):
+        if self.regions is not None:
+            return region_decisions(self.regions, i0, i1, device)
         if self.m2 is None:
             return None
         return self.decode(self.m1, i0, i1, device), self.decode(self.m2, i0, i1, device)
+
+
+def region_decisions(r, i0, i1, device="cpu"):
+    """(m1, m2) bool [(B G), i1 - i0, J, 32] from the region ids of the pairs: the ReLU patterns (D1 | D2 << 32) of each pair's linear
+    piece; pairs without a region (id 0xFFFF: the kernels evaluated the MLP for them) take the decisions of an fp64 evaluation."""
+    ids = (r["rid"][:, :, i0:i1].to(device).to(torch.int64) & 0xFFFF).transpose(1, 2)          # [(B G), n, J]
+    pat = r["pat"].to(device)
+    none = ids == 0xFFFF
+    words = pat[ids.clamp_max(max(pat.numel() - 1, 0))] if pat.numel() else torch.zeros_like(ids)
+    sh = torch.arange(32, device=device)
+    m1 = ((words[..., None] >> sh) & 1).bool()
+    m2 = ((words[..., None] >> (sh + 32)) & 1).bool()
+    if bool(none.any()):
+        w1, b1, w2, b2 = (t.to(device) for t in r["w"])
+        pos = r["gq"].to(device)[None, i0:i1, None, :] - r["vs"].to(device)[:, None, :, :]
+        x1 = (torch.sign(pos) * torch.log(pos.abs() + 1)) @ w1.T + b1
+        x2 = torch.relu(x1) @ w2.T + b2
+        m1 = torch.where(none[..., None], x1 > 0, m1)
+        m2 = torch.where(none[..., None], x2 > 0, m2)
+    return m1, m2
+
+
+def decisions_of(attn_entry, device):
+    """(m1, m2) bool [(B G), N, J, 32] of ONE fused-attention launch (an entry of functional.DECISION_TAP), either kernel family."""
+    a = attn_entry
+    Fh = smml.functional
+    B, N, J, G, H = a["B"], a["N"], a["J"], a["groups"], a["heads"]
+    if a.get("region_ids") is not None:
+        rid = a["region_ids"]
+        nst = rid.shape[2] * 32
+        r = {"rid": rid.view(B, H, nst // 32, J, 32).permute(0, 1, 3, 2, 4).reshape(B * H, J, nst), "pat": Fh.region_tables_view(a["tables"])["pat"],
+             "w": [a[k].detach().double() for k in ("w1", "b1", "w2", "b2")], "vs": a["vs"].detach().double(), "gq": a["gq"].detach().double()}
+        return region_decisions(r, 0, N, device)
+    m1 = Decisions.decode(Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=G, log_distance=a.get("log_distance", True)), 0, N, device)
+    m2 = Decisions.decode(Fh.relu_masks_rows(a["masks2"])[:, ::H // G].reshape(B * G, J, 2, -1), 0, N, device)
+    return m1, m2
 
 
 class decision_tap:

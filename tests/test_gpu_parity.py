@@ -583,9 +583,7 @@ def test_fused_core_random_shapes(cuda):
         (out * wo.to(cuda)).sum().backward()
         keep = Fh.deform_attention_dropout_mask(B, N, J, heads, p_drop, seed, cuda) if p_drop else None
         # the ReLU decisions the kernels took (layer 1 exported, layer 2 as saved for the backward), imposed on both torch evaluations
-        a = tapped[0]
-        m1 = helpers.Decisions.decode(Fh.relu1_masks(a["vs"], a["gq"], a["w1"], a["b1"], B=B, N=N, J=J, groups=groups), 0, N, cuda)
-        m2 = helpers.Decisions.decode(Fh.relu_masks_rows(a["masks2"])[:, ::heads // groups].reshape(B * groups, J, 2, -1), 0, N, cuda)
+        m1, m2 = helpers.decisions_of(tapped[0], cuda)          # either kernel family: per-pair MLP (saved bits) or linear regions
         refs = {}
         for dt in (torch.float32, torch.float64):
             r = {n: x.to(cuda, dt).requires_grad_() for n, x in t.items()}
