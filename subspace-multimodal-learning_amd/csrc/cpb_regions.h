@@ -27,10 +27,15 @@
 
 namespace {
 
+#ifndef SMML_RGN_EXP
+#define SMML_RGN_EXP 0                   // measurement variants of the region forward (tests/build_variants.py): 1 no cell gather, 2 no record /
+#endif                                   // sub-cell resolution, 3 no score store, 4 no region-id store, 5 no signed logs, 6 no LDS (a, c) read
 constexpr int RG_G = 1024;               // level-0 cells per axis
 constexpr int RG_SUB = 8;                // sub-cells per axis of a refined cell
+constexpr int RG_SUBC = (RG_SUB + 1) * (RG_SUB + 1);
 constexpr int RG_SUBCAP = 16384;         // refined cells (8 x 8 entries each)
-constexpr int RG_EDGECAP = 1 << 18;      // single-kink records
+constexpr int RG_EDGES = 1 << 15;        // hash slots of the single-kink records (one per pair of adjacent regions)
+constexpr unsigned RG_E_SUB0 = 4096u, RG_E_EDGE0 = RG_E_SUB0 + 16384u;   // 16-bit cell codes: [0, 4096) region id | [4096, 20480) refined cell | [20480, 53248) record slot | 0xFFFF evaluate the MLP
 constexpr int RG_CANDCAP = 1 << 18;      // cells whose single kink is a layer-1 line, awaiting their check
 constexpr int RG_HASH = 16384;           // hash slots of the region patterns (< 2^16: a slot fits the 16-bit fields of a record)
 constexpr int RG_RCAP = 4096;            // regions with a dense id; patterns beyond it fall to kind 3
@@ -40,14 +45,15 @@ constexpr unsigned long long RG_EMPTY = ~0ull;
 constexpr unsigned RG_K_REGION = 0u << 30, RG_K_EDGE = 1u << 30, RG_K_SUB = 2u << 30, RG_K_MLP = 3u << 30, RG_PAYLOAD = 0x3FFFFFFFu;
 
 struct RegionHeader {                    // first 256 bytes of the table buffer
-  unsigned n_sub, n_edge, n_cand, n_regions, n_keys, overflow;   // overflow: bit 0 sub-blocks, 1 records, 2 candidates, 3 hash, 4 regions
+  unsigned n_sub, n_edge, n_cand, n_regions, n_keys, overflow;   // overflow: bit 0 refined cells, 1 records, 2 candidates, 3 hash, 4 regions
+  unsigned n_cand1, pad0;                  // candidates among the sub-cells
   float pmax, cs, co, pad;               // cell of p: floor(p * cs + co)
-  unsigned stats[8];
+  unsigned stats[6];
 };
 
 // byte offsets inside the table buffer (all multiples of 256)
 struct RegionLayout {
-  size_t hdr, reg, pat, t0, t1, edge, hkey, hid, sublist, cand, klist, corners, wd, total;
+  size_t hdr, reg, pat, t0h, t1h, edge, t0, t1, ekey, hkey, hid, sublist, cand, klist, corners, subcorners, wd, total;
 };
 __host__ __device__ inline RegionLayout region_layout() {
   RegionLayout l;
@@ -56,22 +62,29 @@ __host__ __device__ inline RegionLayout region_layout() {
   l.hdr = take(256);
   l.reg = take((size_t)RG_RCAP * 16);                       // float4 {a0, a1, c, 0} per region
   l.pat = take((size_t)RG_RCAP * 8);                        // D1 | D2 << 32
-  l.t0 = take((size_t)RG_G * RG_G * 4);
+  // what the attention kernels read: 16-bit codes of the cells / sub-cells (2 + 2 MB, of which ~2.7 MB are touched) and the records
+  l.t0h = take((size_t)RG_G * RG_G * 2);
+  l.t1h = take((size_t)RG_SUBCAP * RG_SUB * RG_SUB * 2);
+  l.edge = take((size_t)RG_EDGES * 16);                     // float4 {alpha0, alpha1, beta, bits(neg | pos << 16)} at the record's hash slot
+  // build scratch
+  l.t0 = take((size_t)RG_G * RG_G * 4);                     // kind << 30 | payload, regions as hash slots until the remap pass
   l.t1 = take((size_t)RG_SUBCAP * RG_SUB * RG_SUB * 4);
-  l.edge = take((size_t)RG_EDGECAP * 16);                   // float4 {alpha0, alpha1, beta, bits(neg | pos << 16)}
+  l.ekey = take((size_t)RG_EDGES * 4);                      // neg | pos << 16 (region hash slots) of the record in that slot
   l.hkey = take((size_t)RG_HASH * 8);
   l.hid = take((size_t)RG_HASH * 4);
   l.sublist = take((size_t)RG_SUBCAP * 4);
-  l.cand = take((size_t)RG_CANDCAP * 4);
+  l.cand = take((size_t)RG_CANDCAP * 4 * 2);                 // level 0, level 1
   l.klist = take((size_t)RG_HASH * 8 + (size_t)RG_HASH * 4);   // compacted keys, then their slots
   l.corners = take((size_t)(RG_G + 1) * (RG_G + 1) * 8);
+  l.subcorners = take((size_t)RG_SUBCAP * RG_SUBC * 8);        // ReLU patterns at the 9 x 9 corners of every refined cell
   l.wd = take(1200 * 8);                                    // the MLP's parameters in fp64
   l.total = o;
   return l;
 }
 struct RegionTables {                    // device pointers into one table buffer
-  RegionHeader* hdr; float4* reg; unsigned long long* pat; unsigned* t0; unsigned* t1; float4* edge; unsigned long long* hkey;
-  unsigned* hid; unsigned* sublist; unsigned* cand; unsigned long long* klist; unsigned* kslot; uint2* corners; double* wd;
+  RegionHeader* hdr; float4* reg; unsigned long long* pat; unsigned short* t0h; unsigned short* t1h; float4* edge; unsigned* t0; unsigned* t1;
+  unsigned* ekey; unsigned long long* hkey;
+  unsigned* hid; unsigned* sublist; unsigned* cand; unsigned long long* klist; unsigned* kslot; uint2* corners; uint2* subcorners; double* wd;
 };
 inline RegionTables region_tables(void* base) {
   const RegionLayout l = region_layout();
@@ -80,10 +93,12 @@ inline RegionTables region_tables(void* base) {
   t.hdr = reinterpret_cast<RegionHeader*>(b + l.hdr); t.reg = reinterpret_cast<float4*>(b + l.reg);
   t.pat = reinterpret_cast<unsigned long long*>(b + l.pat); t.t0 = reinterpret_cast<unsigned*>(b + l.t0);
   t.t1 = reinterpret_cast<unsigned*>(b + l.t1); t.edge = reinterpret_cast<float4*>(b + l.edge);
+  t.t0h = reinterpret_cast<unsigned short*>(b + l.t0h); t.t1h = reinterpret_cast<unsigned short*>(b + l.t1h); t.ekey = reinterpret_cast<unsigned*>(b + l.ekey);
   t.hkey = reinterpret_cast<unsigned long long*>(b + l.hkey); t.hid = reinterpret_cast<unsigned*>(b + l.hid);
   t.sublist = reinterpret_cast<unsigned*>(b + l.sublist); t.cand = reinterpret_cast<unsigned*>(b + l.cand);
   t.klist = reinterpret_cast<unsigned long long*>(b + l.klist); t.kslot = reinterpret_cast<unsigned*>(b + l.klist + (size_t)RG_HASH * 8);
-  t.corners = reinterpret_cast<uint2*>(b + l.corners); t.wd = reinterpret_cast<double*>(b + l.wd);
+  t.corners = reinterpret_cast<uint2*>(b + l.corners); t.subcorners = reinterpret_cast<uint2*>(b + l.subcorners);
+  t.wd = reinterpret_cast<double*>(b + l.wd);
   return t;
 }
 
@@ -100,12 +115,13 @@ __global__ void region_prep_kernel(CpbParams cp, float pmax, RegionTables t) {
   else if (i == 1184) t.wd[i] = (double)cp.b3[0];
   if (i == 0) {
     RegionHeader h;
-    h.n_sub = h.n_edge = h.n_cand = h.n_regions = h.n_keys = h.overflow = 0;
+    h.n_sub = h.n_edge = h.n_cand = h.n_regions = h.n_keys = h.overflow = h.n_cand1 = h.pad0 = 0;
     h.pmax = pmax; h.cs = (float)((double)RG_G / (2.0 * (double)pmax)); h.co = (float)(RG_G / 2); h.pad = 0.f;
-    for (int k = 0; k < 8; ++k) h.stats[k] = 0;
+    for (int k = 0; k < 6; ++k) h.stats[k] = 0;
     *t.hdr = h;
   }
   for (int s = i; s < RG_HASH; s += gridDim.x * blockDim.x) t.hkey[s] = RG_EMPTY;
+  for (int s = i; s < RG_EDGES; s += gridDim.x * blockDim.x) t.ekey[s] = 0xFFFFFFFFu;
 }
 
 // ReLU patterns of the MLP at p in fp64, "natural" evaluation (every unit decides by its own pre-activation).  wd: uniform address
@@ -139,15 +155,31 @@ __global__ __launch_bounds__(256) void region_corners_kernel(RegionTables t) {
   t.corners[i] = region_eval(t.wd, -pm + ix * h, -pm + iy * h);
 }
 
+// slot of `key` in the pattern hash (inserted if absent).  A million cells name ~2 000 patterns: the slot is READ first (an L2 read,
+// past the CU's L1, which is not coherent) and the compare-and-swap is issued only on an empty slot.
 __device__ __forceinline__ unsigned region_hash_insert(unsigned long long* __restrict__ hkey, unsigned long long key) {
   if (key == RG_EMPTY) return RG_NONE;              // the all-ones pattern doubles as the empty marker: such pairs take the MLP path
   unsigned slot = (unsigned)(mix64(key) & (RG_HASH - 1));
   for (int probe = 0; probe < RG_HASH; ++probe) {
-    const unsigned long long prev = atomicCAS(&hkey[slot], RG_EMPTY, key);
-    if (prev == RG_EMPTY || prev == key) return slot;
+    unsigned long long cur = __hip_atomic_load(&hkey[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == RG_EMPTY) {
+      cur = atomicCAS(&hkey[slot], RG_EMPTY, key);
+      if (cur == RG_EMPTY) return slot;
+    }
+    if (cur == key) return slot;
     slot = (slot + 1) & (RG_HASH - 1);
   }
   return RG_NONE;
+}
+// the same for a wave whose neighbouring lanes mostly hold the same key: the first lane of every run inserts, the others then find it
+__device__ __forceinline__ unsigned region_hash_insert_runs(unsigned long long* __restrict__ hkey, unsigned long long key, bool active) {
+  const unsigned long long prev = __shfl_up(key, 1);
+  const bool prev_active = __shfl_up((int)active, 1) != 0;
+  const bool leader = active && ((threadIdx.x & 63) == 0 || !prev_active || prev != key);
+  unsigned slot = RG_NONE;
+  if (leader) slot = region_hash_insert(hkey, key);
+  if (active && !leader) slot = region_hash_insert(hkey, key);
+  return slot;
 }
 
 // record of a cell crossed by the kink of layer-2 unit o while every layer-1 unit keeps its sign d1: inside the cell
@@ -170,25 +202,63 @@ __device__ __forceinline__ float4 region_edge_l1(const double* __restrict__ wd, 
   const unsigned pos = region_hash_insert(hkey, (unsigned long long)(d1 | bit) | ((unsigned long long)d2 << 32));
   return make_float4((float)wd[WD_W1 + 2 * u], (float)wd[WD_W1 + 2 * u + 1], (float)wd[WD_B1 + u], __uint_as_float(neg | (pos << 16)));
 }
-__device__ __forceinline__ unsigned region_new_edge(RegionTables t, float4 rec) {
-  const unsigned idx = atomicAdd(&t.hdr->n_edge, 1u);
-  if (idx >= (unsigned)RG_EDGECAP) { atomicOr(&t.hdr->overflow, 2u); return RG_K_MLP; }
-  t.edge[idx] = rec;
-  return RG_K_EDGE | idx;
+// one slot of a list per lane that wants one: a single atomic per wave (ballot + prefix count) instead of one per lane on one counter.
+// Every lane of the wave must call it.
+__device__ __forceinline__ unsigned wave_alloc(unsigned* counter, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return 0u;
+  const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+  unsigned base = 0u;
+  if (lane == first) base = atomicAdd(counter, (unsigned)__popcll(m));
+  base = __shfl(base, first);
+  return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+// The record of a one-kink cell, shared by every cell the same kink segment crosses: two adjacent regions meet in exactly one kink, so
+// the pair (negative side, positive side) names the record - a hash of 32 K slots, the slot is the record's 15-bit id.  Every cell of the
+// segment computes the same record and may write it (identical values).  `want` lanes get an entry (callable by any subset of lanes).
+__device__ __forceinline__ unsigned region_new_edge(RegionTables t, bool want, float4 rec) {
+  if (!want) return RG_K_MLP;
+  const unsigned key = __float_as_uint(rec.w);
+  if ((key & 0xFFFFu) == RG_NONE || (key >> 16) == RG_NONE) return RG_K_MLP;       // a side without a hash slot (hash full)
+  unsigned slot = (unsigned)(mix64((unsigned long long)key) & (RG_EDGES - 1));
+  for (int probe = 0; probe < RG_EDGES; ++probe) {
+    unsigned cur = __hip_atomic_load(&t.ekey[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0xFFFFFFFFu) {
+      cur = atomicCAS(&t.ekey[slot], 0xFFFFFFFFu, key);
+      if (cur == 0xFFFFFFFFu) { atomicAdd(&t.hdr->n_edge, 1u); cur = key; }
+    }
+    if (cur == key) { t.edge[slot] = rec; return RG_K_EDGE | slot; }
+    slot = (slot + 1) & (RG_EDGES - 1);
+  }
+  atomicOr(&t.hdr->overflow, 2u);
+  return RG_K_MLP;
+}
+// appends a refined cell (wave-wide; `want` lanes get an entry)
+__device__ __forceinline__ unsigned region_new_sub(RegionTables t, bool want, unsigned cell) {
+  const unsigned idx = wave_alloc(&t.hdr->n_sub, want);
+  if (!want) return RG_K_MLP;
+  if (idx >= (unsigned)RG_SUBCAP) { atomicOr(&t.hdr->overflow, 1u); return RG_K_MLP; }
+  t.sublist[idx] = cell;
+  return RG_K_SUB | idx;
 }
 
-// Classification of one cell from the patterns of its four corners.  -> final entry, or RG_K_SUB without payload = "several kinks"
-// (the caller refines or gives up), or 0xFFFFFFFF = "one layer-1 line crosses it, layer-2 signs equal at the corners": to be checked
-// at the two points where the line leaves the cell (the only places a layer-2 unit could still change sign inside it).
+// Classification of one cell from the patterns of its four corners (every lane of the wave calls it; `valid` lanes get an entry).
+// -> final entry, or RG_K_SUB without payload = "several kinks" (the caller refines or gives up), or RG_PENDING = "one layer-1 line
+// crosses it, layer-2 signs equal at the corners": to be checked at the two points where the line leaves the cell (the only places a
+// layer-2 unit could still change sign inside it).
 constexpr unsigned RG_PENDING = 0xFFFFFFFFu;
-__device__ __forceinline__ unsigned region_classify(RegionTables t, uint2 c00, uint2 c10, uint2 c01, uint2 c11) {
+__device__ __forceinline__ unsigned region_classify(RegionTables t, bool valid, uint2 c00, uint2 c10, uint2 c01, uint2 c11) {
   const unsigned m1 = (c00.x ^ c10.x) | (c00.x ^ c01.x) | (c00.x ^ c11.x);
   const unsigned m2 = (c00.y ^ c10.y) | (c00.y ^ c01.y) | (c00.y ^ c11.y);
-  if (m1 == 0u && m2 == 0u) {
-    const unsigned slot = region_hash_insert(t.hkey, (unsigned long long)c00.x | ((unsigned long long)c00.y << 32));
-    return slot == RG_NONE ? RG_K_MLP : (RG_K_REGION | slot);
-  }
-  if (m1 == 0u && __popc(m2) == 1) return region_new_edge(t, region_edge_l2(t.wd, c00.x, c00.y, __ffs(m2) - 1, t.hkey));
+  const bool plain = valid && m1 == 0u && m2 == 0u;
+  const unsigned slot = region_hash_insert_runs(t.hkey, (unsigned long long)c00.x | ((unsigned long long)c00.y << 32), plain);
+  const bool kink2 = valid && m1 == 0u && __popc(m2) == 1;
+  float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kink2) rec = region_edge_l2(t.wd, c00.x, c00.y, __ffs(m2) - 1, t.hkey);
+  const unsigned e_edge = region_new_edge(t, kink2, rec);
+  if (plain) return slot == RG_NONE ? RG_K_MLP : (RG_K_REGION | slot);
+  if (!valid) return RG_K_MLP;
+  if (kink2) return e_edge;
   if (m2 == 0u && __popc(m1) == 1) return RG_PENDING;
   return RG_K_SUB;
 }
@@ -198,89 +268,112 @@ __device__ __forceinline__ bool region_line_cell_ok(const double* __restrict__ w
   const double wx = wd[WD_W1 + 2 * u], wy = wd[WD_W1 + 2 * u + 1], bb = wd[WD_B1 + u];
   const double cx[4] = {x0, x0 + h, x0 + h, x0}, cy[4] = {y0, y0, y0 + h, y0 + h};     // corners in cyclic order
   double v[4];
+#pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = fma(wx, cx[k], fma(wy, cy[k], bb));
-  bool ok = true;
+  double px[2] = {x0, x0}, py[2] = {y0, y0};
+  int n = 0;
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int n = (k + 1) & 3;
-    if ((v[k] > 0.0) != (v[n] > 0.0)) {
-      const double s = v[k] / (v[k] - v[n]);
-      const uint2 m = region_eval(wd, cx[k] + s * (cx[n] - cx[k]), cy[k] + s * (cy[n] - cy[k]));
-      ok = ok && (m.y == d2);
+    const int nx = (k + 1) & 3;
+    if ((v[k] > 0.0) != (v[nx] > 0.0)) {
+      const double s = v[k] / (v[k] - v[nx]);
+      const double qx = cx[k] + s * (cx[nx] - cx[k]), qy = cy[k] + s * (cy[nx] - cy[k]);
+      if (n == 0) { px[0] = qx; py[0] = qy; } else { px[1] = qx; py[1] = qy; }
+      ++n;
     }
   }
-  return ok;
-}
-
-__device__ __forceinline__ unsigned region_new_sub(RegionTables t, unsigned cell) {
-  const unsigned idx = atomicAdd(&t.hdr->n_sub, 1u);
-  if (idx >= (unsigned)RG_SUBCAP) { atomicOr(&t.hdr->overflow, 1u); return RG_K_MLP; }
-  t.sublist[idx] = cell;
-  return RG_K_SUB | idx;
+  if (n != 2) return false;                           // a line through a corner: let the caller refine / evaluate
+  const uint2 ma = region_eval(wd, px[0], py[0]);
+  const uint2 mb = region_eval(wd, px[1], py[1]);
+  return ma.y == d2 && mb.y == d2;
 }
 
 __global__ __launch_bounds__(256) void region_classify0_kernel(RegionTables t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= RG_G * RG_G) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // the grid covers the cells exactly
   const int iy = i / RG_G, ix = i - iy * RG_G;
   constexpr int GP = RG_G + 1;
-  unsigned e;
-  if (ix == 0 || iy == 0 || ix == RG_G - 1 || iy == RG_G - 1) e = RG_K_MLP;      // the border also takes every point outside the square
-  else {
-    e = region_classify(t, t.corners[iy * GP + ix], t.corners[iy * GP + ix + 1], t.corners[(iy + 1) * GP + ix], t.corners[(iy + 1) * GP + ix + 1]);
-    if (e == RG_PENDING) {
-      const unsigned idx = atomicAdd(&t.hdr->n_cand, 1u);
-      if (idx < (unsigned)RG_CANDCAP) { t.cand[idx] = (unsigned)i; e = RG_K_MLP; }      // region_cand0_kernel writes the final entry
-      else { atomicOr(&t.hdr->overflow, 4u); e = region_new_sub(t, (unsigned)i); }
-    } else if (e == RG_K_SUB) e = region_new_sub(t, (unsigned)i);
+  const bool inner = !(ix == 0 || iy == 0 || ix == RG_G - 1 || iy == RG_G - 1);   // the border also takes every point outside the square
+  unsigned e = region_classify(t, inner, t.corners[iy * GP + ix], t.corners[iy * GP + ix + 1], t.corners[(iy + 1) * GP + ix],
+                               t.corners[(iy + 1) * GP + ix + 1]);
+  const bool pending = e == RG_PENDING;
+  const unsigned cidx = wave_alloc(&t.hdr->n_cand, pending);
+  bool refine = e == RG_K_SUB;
+  if (pending) {
+    if (cidx < (unsigned)RG_CANDCAP) { t.cand[cidx] = (unsigned)i; e = RG_K_MLP; }     // region_cand_kernel<0> writes the final entry
+    else { atomicOr(&t.hdr->overflow, 4u); refine = true; }
   }
-  t.t0[i] = e;
+  const unsigned e_sub = region_new_sub(t, refine, (unsigned)i);
+  t.t0[i] = refine ? e_sub : e;
 }
 
-__global__ __launch_bounds__(256) void region_cand0_kernel(RegionTables t) {
-  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= min(t.hdr->n_cand, (unsigned)RG_CANDCAP)) return;
-  const unsigned i = t.cand[k];
-  const int iy = i / RG_G, ix = i - iy * RG_G;
-  constexpr int GP = RG_G + 1;
-  const uint2 c00 = t.corners[iy * GP + ix], c10 = t.corners[iy * GP + ix + 1], c01 = t.corners[(iy + 1) * GP + ix];
-  const unsigned m1 = (c00.x ^ c10.x) | (c00.x ^ c01.x) | (c00.x ^ t.corners[(iy + 1) * GP + ix + 1].x);
-  const int u = __ffs(m1) - 1;
-  const double pm = (double)t.hdr->pmax, h = 2.0 * pm / RG_G;
-  unsigned e;
-  if (region_line_cell_ok(t.wd, u, c00.y, -pm + ix * h, -pm + iy * h, h)) e = region_new_edge(t, region_edge_l1(t.wd, c00.x, c00.y, u, t.hkey));
-  else e = region_new_sub(t, i);
-  t.t0[i] = e;
-}
-
-// level 1: one workgroup per refined cell, 81 sub-corners, 64 sub-cells
-__global__ __launch_bounds__(128) void region_sub_kernel(RegionTables t) {
-  __shared__ uint2 sc[(RG_SUB + 1) * (RG_SUB + 1)];
+// level 1: the 9 x 9 corners of every refined cell (one thread per corner), then its 8 x 8 sub-cells (one thread per sub-cell)
+__global__ __launch_bounds__(256) void region_subcorners_kernel(RegionTables t) {
   const unsigned nsub = min(t.hdr->n_sub, (unsigned)RG_SUBCAP);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsub * RG_SUBC) return;
+  const unsigned blk = i / RG_SUBC, k = i - blk * RG_SUBC;
+  const unsigned cell = t.sublist[blk];
+  const int iy = cell / RG_G, ix = cell - iy * RG_G, sy = k / (RG_SUB + 1), sx = k - sy * (RG_SUB + 1);
   const double pm = (double)t.hdr->pmax, h = 2.0 * pm / RG_G, hs = h / RG_SUB;
-  for (unsigned blk = blockIdx.x; blk < nsub; blk += gridDim.x) {
+  t.subcorners[i] = region_eval(t.wd, -pm + ix * h + sx * hs, -pm + iy * h + sy * hs);
+}
+__global__ __launch_bounds__(256) void region_classify1_kernel(RegionTables t) {
+  const unsigned nsub = min(t.hdr->n_sub, (unsigned)RG_SUBCAP);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < nsub * (RG_SUB * RG_SUB);
+  const unsigned ic = valid ? i : 0u;
+  const unsigned blk = ic / (RG_SUB * RG_SUB), k = ic - blk * (RG_SUB * RG_SUB);
+  const int sy = k / RG_SUB, sx = k - sy * RG_SUB;
+  const uint2* sc = t.subcorners + (size_t)blk * RG_SUBC;
+  uint2 z = make_uint2(0u, 0u);
+  const uint2 c00 = nsub ? sc[sy * (RG_SUB + 1) + sx] : z, c10 = nsub ? sc[sy * (RG_SUB + 1) + sx + 1] : z,
+              c01 = nsub ? sc[(sy + 1) * (RG_SUB + 1) + sx] : z, c11 = nsub ? sc[(sy + 1) * (RG_SUB + 1) + sx + 1] : z;
+  unsigned e = region_classify(t, valid, c00, c10, c01, c11);
+  const bool pending = valid && e == RG_PENDING;
+  const unsigned cidx = wave_alloc(&t.hdr->n_cand1, pending);
+  if (!valid) return;
+  if (pending) {
+    if (cidx < (unsigned)RG_CANDCAP) t.cand[RG_CANDCAP + cidx] = i;
+    else atomicOr(&t.hdr->overflow, 4u);
+    e = RG_K_MLP;                                                   // region_cand_kernel<1> writes the final entry
+  } else if (e == RG_K_SUB) e = RG_K_MLP;
+  t.t1[i] = e;
+}
+
+// the cells one layer-1 line crosses: edge record if no layer-2 unit changes sign where the line leaves the cell, else refine
+// (level 0) or evaluate the MLP (level 1)
+template <int LEVEL>
+__global__ __launch_bounds__(256) void region_cand_kernel(RegionTables t) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned ncand = min(LEVEL ? t.hdr->n_cand1 : t.hdr->n_cand, (unsigned)RG_CANDCAP);
+  if (blockIdx.x * blockDim.x >= ncand) return;                     // whole workgroup
+  const bool valid = k < ncand;
+  const unsigned i = t.cand[LEVEL * RG_CANDCAP + (valid ? k : 0u)];
+  const double pm = (double)t.hdr->pmax, h = 2.0 * pm / RG_G, hs = h / RG_SUB;
+  uint2 c00, c10, c01, c11;
+  double x0, y0, hh;
+  if (LEVEL == 0) {
+    const int iy = i / RG_G, ix = i - iy * RG_G;
+    constexpr int GP = RG_G + 1;
+    c00 = t.corners[iy * GP + ix]; c10 = t.corners[iy * GP + ix + 1]; c01 = t.corners[(iy + 1) * GP + ix]; c11 = t.corners[(iy + 1) * GP + ix + 1];
+    x0 = -pm + ix * h; y0 = -pm + iy * h; hh = h;
+  } else {
+    const unsigned blk = i / (RG_SUB * RG_SUB), kk = i - blk * (RG_SUB * RG_SUB);
+    const int sy = kk / RG_SUB, sx = kk - sy * RG_SUB;
+    const uint2* sc = t.subcorners + (size_t)blk * RG_SUBC;
+    c00 = sc[sy * (RG_SUB + 1) + sx]; c10 = sc[sy * (RG_SUB + 1) + sx + 1]; c01 = sc[(sy + 1) * (RG_SUB + 1) + sx]; c11 = sc[(sy + 1) * (RG_SUB + 1) + sx + 1];
     const unsigned cell = t.sublist[blk];
     const int iy = cell / RG_G, ix = cell - iy * RG_G;
-    const double x0 = -pm + ix * h, y0 = -pm + iy * h;
-    __syncthreads();
-    if (threadIdx.x < (RG_SUB + 1) * (RG_SUB + 1)) {
-      const int sy = threadIdx.x / (RG_SUB + 1), sx = threadIdx.x - sy * (RG_SUB + 1);
-      sc[threadIdx.x] = region_eval(t.wd, x0 + sx * hs, y0 + sy * hs);
-    }
-    __syncthreads();
-    if (threadIdx.x < RG_SUB * RG_SUB) {
-      const int sy = threadIdx.x / RG_SUB, sx = threadIdx.x - sy * RG_SUB;
-      const uint2 c00 = sc[sy * (RG_SUB + 1) + sx], c10 = sc[sy * (RG_SUB + 1) + sx + 1], c01 = sc[(sy + 1) * (RG_SUB + 1) + sx],
-                  c11 = sc[(sy + 1) * (RG_SUB + 1) + sx + 1];
-      unsigned e = region_classify(t, c00, c10, c01, c11);
-      if (e == RG_PENDING) {
-        const unsigned m1 = (c00.x ^ c10.x) | (c00.x ^ c01.x) | (c00.x ^ c11.x);
-        const int u = __ffs(m1) - 1;
-        e = region_line_cell_ok(t.wd, u, c00.y, x0 + sx * hs, y0 + sy * hs, hs) ? region_new_edge(t, region_edge_l1(t.wd, c00.x, c00.y, u, t.hkey))
-                                                                                   : RG_K_MLP;
-      } else if (e == RG_K_SUB) e = RG_K_MLP;
-      t.t1[(size_t)blk * (RG_SUB * RG_SUB) + threadIdx.x] = e;
-    }
+    x0 = -pm + ix * h + sx * hs; y0 = -pm + iy * h + sy * hs; hh = hs;
   }
+  const unsigned m1 = (c00.x ^ c10.x) | (c00.x ^ c01.x) | (c00.x ^ c11.x);
+  const int u = __ffs(m1) - 1;
+  const bool ok = valid && region_line_cell_ok(t.wd, u, c00.y, x0, y0, hh);
+  float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) rec = region_edge_l1(t.wd, c00.x, c00.y, u, t.hkey);
+  const unsigned e_edge = region_new_edge(t, ok, rec);
+  const unsigned e_sub = LEVEL == 0 ? region_new_sub(t, valid && !ok, i) : RG_K_MLP;
+  if (valid) (LEVEL == 0 ? t.t0 : t.t1)[i] = ok ? e_edge : e_sub;
 }
 
 // dense region ids = rank of the pattern among the patterns in use (independent of insertion order)
@@ -295,49 +388,64 @@ __global__ __launch_bounds__(256) void region_compact_kernel(RegionTables t) {
   }
 }
 __global__ __launch_bounds__(256) void region_rank_kernel(RegionTables t) {
+  __shared__ unsigned long long ks[2048];
   const unsigned n = t.hdr->n_keys;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { t.hdr->n_regions = min(n, (unsigned)RG_RCAP); if (n > (unsigned)RG_RCAP) atomicOr(&t.hdr->overflow, 16u); }
-  if (i >= n) return;
-  const unsigned long long k = t.klist[i];
+  if (blockIdx.x * blockDim.x >= n) return;                                  // whole workgroup
+  const unsigned long long k = i < n ? t.klist[i] : 0ull;
   unsigned rank = 0;
-  for (unsigned j = 0; j < n; ++j) rank += (t.klist[j] < k) ? 1u : 0u;
-  if (rank >= (unsigned)RG_RCAP) return;                                     // hid stays RG_NONE: the MLP path
+  for (unsigned base = 0; base < n; base += 2048) {
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < 2048 && base + j < n; j += 256) ks[j] = t.klist[base + j];
+    __syncthreads();
+    const unsigned m = min(2048u, n - base);
+    for (unsigned j = 0; j < m; ++j) rank += (ks[j] < k) ? 1u : 0u;
+  }
+  if (i >= n || rank >= (unsigned)RG_RCAP) return;                           // hid stays RG_NONE: the MLP path
   t.hid[t.kslot[i]] = rank;
   t.pat[rank] = k;
-  // (a, c) of the region: c1_i = d1_i sum_o W2[o][i] w3[o] d2_o;  a = sum_i c1_i W1[i];  c = sum_i c1_i b1[i] + sum_o d2_o w3[o] b2[o] + b3
-  const double* __restrict__ wd = t.wd;
-  const unsigned d1 = (unsigned)k, d2 = (unsigned)(k >> 32);
-  double a0 = 0.0, a1 = 0.0, c = wd[WD_B3];
-  for (int o = 0; o < CH; ++o)
-    if ((d2 >> o) & 1u) c = fma(wd[WD_W3 + o], wd[WD_B2 + o], c);
-  for (int i2 = 0; i2 < CH; ++i2) {
-    if (!((d1 >> i2) & 1u)) continue;
-    double c1 = 0.0;
-    for (int o = 0; o < CH; ++o)
-      if ((d2 >> o) & 1u) c1 = fma(wd[WD_W2 + o * CH + i2], wd[WD_W3 + o], c1);
-    a0 = fma(c1, wd[WD_W1 + 2 * i2], a0); a1 = fma(c1, wd[WD_W1 + 2 * i2 + 1], a1); c = fma(c1, wd[WD_B1 + i2], c);
-  }
-  t.reg[rank] = make_float4((float)a0, (float)a1, (float)c, 0.f);
 }
-// hash slots -> dense ids in the cell tables and the records
+// (a, c) of every region, one wave per region (lane = hidden unit i; the two halves compute the same):
+//   c1_i = d1_i sum_o W2[o][i] w3[o] d2_o;  a = sum_i c1_i W1[i];  c = sum_i c1_i b1[i] + sum_o d2_o w3[o] b2[o] + b3
+__global__ __launch_bounds__(256) void region_coef_kernel(RegionTables t) {
+  const unsigned r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= t.hdr->n_regions) return;
+  const int i = threadIdx.x & 31;
+  const double* __restrict__ wd = t.wd;
+  const unsigned long long k = t.pat[r];
+  const unsigned d1 = (unsigned)k, d2 = (unsigned)(k >> 32);
+  double c1 = 0.0;
+  for (int o = 0; o < CH; ++o)
+    if ((d2 >> o) & 1u) c1 = fma(wd[WD_W2 + o * CH + i], wd[WD_W3 + o], c1);
+  c1 = ((d1 >> i) & 1u) ? c1 : 0.0;
+  double a0 = c1 * wd[WD_W1 + 2 * i], a1 = c1 * wd[WD_W1 + 2 * i + 1];
+  double c = fma(c1, wd[WD_B1 + i], ((d2 >> i) & 1u) ? wd[WD_W3 + i] * wd[WD_B2 + i] : 0.0);
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); c += __shfl_xor(c, off); }
+  if ((threadIdx.x & 63) == 0) t.reg[r] = make_float4((float)a0, (float)a1, (float)(c + wd[WD_B3]), 0.f);
+}
+// hash slots -> dense ids: the 16-bit cell codes the attention kernels read, and the region fields of the records
+__device__ __forceinline__ unsigned short region_code(const RegionTables& t, unsigned e) {
+  const unsigned kind = e >> 30, pay = e & RG_PAYLOAD;
+  if (kind == 0u) return (unsigned short)t.hid[pay];                         // dense id, or RG_NONE = 0xFFFF
+  if (kind == 1u) return (unsigned short)(RG_E_EDGE0 + pay);
+  if (kind == 2u) return (unsigned short)(RG_E_SUB0 + pay);
+  return (unsigned short)RG_NONE;
+}
 __global__ __launch_bounds__(256) void region_remap_kernel(RegionTables t) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n0 = (size_t)RG_G * RG_G, n1 = (size_t)min(t.hdr->n_sub, (unsigned)RG_SUBCAP) * (RG_SUB * RG_SUB);
-  const size_t n2 = min(t.hdr->n_edge, (unsigned)RG_EDGECAP);
-  if (i < n0 + n1) {
-    unsigned* p = i < n0 ? &t.t0[i] : &t.t1[i - n0];
-    const unsigned e = *p;
-    if ((e >> 30) == 0u) {
-      const unsigned id = t.hid[e & RG_PAYLOAD];
-      *p = id == RG_NONE ? RG_K_MLP : (RG_K_REGION | id);
+  if (i < n0) t.t0h[i] = region_code(t, t.t0[i]);
+  else if (i < n0 + n1) t.t1h[i - n0] = region_code(t, t.t1[i - n0]);
+  else if (i < n0 + n1 + RG_EDGES) {
+    const size_t k = i - n0 - n1;
+    const unsigned b = t.ekey[k];
+    if (b != 0xFFFFFFFFu) {
+      float4 r = t.edge[k];
+      r.w = __uint_as_float(t.hid[b & 0xFFFFu] | (t.hid[b >> 16] << 16));
+      t.edge[k] = r;
     }
-  } else if (i < n0 + n1 + n2) {
-    float4 r = t.edge[i - n0 - n1];
-    const unsigned b = __float_as_uint(r.w), neg = b & 0xFFFFu, pos = b >> 16;
-    const unsigned ineg = neg == RG_NONE ? RG_NONE : t.hid[neg], ipos = pos == RG_NONE ? RG_NONE : t.hid[pos];
-    r.w = __uint_as_float(ineg | (ipos << 16));
-    t.edge[i - n0 - n1] = r;
   }
 }
 
@@ -347,11 +455,14 @@ static int region_build_launch(CpbParams cp, float pmax, void* tables, hipStream
   constexpr int GP = RG_G + 1;
   hipLaunchKernelGGL(region_corners_kernel, dim3((GP * GP + 255) / 256), dim3(256), 0, st, t);
   hipLaunchKernelGGL(region_classify0_kernel, dim3(RG_G * RG_G / 256), dim3(256), 0, st, t);
-  hipLaunchKernelGGL(region_cand0_kernel, dim3(RG_CANDCAP / 256), dim3(256), 0, st, t);
-  hipLaunchKernelGGL(region_sub_kernel, dim3(4096), dim3(128), 0, st, t);
+  hipLaunchKernelGGL(region_cand_kernel<0>, dim3(RG_CANDCAP / 256), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(region_subcorners_kernel, dim3((RG_SUBCAP * RG_SUBC + 255) / 256), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(region_classify1_kernel, dim3(RG_SUBCAP * RG_SUB * RG_SUB / 256), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(region_cand_kernel<1>, dim3(RG_CANDCAP / 256), dim3(256), 0, st, t);
   hipLaunchKernelGGL(region_compact_kernel, dim3(RG_HASH / 256), dim3(256), 0, st, t);
   hipLaunchKernelGGL(region_rank_kernel, dim3(RG_HASH / 256), dim3(256), 0, st, t);
-  const size_t nmax = (size_t)RG_G * RG_G + (size_t)RG_SUBCAP * RG_SUB * RG_SUB + RG_EDGECAP;
+  hipLaunchKernelGGL(region_coef_kernel, dim3(RG_RCAP / 4), dim3(256), 0, st, t);
+  const size_t nmax = (size_t)RG_G * RG_G + (size_t)RG_SUBCAP * RG_SUB * RG_SUB + RG_EDGES;
   hipLaunchKernelGGL(region_remap_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, st, t);
   return 0;
 }
@@ -361,33 +472,42 @@ static int region_build_launch(CpbParams cp, float pmax, void* tables, hipStream
 // per-pair pieces shared by the region kernels
 // ------------------------------------------------------------------------------------------------
 struct RegionView {                      // what a region kernel reads of the tables
-  const RegionHeader* hdr; const unsigned* t0; const unsigned* t1; const float4* edge; const float4* reg;
+  const RegionHeader* hdr; const unsigned short* t0; const unsigned short* t1; const float4* edge; const float4* reg;
 };
 inline RegionView region_view(void* base) {
   const RegionTables t = region_tables(base);
-  return RegionView{t.hdr, t.t0, t.t1, t.edge, t.reg};
+  return RegionView{t.hdr, t.t0h, t.t1h, t.edge, t.reg};
 }
 __device__ __forceinline__ int region_cell(float u) { return min(max((int)u, 0), RG_G - 1); }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (vmcnt(0)), which would
+// drain the table gathers and the K / V prefetch the forward keeps in flight across its barriers
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // first-level entry address of p (cell coordinates in cx, cy; u = p cs + co)
 __device__ __forceinline__ unsigned region_cell_index(float u0, float u1, int& cx, int& cy) {
   cx = region_cell(u0); cy = region_cell(u1);
   return (unsigned)(cy * RG_G + cx);
 }
-// entry -> region id (RG_NONE: evaluate the MLP).  e: first-level entry of the pair's cell.
+// entry -> region id (RG_NONE: evaluate the MLP).  e: first-level entry of the pair's cell.  The two common kinds (region: 92 %
+// of the pairs, one kink: 8 %) take no branch - every lane reads a kink record (record 0 for the lanes that need none) and selects;
+// refined cells (0.7 %) branch to their sub-cell's entry.
+__device__ __forceinline__ unsigned region_side(const float4 r, float p0, float p1) {
+  const float g = fmaf(r.x, p0, fmaf(r.y, p1, r.z));
+  const unsigned b = __float_as_uint(r.w);
+  return g > 0.f ? (b >> 16) : (b & 0xFFFFu);
+}
 __device__ __forceinline__ unsigned region_resolve(const RegionView& rv, unsigned e, float p0, float p1, float u0, float u1, int cx, int cy) {
-  if ((e >> 30) == 2u) {                                    // refined cell: the sub-cell's entry
+  const unsigned es = e - RG_E_EDGE0;                       // record slot if e codes a record
+  unsigned rid = e;                                         // region ids and 0xFFFF (= RG_NONE) pass through
+  if (es < (unsigned)RG_EDGES) rid = region_side(rv.edge[es], p0, p1);    // ~8 % of the lanes: the others issue no request
+  if (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) {             // refined cell: the sub-cell's code
     const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
     const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
-    e = rv.t1[(size_t)(e & RG_PAYLOAD) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx];
+    const unsigned e1 = rv.t1[(size_t)(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx];
+    const unsigned es1 = e1 - RG_E_EDGE0;
+    rid = e1;
+    if (es1 < (unsigned)RG_EDGES) rid = region_side(rv.edge[es1], p0, p1);
   }
-  unsigned rid = e & 0xFFFFu;
-  if ((e >> 30) == 1u) {                                    // one kink crosses the cell: which side
-    const float4 r = rv.edge[e & RG_PAYLOAD];
-    const float g = fmaf(r.x, p0, fmaf(r.y, p1, r.z));
-    const unsigned b = __float_as_uint(r.w);
-    rid = g > 0.f ? (b >> 16) : (b & 0xFFFFu);
-  }
-  return (e >> 30) == 3u ? RG_NONE : rid;
+  return rid;
 }
 
 // The MLP itself for ONE pair, evaluated by the whole wave (kind 3 pairs: ~3e-5 of all): lane c = l & 31 owns hidden unit c of both
@@ -426,7 +546,8 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   __shared__ __attribute__((aligned(16))) _Float16 Vp[2][KT * FTLD];         // V tile, hi / lo planes, read transposed (A operand of O^T)
   __shared__ __attribute__((aligned(16))) float4 regl[RG_LCAP];              // (a0, a1, c) of the regions
   __shared__ float w2t[CH * CH];                                             // W2 transposed (the MLP path)
-  __shared__ float vsl[KT][2];                                               // sample positions of the tile's keys
+  __shared__ float vsl[2][KT][2];                                            // sample positions of this tile's and the next tile's keys
+  __shared__ __attribute__((aligned(16))) unsigned short ridl[WAVES][KT][QT + 8];   // per wave: the tile's region ids [key][query] (80-byte rows)
 
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int wave = tid >> 6;
@@ -435,12 +556,19 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   const int HD = H * DH;
   const bool qvalid = (q0 + c) < N;
   const int qi = qvalid ? (q0 + c) : (N - 1);
+  const float* VSb = VS + (size_t)(b * H + h) * J * 2;                       // one head per offset group: group = head
 
   {
     const int nreg = min((int)rv.hdr->n_regions, RG_LCAP);
     for (int i = tid; i < nreg; i += 256) regl[i] = rv.reg[i];
     for (int i = tid; i < CH * CH; i += 256) w2t[(i & 31) * CH + (i >> 5)] = cp.w2[i];      // i = o * 32 + in
+    if (tid < KT) {
+      const int key = min(tid, J - 1);
+      vsl[0][tid][0] = VSb[(size_t)key * 2];
+      vsl[0][tid][1] = VSb[(size_t)key * 2 + 1];
+    }
   }
+  __syncthreads();
   const float cs = rv.hdr->cs, co = rv.hdr->co;
   const CoopMlp mlp{cp.w1[c * 2], cp.w1[c * 2 + 1], cp.b1[c], cp.b2[c], cp.w3[c], cp.b3[0], w2t, nullptr};
 
@@ -462,94 +590,171 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   float m_run = -INFINITY, l_run = 0.f;
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
-  const float* VSb = VS + (size_t)(b * H + h) * J * 2;                       // one head per offset group: group = head
   float* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;    // this wave's [J][32] block (layout: deform_attn_fwd_kernel)
   unsigned short* RIDb = RID ? RID + ((size_t)(b * H + h) * NST + q0) * J : nullptr;
 
+  // K / V rows of a tile travel global -> registers (one tile ahead) -> fp16 hi / lo images in LDS
+  float4 kreg[2], vreg[2];
+  float2 vsn = make_float2(0.f, 0.f);
+  auto fetch_kv = [&](int jn) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = jn + (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
+      kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i];
+      if (key < J) {
+        kreg[i] = *reinterpret_cast<const float4*>(Kb + (size_t)key * HD + d4);
+        vreg[i] = *reinterpret_cast<const float4*>(Vb + (size_t)key * HD + d4);
+      }
+    }
+    if (tid < KT) vsn = *reinterpret_cast<const float2*>(VSb + (size_t)min(jn + KT + tid, J - 1) * 2);
+  };
+  fetch_kv(0);
   const int ntiles = (J + KT - 1) / KT;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int j0 = kt * KT;
-    __syncthreads();
+    // position bias of this lane's 16 (key, query) pairs, register r <-> key acc_row(r, hf).  Step 1, before anything else of the
+    // tile: the signed-log offsets and the gathers of the 16 cell codes - they are in flight during the staging of K / V, the barrier
+    // and the S^T products (the sample positions of a tile are staged one tile ahead).
+    float p0[16], p1[16];
+    unsigned ent[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 vv = *reinterpret_cast<const float2*>(&vsl[kt & 1][acc_row(r, hf)][0]);
+#if SMML_RGN_EXP == 5
+      p0[r] = (gq0 - vv.x) * 0.5f; p1[r] = (gq1 - vv.y) * 0.5f;
+#else
+      p0[r] = slog1p(gq0 - vv.x);
+      p1[r] = slog1p(gq1 - vv.y);
+#endif
+      int cx, cy;
+#if SMML_RGN_EXP == 1
+      ent[r] = region_cell_index(fmaf(p0[r], cs, co), fmaf(p1[r], cs, co), cx, cy) & 1023u;
+#else
+      ent[r] = rv.t0[region_cell_index(fmaf(p0[r], cs, co), fmaf(p1[r], cs, co), cx, cy)];
+#endif
+    }
+    lds_barrier();                                     // every wave is done with the previous tile's K / V images
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (j0 + key < J) {
-        kv = *reinterpret_cast<const float4*>(Kb + (size_t)(j0 + key) * HD + d4);
-        vv = *reinterpret_cast<const float4*>(Vb + (size_t)(j0 + key) * HD + d4);
-      }
       uint2v hi, lo;
-      split4_h2(kv, hi, lo);
+      split4_h2(kreg[i], hi, lo);
       *reinterpret_cast<uint2v*>(&Kp[0][key * FRLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Kp[1][key * FRLD + d4]) = lo;
-      split4_h2(vv, hi, lo);
+      split4_h2(vreg[i], hi, lo);
       *reinterpret_cast<uint2v*>(&Vp[0][key * FTLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Vp[1][key * FTLD + d4]) = lo;
     }
-    if (tid < KT) {
-      const int key = min(j0 + tid, J - 1);
-      vsl[tid][0] = VSb[(size_t)key * 2];
-      vsl[tid][1] = VSb[(size_t)key * 2 + 1];
-    }
-    __syncthreads();
+    if (tid < KT) { vsl[(kt + 1) & 1][tid][0] = vsn.x; vsl[(kt + 1) & 1][tid][1] = vsn.y; }     // the NEXT tile's sample positions
+    lds_barrier();
+    fetch_kv(j0 + KT);                                 // the next tile's K / V rows and the sample positions after it, in flight during this tile
 
-    // position bias of this lane's 16 (key, query) pairs: register r <-> key acc_row(r, hf), in two groups of eight - first the
-    // cell entries of a group (independent gathers, all in flight; the S^T products run under the first group's), then their resolution
-    const int nk = min(KT, J - j0);
+    // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
-    float tmax = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int o = c * FRLD + 16 * st + 8 * hf;
+      const half8 kh = *reinterpret_cast<const half8*>(&Kp[0][o]), kl = *reinterpret_cast<const half8*>(&Kp[1][o]);
+      s = mfma16(kl, qh[st], s);
+      s = mfma16(kh, ql[st], s);
+      s = mfma16(kh, qh[st], s);
+    }
+
+    // Step 2: code -> region -> a . p + c, eight pairs at a time and in STAGES, each stage's gathers issued together (a dependent
+    // gather inside a per-pair branch would expose one L2 round trip per pair: measured 2 ms of this kernel's 3.2):
+    //   (a) refined cells (0.7 % of the pairs) take their sub-cell's code; (b) the records of the one-kink cells (8 %) - every lane
+    //   reads one (record 0 where it needs none: one address, no traffic); (c) the side of the kink, the region's (a, c) from LDS.
+    const int nk = min(KT, J - j0);
+    unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
-      float p0[8], p1[8];
-      unsigned ent[8];
+      unsigned e8[8], e1[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {         // (a) issue: the sub-cell codes of the refined cells (none is consumed inside this loop)
+        const int r = 8 * g8 + r8;
+        const unsigned e = ent[r];
+        e1[r8] = 0u;
+#if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
+        const bool sub = e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0;
+        if (__ballot(sub)) {                   // wave-uniform: a third of the (wave, pair) steps
+          const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
+          int cx, cy;
+          region_cell_index(u0, u1, cx, cy);
+          const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
+          const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
+          e1[r8] = rv.t1[sub ? (size_t)(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx : (size_t)0];
+        }
+#endif
+      }
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
-        const float2 vv = *reinterpret_cast<const float2*>(&vsl[acc_row(8 * g8 + r8, hf)][0]);
-        p0[r8] = slog1p(gq0 - vv.x);
-        p1[r8] = slog1p(gq1 - vv.y);
-        int cx, cy;
-        ent[r8] = rv.t0[region_cell_index(fmaf(p0[r8], cs, co), fmaf(p1[r8], cs, co), cx, cy)];
+        const unsigned e = ent[8 * g8 + r8];
+        e8[r8] = (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) ? e1[r8] : e;
       }
-      if (g8 == 0) {
-        // S^T[key, query] = K . (scale Q)^T
+      float4 rec8[8];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const int o = c * FRLD + 16 * st + 8 * hf;
-          const half8 kh = *reinterpret_cast<const half8*>(&Kp[0][o]), kl = *reinterpret_cast<const half8*>(&Kp[1][o]);
-          s = mfma16(kl, qh[st], s);
-          s = mfma16(kh, ql[st], s);
-          s = mfma16(kh, qh[st], s);
-        }
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const unsigned es = e8[r8] - RG_E_EDGE0;
+#if SMML_RGN_EXP == 8
+        rec8[r8] = make_float4(__uint_as_float(es), 1.f, 0.5f, __uint_as_float(0x00010002u));
+#else
+        rec8[r8] = rv.edge[es < (unsigned)RG_EDGES ? es : 0u];
+#endif
       }
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = 8 * g8 + r8;
-        const float u0 = fmaf(p0[r8], cs, co), u1 = fmaf(p1[r8], cs, co);
-        int cx, cy;
-        region_cell_index(u0, u1, cx, cy);
-        const unsigned id = region_resolve(rv, ent[r8], p0[r8], p1[r8], u0, u1, cx, cy);
+#if SMML_RGN_EXP == 2
+        const unsigned id = ent[r] & 1023u;
+#else
+        const unsigned es = e8[r8] - RG_E_EDGE0;
+        const unsigned id = es < (unsigned)RG_EDGES ? region_side(rec8[r8], p0[r], p1[r]) : e8[r8];    // region ids and 0xFFFF pass through
+#endif
         float bias = 0.f;
         if (id < (unsigned)RG_LCAP) {
+#if SMML_RGN_EXP == 6
+          const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
+#else
           const float4 ac = regl[id];
-          bias = fmaf(ac.x, p0[r8], fmaf(ac.y, p1[r8], ac.z));
+#endif
+          bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
         } else if (id != RG_NONE) {
           const float4 ac = rv.reg[id];
-          bias = fmaf(ac.x, p0[r8], fmaf(ac.y, p1[r8], ac.z));
-        }
-        // pairs without a region: the MLP itself, one pair at a time, by the whole wave
-        unsigned long long todo = __ballot(id == RG_NONE);
-        while (todo) {
-          const int l = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          float h1; bool on2;
-          const float v = coop_mlp_fwd(mlp, __shfl(p0[r8], l), __shfl(p1[r8], l), c, h1, on2);
-          if (lane == l) bias = v;
+          bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
         }
         const bool kin = acc_row(r, hf) < nk;
-        if (SAVE && kin) RIDb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = (unsigned short)id;
-        const float sv = kin ? s[r] + bias : -INFINITY;
-        s[r] = sv;
-        tmax = fmaxf(tmax, sv);
+        nonemask |= (id == RG_NONE && kin) ? (1u << r) : 0u;
+        if (SAVE) ridl[wave][acc_row(r, hf)][c] = (unsigned short)id;
+        s[r] = kin ? s[r] + bias : -INFINITY;
       }
     }
+    if (SAVE) {
+      // the tile's region ids leave as whole rows: [key][32 queries] is 64 bytes per key - a lane takes the 16 ids of its (key, half of
+      // the queries) from the wave's LDS image and stores them with two 16-byte stores (instead of 16 two-byte stores per lane)
+      wave_lds_fence();
+      const int key = lane >> 1, qh16 = (lane & 1) * 16;
+      const uint4 w0 = *reinterpret_cast<const uint4*>(&ridl[wave][key][qh16]), w1 = *reinterpret_cast<const uint4*>(&ridl[wave][key][qh16 + 8]);
+      if (key < nk && SMML_RGN_EXP != 4) {
+        uint4* dst = reinterpret_cast<uint4*>(RIDb + (size_t)(j0 + key) * 32 + qh16);
+        dst[0] = w0;
+        dst[1] = w1;
+      }
+      wave_lds_fence();
+    }
+    // pairs without a region (~1e-4 of all): the MLP itself, one pair at a time, by the whole wave - outside the unrolled loops
+    for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
+      const int l = __ffsll((long long)todo) - 1;
+      const float g0 = __shfl(gq0, l), g1 = __shfl(gq1, l);
+      for (unsigned m = (unsigned)__shfl((int)nonemask, l); m; m &= m - 1) {
+        const int r = __ffs((int)m) - 1;
+        const float2 vv = *reinterpret_cast<const float2*>(&vsl[kt & 1][acc_row(r, l >> 5)][0]);
+        float h1; bool on2;
+        const float v = coop_mlp_fwd(mlp, slog1p(g0 - vv.x), slog1p(g1 - vv.y), c, h1, on2);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) s[rr] += (rr == r && lane == l) ? v : 0.f;
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     unsigned keepbits = 0xFFFFu;              // dropout decisions of this lane's 16 keys (bit r)
     if (dc.thresh) {
       const unsigned long long base2 = ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1) + (j0 >> 1);
@@ -569,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = acc_row(r, hf);
-        if (key < nk) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
+        if (key < nk && SMML_RGN_EXP != 3) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
       }
     }
     tmax = xhalf_max(tmax);
@@ -621,7 +826,6 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   }
 }
 
-
 // ------------------------------------------------------------------------------------------------
 // backward of the position bias per linear region: d vs per pair, region moments of d bias in 64-bit fixed point
 // ------------------------------------------------------------------------------------------------
@@ -647,10 +851,13 @@ struct RegionBwdLds {                    // dynamic LDS of cpb_region_bwd_kernel
   float2 dvs[16][64];                    // per-wave d vs of its key block (combined in a fixed order at the end)
 };
 
-// grid (chunks, H, B); block = 64 * nkb * wpk threads: wave w owns key block w % nkb (64 keys, lane = key) and every wpk-th query
-// tile (32 queries) of the chunk.  For each of its tiles a lane reads its key's 32 d scores and 32 region ids (one 128-byte and one
-// 64-byte row) and walks the queries: no cross-lane sums for d vs, three integer LDS atomics per pair for the moments.
-__global__ __launch_bounds__(1024) void cpb_region_bwd_kernel(
+// grid (chunks, H, B); block = 64 * nkb * wpk threads (<= 768): wave w owns the keys lane * nkb + (w % nkb) (lane = key; keys of one
+// wave are nkb apart, so that its lanes fall into different regions: no same-address serialisation of the LDS adds) and every wpk-th
+// query tile (32 queries) of the chunk.  For each of its tiles a lane reads its key's 32 d scores and 32 region ids (one 128-byte and
+// one 64-byte row, the next tile's rows in flight meanwhile) and walks the queries: no cross-lane sums for d vs; the three moments of a
+// RUN of queries in the same region (~4 on the query grid) are summed in registers and go to the region's LDS accumulators with three
+// 64-bit integer adds when the region changes.
+__global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const float* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, RegionView rv, const unsigned* __restrict__ AMAX, unsigned long long* __restrict__ HIST, unsigned long long* __restrict__ GRAD,
     float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift) {
@@ -668,33 +875,56 @@ __global__ __launch_bounds__(1024) void cpb_region_bwd_kernel(
   }
   __syncthreads();
   const RegionScale sc = region_scale(*AMAX, kbits);
+  const double Sg = __longlong_as_double(__double_as_longlong(sc.S) - ((long long)shift << 52));     // scale of the global accumulators
   const CoopMlp mlp{cp.w1[c * 2], cp.w1[c * 2 + 1], cp.b1[c], cp.b2[c], cp.w3[c], cp.b3[0], L.w2t, L.w2r};
   float big;
   asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
 
   const int kb = wave % nkb, tslot = wave / nkb;                   // waves beyond nkb * wpk do not exist (block size)
-  const int key = kb * 64 + lane;
+  const int key = lane * nkb + kb;
   const bool kvalid = key < J;
   const int keyc = min(key, J - 1);
   const float vs0 = VS[((size_t)(b * H + h) * J + keyc) * 2], vs1 = VS[((size_t)(b * H + h) * J + keyc) * 2 + 1];
   const int ntq = (N + QT - 1) / QT;
   const int t_begin = chunk * tiles_per_chunk, t_end = min(t_begin + tiles_per_chunk, ntq);
   float dv0 = 0.f, dv1 = 0.f;
+  unsigned cur = RG_NONE;                                           // region of the current run of this lane, its three moment sums
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  auto flush = [&](unsigned id, float m0, float m1, float m2) {
+    if (id < (unsigned)RG_LCAP) {
+      atomicAdd(&L.hist[id * 3], (unsigned long long)region_fix(m0, sc.S));
+      atomicAdd(&L.hist[id * 3 + 1], (unsigned long long)region_fix(m1, sc.S));
+      atomicAdd(&L.hist[id * 3 + 2], (unsigned long long)region_fix(m2, sc.S));
+    } else if (id != RG_NONE) {                                     // a region beyond the LDS-resident ones: global memory
+      atomicAdd(&HIST[id * 3], (unsigned long long)region_fix(m0, Sg));
+      atomicAdd(&HIST[id * 3 + 1], (unsigned long long)region_fix(m1, Sg));
+      atomicAdd(&HIST[id * 3 + 2], (unsigned long long)region_fix(m2, Sg));
+    }
+  };
 
+  float4 dbn[8];
+  uint4 ridn[4];
+  auto fetch = [&](int tile) {
+    const size_t row = ((size_t)(b * H + h) * NST + (size_t)tile * QT) * J + (size_t)keyc * 32;   // [B, H, nst / 32, J, 32]: this key's 32 queries of the tile
+    const float4* dp = reinterpret_cast<const float4*>(dLT + row);
+    const uint4* rp = reinterpret_cast<const uint4*>(RID + row);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dbn[i] = dp[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ridn[i] = rp[i];
+  };
+  if (t_begin + tslot < t_end) fetch(t_begin + tslot);
   for (int tile = t_begin + tslot; tile < t_end; tile += wpk) {
     const int q0 = tile * QT;
     const int nq = min(QT, N - q0);
-    const size_t row = ((size_t)(b * H + h) * NST + q0) * J + (size_t)keyc * 32;     // [B, H, nst / 32, J, 32]: this key's 32 queries of the tile
     float dbr[32];
     unsigned ridw[16];
-    {
-      const float4* dp = reinterpret_cast<const float4*>(dLT + row);
-      const uint4* rp = reinterpret_cast<const uint4*>(RID + row);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float4 t = dp[i]; dbr[4 * i] = t.x; dbr[4 * i + 1] = t.y; dbr[4 * i + 2] = t.z; dbr[4 * i + 3] = t.w; }
+    for (int i = 0; i < 8; ++i) { dbr[4 * i] = dbn[i].x; dbr[4 * i + 1] = dbn[i].y; dbr[4 * i + 2] = dbn[i].z; dbr[4 * i + 3] = dbn[i].w; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const uint4 t = rp[i]; ridw[4 * i] = t.x; ridw[4 * i + 1] = t.y; ridw[4 * i + 2] = t.z; ridw[4 * i + 3] = t.w; }
-    }
+    for (int i = 0; i < 4; ++i) { ridw[4 * i] = ridn[i].x; ridw[4 * i + 1] = ridn[i].y; ridw[4 * i + 2] = ridn[i].z; ridw[4 * i + 3] = ridn[i].w; }
+    if (tile + wpk < t_end) fetch(tile + wpk);                      // the next tile's rows, in flight during this tile's 32 queries
+    unsigned nonemask = 0u;                                         // bit q: this key's pair with query q0 + q has no region
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
       if (q < nq) {                                                 // uniform
@@ -702,61 +932,68 @@ __global__ __launch_bounds__(1024) void cpb_region_bwd_kernel(
         const float d0 = gx - vs0, d1 = gy - vs1;
         const float p0 = slog1p(d0), p1 = slog1p(d1);
         const float s0 = dpos_of<false>(d0, big), s1 = dpos_of<false>(d1, big);
-        const unsigned id = kvalid ? ((ridw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) : 0u;
+        const unsigned id = kvalid ? ((ridw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) : RG_NONE;
         const float dbv = kvalid ? dbr[q] : 0.f;
+        if (id != cur) {                                            // the run ends: its sums go to the region's accumulators
+          flush(cur, r0, r1, r2);
+          cur = id; r0 = 0.f; r1 = 0.f; r2 = 0.f;
+        }
+        r0 += dbv; r1 = fmaf(dbv, p0, r1); r2 = fmaf(dbv, p1, r2);
         float a0 = 0.f, a1 = 0.f;
         if (id < (unsigned)RG_LCAP) {
           const float2 a = L.reg2[id];
           a0 = a.x; a1 = a.y;
-          atomicAdd(&L.hist[id * 3], (unsigned long long)region_fix(dbv, sc.S));
-          atomicAdd(&L.hist[id * 3 + 1], (unsigned long long)region_fix(dbv * p0, sc.S));
-          atomicAdd(&L.hist[id * 3 + 2], (unsigned long long)region_fix(dbv * p1, sc.S));
-        } else if (id != RG_NONE) {                                 // a region beyond the LDS-resident ones: global memory
+        } else if (id != RG_NONE) {
           const float4 a = rv.reg[id];
           a0 = a.x; a1 = a.y;
-          const double Sg = __longlong_as_double(__double_as_longlong(sc.S) - ((long long)shift << 52));
-          atomicAdd(&HIST[id * 3], (unsigned long long)region_fix(dbv, Sg));
-          atomicAdd(&HIST[id * 3 + 1], (unsigned long long)region_fix(dbv * p0, Sg));
-          atomicAdd(&HIST[id * 3 + 2], (unsigned long long)region_fix(dbv * p1, Sg));
         }
-        // pairs without a region: the MLP's own backward for that pair, by the whole wave
-        unsigned long long todo = __ballot(kvalid && id == RG_NONE);
-        while (todo) {
-          const int l = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const float pp0 = __shfl(p0, l), pp1 = __shfl(p1, l), dbl = __shfl(dbv, l);
-          float h1; bool on2;
-          (void)coop_mlp_fwd(mlp, pp0, pp1, c, h1, on2);
-          // x2 of unit c again (the forward helper returns only its sign): cheap next to the rest
-          float x2 = mlp.b2;
-#pragma unroll 8
-          for (int i = 0; i < CH; ++i) x2 = fmaf(mlp.w2t[i * CH + c], __shfl(h1, i), x2);
-          const float g2 = on2 ? mlp.w3 : 0.f;
-          float c1 = 0.f;
-#pragma unroll 8
-          for (int o = 0; o < CH; ++o) c1 = fmaf(mlp.w2r[o * CH + c], __shfl(g2, o), c1);
-          c1 = h1 > 0.f ? c1 : 0.f;
-          const float dp0 = coop_sum32(c1 * mlp.w1x), dp1 = coop_sum32(c1 * mlp.w1y);
-          if (lane == l) { a0 = dp0; a1 = dp1; }
-          for (int ii = 0; ii < 16; ++ii) {                         // dW2[out = c][in = 16 hf + ii]
-            const int i = 16 * hf + ii;
-            const float hi = __shfl(h1, i);
-            atomicAdd(&L.grad[c * CH + i], (unsigned long long)region_fix(dbl * g2 * hi, sc.S));
-          }
-          if (hf == 0) {
-            atomicAdd(&L.grad[1024 + 2 * c], (unsigned long long)region_fix(dbl * c1 * pp0, sc.S));
-            atomicAdd(&L.grad[1024 + 2 * c + 1], (unsigned long long)region_fix(dbl * c1 * pp1, sc.S));
-            atomicAdd(&L.grad[1024 + 64 + c], (unsigned long long)region_fix(dbl * c1, sc.S));
-            atomicAdd(&L.grad[1024 + 96 + c], (unsigned long long)region_fix(dbl * g2, sc.S));
-            atomicAdd(&L.grad[1024 + 128 + c], (unsigned long long)region_fix(on2 ? dbl * x2 : 0.f, sc.S));
-            if (c == 0) atomicAdd(&L.grad[1024 + 160], (unsigned long long)region_fix(dbl, sc.S));
-          }
-        }
+        nonemask |= (kvalid && id == RG_NONE) ? (1u << q) : 0u;
         dv0 = fmaf(-dbv * a0, s0, dv0);
         dv1 = fmaf(-dbv * a1, s1, dv1);
       }
     }
+    // pairs without a region (~1e-4 of all): the MLP's own backward for that pair, by the whole wave - outside the unrolled loop
+    for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
+      const int l = __ffsll((long long)todo) - 1;
+      const float v0 = __shfl(vs0, l), v1 = __shfl(vs1, l);
+      const int kl = __shfl(keyc, l);
+      const float* drow = dLT + ((size_t)(b * H + h) * NST + (size_t)q0) * J + (size_t)kl * 32;
+      for (unsigned m = (unsigned)__shfl((int)nonemask, l); m; m &= m - 1) {
+        const int q = __ffs((int)m) - 1;
+        const float d0 = GQ[(size_t)(q0 + q) * 2] - v0, d1 = GQ[(size_t)(q0 + q) * 2 + 1] - v1;
+        const float pp0 = slog1p(d0), pp1 = slog1p(d1), dbl = drow[q];
+        float h1; bool on2;
+        (void)coop_mlp_fwd(mlp, pp0, pp1, c, h1, on2);
+        float x2 = mlp.b2;                                          // x2 of unit c again (the forward helper returns only its sign)
+#pragma unroll 8
+        for (int i = 0; i < CH; ++i) x2 = fmaf(mlp.w2t[i * CH + c], __shfl(h1, i), x2);
+        const float g2 = on2 ? mlp.w3 : 0.f;
+        float c1 = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < CH; ++o) c1 = fmaf(mlp.w2r[o * CH + c], __shfl(g2, o), c1);
+        c1 = h1 > 0.f ? c1 : 0.f;
+        const float dp0 = coop_sum32(c1 * mlp.w1x), dp1 = coop_sum32(c1 * mlp.w1y);
+        if (lane == l) {
+          dv0 = fmaf(-dbl * dp0, dpos_of<false>(d0, big), dv0);
+          dv1 = fmaf(-dbl * dp1, dpos_of<false>(d1, big), dv1);
+        }
+        for (int ii = 0; ii < 16; ++ii) {                           // dW2[out = c][in = 16 hf + ii]
+          const int i = 16 * hf + ii;
+          const float hi = __shfl(h1, i);
+          atomicAdd(&L.grad[c * CH + i], (unsigned long long)region_fix(dbl * g2 * hi, sc.S));
+        }
+        if (hf == 0) {
+          atomicAdd(&L.grad[1024 + 2 * c], (unsigned long long)region_fix(dbl * c1 * pp0, sc.S));
+          atomicAdd(&L.grad[1024 + 2 * c + 1], (unsigned long long)region_fix(dbl * c1 * pp1, sc.S));
+          atomicAdd(&L.grad[1024 + 64 + c], (unsigned long long)region_fix(dbl * c1, sc.S));
+          atomicAdd(&L.grad[1024 + 96 + c], (unsigned long long)region_fix(dbl * g2, sc.S));
+          atomicAdd(&L.grad[1024 + 128 + c], (unsigned long long)region_fix(on2 ? dbl * x2 : 0.f, sc.S));
+          if (c == 0) atomicAdd(&L.grad[1024 + 160], (unsigned long long)region_fix(dbl, sc.S));
+        }
+      }
+    }
   }
+  flush(cur, r0, r1, r2);
   L.dvs[wave][lane] = make_float2(dv0, dv1);
   __syncthreads();
   // d vs of this chunk: the wpk waves of a key block in a fixed order -> slab [chunk][b, h][J]

@@ -1327,7 +1327,7 @@ static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
   p.tiles_per_chunk = (ntq + p.chunks - 1) / p.chunks;
   p.chunks = (ntq + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
   p.nkb = (J + 63) / 64;
-  p.wpk = p.nkb <= 16 ? 16 / p.nkb : 0;
+  p.wpk = p.nkb <= 12 ? 12 / p.nkb : 0;        // at most 12 waves per workgroup (three per SIMD at <= 168 registers)
   if (p.wpk > p.tiles_per_chunk) p.wpk = p.tiles_per_chunk;
   // fixed point: |d bias (1, p0, p1)| <= 4 amax (|p| <= log(1 + |d|) < 4 for any reachable offset); a workgroup adds at most
   // tiles_per_chunk 32 J values into an LDS accumulator, the launch at most B H N J into a global one - both stay below 2^62
@@ -1364,7 +1364,7 @@ int smml_cpb_regions_build(const float* w1, const float* b1, const float* w2, co
 static int check_region(const char* fn, int B, int N, int J, int H) {
   int rc = check_common(fn, B, N, J, H, H, 2);
   if (rc) return rc;
-  SMML_REQUIRE(J <= 1024, "%s: the region kernels take at most 1024 keys (got %d)", fn, J);
+  SMML_REQUIRE(J <= 768, "%s: the region kernels take at most 768 keys (got %d)", fn, J);
   return SMML_OK;
 }
 

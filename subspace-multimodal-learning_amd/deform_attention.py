@@ -147,6 +147,30 @@ class DeformCrossAttention2D(nn.Module):
             raise ValueError(f"token count {n} is not a square; pass grid_hw=(rows, cols)")
         return s, s
 
+    def _region_pmax(self, Hh: int, Ww: int) -> float:
+        """Half-width of the square of signed-log offsets the position bias can be asked for: |gq| and |vs| are bounded by the grids'
+        shapes and tanh . offset_scale (normalize_grid divides x by rows - 1, y by cols - 1)."""
+        L = Fh.capi.lib()
+        th = L.smml_offsets_out_len(Hh, self.offset_kernel_size, self.downsample_factor)
+        tw = L.smml_offsets_out_len(Ww, self.offset_kernel_size, self.downsample_factor)
+        lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
+        gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
+        vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
+        return Fh.table_pmax(gqb, vsb)
+
+    def _regions_apply(self) -> bool:
+        return (Fh.CPB_REGIONS and self.compute_dtype is None and not self.consistent_grid_norm and self.heads == self.offset_groups
+                and self.rel_pos_bias.mlp[0][0].weight.is_cuda)
+
+    def prefetch_regions(self, n_tokens: int) -> None:
+        """Starts the build of the position bias's region tables on a side stream (functional.RegionPrefetch); the next forward_tokens on
+        a bag of n_tokens joins it.  Optional: without it the tables are built in front of the attention launch."""
+        self._prefetch = None
+        if not (self._regions_apply() and Fh.REGION_PREFETCH):
+            return
+        Hh, Ww = self._grid(n_tokens)
+        self._prefetch = Fh.RegionPrefetch(*self.rel_pos_bias.tensors(), self._region_pmax(Hh, Ww))
+
     def forward_tokens(self, x1t, x2t, return_vgrid=False, residual=None):
         """Token-major entry: x1t (queries) / x2t (keys, values) [B, N, C] -> [B, N, C] (+ residual)."""
         B, N, C = x1t.shape
@@ -175,7 +199,9 @@ class DeformCrossAttention2D(nn.Module):
         gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
         vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
         if self.compute_dtype is None and not self.consistent_grid_norm:
-            tab = {"cpb_region_pmax": Fh.table_pmax(gqb, vsb)}      # the square the region tables of the position bias cover (no host sync)
+            # the square the region tables of the position bias cover (no host sync), and the build started by prefetch_regions, if any
+            tab = {"cpb_region_pmax": self._region_pmax(Hh, Ww), "cpb_region_prefetch": getattr(self, "_prefetch", None)}
+            self._prefetch = None
         if self.cpb_table:
             tab = {"cpb_table": self.cpb_table, "cpb_table_pmax": None if self.consistent_grid_norm else Fh.table_pmax(gqb, vsb),   # None: from the data
                    "cpb_table_grid": (Hh, Ww)}                 # gq is a regular grid in both normalisations

@@ -94,7 +94,13 @@ class DeformCrossTransMIL(nn.Module):
         self.pooler = Pooler(args.path_dim)
         self.multimodal_projection = nn.Linear(args.path_dim, self.args.path_dim)
 
+    def prefetch(self, n_tokens: int) -> None:
+        """Work that depends on the parameters only and can run beside the first layers: the position bias's region tables."""
+        if self.args.attn_dim == 2 and not bool(getattr(self.args, "wrap_pad_to_square", False)):
+            self.layer3.attn2d.prefetch_regions(n_tokens)
+
     def forward(self, path, omic):
+        self.prefetch(path.shape[1])
         return self.forward_features(Fh.linear(path.float(), self._fc1[0].weight, self._fc1[0].bias, act=Fh.ACT_RELU), omic)   # [B, N, C]
 
     def forward_features(self, path, omic):

@@ -873,15 +873,16 @@ TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
 # default wherever it applies (signed-log offsets, one head per offset group, J <= 1024).  SMML_CPB_REGIONS=0 keeps the per-pair MLP
 # kernels (the cross-check of tests/test_gpu_regions.py, and the path of every other configuration).
 CPB_REGIONS = __import__("os").environ.get("SMML_CPB_REGIONS", "1") != "0"
-REGION_MAX_KEYS = 1024
+REGION_MAX_KEYS = 768
 
 
-REGION_GRID, REGION_SUB, REGION_SUBCAP, REGION_EDGECAP, REGION_RCAP = 1024, 8, 16384, 1 << 18, 4096     # csrc/cpb_regions.h
+REGION_GRID, REGION_SUB, REGION_SUBCAP, REGION_EDGES, REGION_RCAP = 1024, 8, 16384, 1 << 15, 4096     # csrc/cpb_regions.h
+REGION_CODE_SUB0, REGION_CODE_EDGE0 = 4096, 4096 + 16384
 
 
 def region_tables_view(tables: torch.Tensor):
     """Views into a region-table buffer (tests / diagnostics; layout: region_layout() of csrc/cpb_regions.h): header counters,
-    (a0, a1, c) per region, ReLU patterns (D1 | D2 << 32), first-level cells, sub-cells, single-kink records."""
+    (a0, a1, c) per region, ReLU patterns (D1 | D2 << 32), 16-bit codes of the cells and sub-cells, single-kink records by slot."""
     o = [0]
 
     def take(nbytes):
@@ -890,16 +891,17 @@ def region_tables_view(tables: torch.Tensor):
         return at
     G, SUB = REGION_GRID, REGION_SUB
     hdr_o, reg_o, pat_o = take(256), take(REGION_RCAP * 16), take(REGION_RCAP * 8)
-    t0_o, t1_o, edge_o = take(G * G * 4), take(REGION_SUBCAP * SUB * SUB * 4), take(REGION_EDGECAP * 16)
+    t0_o, t1_o, edge_o = take(G * G * 2), take(REGION_SUBCAP * SUB * SUB * 2), take(REGION_EDGES * 16)
     hdr = tables[hdr_o:hdr_o + 256].view(torch.int32)
     n_sub, n_edge, n_regions = int(hdr[0]), int(hdr[1]), int(hdr[3])
     return {"n_sub": n_sub, "n_edge": n_edge, "n_cand": int(hdr[2]), "n_regions": n_regions, "n_keys": int(hdr[4]), "overflow": int(hdr[5]),
-            "pmax": float(hdr[6:7].view(torch.float32)), "cs": float(hdr[7:8].view(torch.float32)), "co": float(hdr[8:9].view(torch.float32)),
+            "n_cand1": int(hdr[6]), "pmax": float(hdr[8:9].view(torch.float32)), "cs": float(hdr[9:10].view(torch.float32)),
+            "co": float(hdr[10:11].view(torch.float32)),
             "reg": tables[reg_o:reg_o + REGION_RCAP * 16].view(torch.float32).view(REGION_RCAP, 4)[:n_regions],
             "pat": tables[pat_o:pat_o + REGION_RCAP * 8].view(torch.int64)[:n_regions],
-            "t0": tables[t0_o:t0_o + G * G * 4].view(torch.int32).view(G, G),
-            "t1": tables[t1_o:t1_o + REGION_SUBCAP * SUB * SUB * 4].view(torch.int32).view(REGION_SUBCAP, SUB * SUB)[:min(n_sub, REGION_SUBCAP)],
-            "edge": tables[edge_o:edge_o + REGION_EDGECAP * 16].view(torch.float32).view(REGION_EDGECAP, 4)[:min(n_edge, REGION_EDGECAP)]}
+            "t0": tables[t0_o:t0_o + G * G * 2].view(torch.int16).view(G, G),
+            "t1": tables[t1_o:t1_o + REGION_SUBCAP * SUB * SUB * 2].view(torch.int16).view(REGION_SUBCAP, SUB * SUB)[:max(min(n_sub, REGION_SUBCAP), 1)],
+            "edge": tables[edge_o:edge_o + REGION_EDGES * 16].view(torch.float32).view(REGION_EDGES, 4)}
 
 
 def region_patterns(region_ids: torch.Tensor, tables: torch.Tensor):
@@ -913,20 +915,58 @@ def region_patterns(region_ids: torch.Tensor, tables: torch.Tensor):
     return torch.where(none, torch.full_like(d1, -1), d1), torch.where(none, torch.full_like(d2, -1), d2)
 
 
-def cpb_regions_build(w1, b1, w2, b2, w3, b3, pmax: float) -> torch.Tensor:
-    """The region tables of the position-bias MLP with these parameters over [-pmax, pmax]^2 (uint8 scratch owned by the caller)."""
+def cpb_regions_build(w1, b1, w2, b2, w3, b3, pmax: float, tables: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The region tables of the position-bias MLP with these parameters over [-pmax, pmax]^2 (uint8 scratch owned by the caller), built
+    on the current stream."""
     L = capi.lib()
     nbytes = L.smml_cpb_regions_bytes()
-    tables = torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
+    if tables is None:
+        tables = torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
     capi.check(L.smml_cpb_regions_build(capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.fptr(_c(w2)), capi.fptr(_c(b2)), capi.fptr(_c(w3)),
                                         capi.fptr(_c(b3)), float(pmax), capi.ptr(tables), nbytes, capi.stream()), "cpb_regions_build")
     return tables
 
 
+_REGION_STREAMS = {}
+REGION_PREFETCH = __import__("os").environ.get("SMML_REGION_PREFETCH", "1") != "0"
+
+
+class RegionPrefetch:
+    """Region tables being built on a side stream (they depend on the bias MLP's parameters only, not on the bag): started at the top of
+    the module's forward, joined by the attention launch - the ~0.3 ms of the build run beside the projections, the offsets network and
+    the sampler instead of in front of the attention kernel."""
+
+    def __init__(self, w1, b1, w2, b2, w3, b3, pmax: float):
+        dev = w1.device
+        main = torch.cuda.current_stream(dev)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = _REGION_STREAMS.get(key)
+        if side is None:
+            side = _REGION_STREAMS[key] = torch.cuda.Stream(device=dev)
+        self.pmax = float(pmax)
+        self.params = tuple(t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)) + tuple(t._version for t in (w1, b1, w2, b2, w3, b3))
+        # allocated from the MAIN stream's pool (that is where it is used last and freed); the side stream starts behind everything the
+        # main stream has queued so far, i.e. behind the previous owner of the block
+        self.tables = torch.empty(capi.lib().smml_cpb_regions_bytes(), device=dev, dtype=torch.uint8)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cpb_regions_build(w1.detach(), b1.detach(), w2.detach(), b2.detach(), w3.detach(), b3.detach(), pmax, self.tables)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+
+    def matches(self, w1, b1, w2, b2, w3, b3, pmax: float) -> bool:
+        return (self.pmax == float(pmax) and
+                self.params == tuple(t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)) + tuple(t._version for t in (w1, b1, w2, b2, w3, b3)))
+
+    def join(self) -> torch.Tensor:
+        torch.cuda.current_stream(self.tables.device).wait_event(self.event)
+        return self.tables
+
+
 class _DeformAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed, seed_offset=None,
-                compute_dtype=None, fork=None, table_pmax_fwd=None, log_distance=True, region_pmax=None):
+                compute_dtype=None, fork=None, table_pmax_fwd=None, log_distance=True, region_pmax=None, region_prefetch=None):
         ctx.fork = fork
         ctx.log_distance = bool(log_distance)
         if not log_distance and (vs.shape[-1] != 1 or table_pmax_fwd is not None):
@@ -953,7 +993,10 @@ class _DeformAttn(torch.autograd.Function):
                    and J <= REGION_MAX_KEYS and tuple(w3.shape) == (1, 32))
         ctx.regions = regions
         if regions:
-            tables = cpb_regions_build(w1, b1, w2, b2, w3, b3, region_pmax)
+            if region_prefetch is not None and region_prefetch.matches(w1, b1, w2, b2, w3, b3, region_pmax):
+                tables = region_prefetch.join()                 # built beside the layers in front of the attention (RegionPrefetch)
+            else:
+                tables = cpb_regions_build(w1, b1, w2, b2, w3, b3, region_pmax)
             rid = None
             if need_grad:
                 nst = L.smml_deform_attn_nst(N)
@@ -1075,7 +1118,7 @@ class _DeformAttn(torch.autograd.Function):
         L.smml_deform_attn_set_log_distance(1)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_regions(ctx, dout):
@@ -1102,7 +1145,7 @@ class _DeformAttn(torch.autograd.Function):
         _set_seed_offset(L, None)
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)
-        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None
+        return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1242,7 +1285,7 @@ def graph_seed_offset(device, allocate_only: bool = False):
 def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, groups: int, scale: float,
                      dropout_p: float = 0.0, dropout_seed: int = 0, dropout_seed_offset=None, compute_dtype=None, fork=None,
                      cpb_table: bool = False, cpb_table_pmax=None, cpb_table_grid=None, log_distance: bool = True,
-                     cpb_regions=None, cpb_region_pmax=None):
+                     cpb_regions=None, cpb_region_pmax=None, cpb_region_prefetch=None):
     """dropout(softmax(scale q k^T + CPB(gq - vs))) v.  q [B, N, H*64], k/v [B, J, H*64], vs [(B G), J, P], gq [N, P].
     dropout_p > 0 applies nn.Dropout semantics to the probabilities with a counter-based mask from dropout_seed
     (+ the value of the device tensor dropout_seed_offset at run time, see graph_seed_offset).
@@ -1277,7 +1320,7 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
             and tuple(w3.shape) == (1, 32)):
         region_pmax = cpb_region_pmax if cpb_region_pmax is not None else table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
-                             dropout_seed_offset, compute_dtype, fork, None, log_distance, region_pmax)
+                             dropout_seed_offset, compute_dtype, fork, None, log_distance, region_pmax, cpb_region_prefetch)
 
 
 def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: float, dropout_seed: int, device, seed_offset=None):

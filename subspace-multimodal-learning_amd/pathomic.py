@@ -93,6 +93,8 @@ class DeformPathomicNet(nn.Module):
         ft, fi = self.pathomic_net_tumor._fc1[0], self.pathomic_net_immune._fc1[0]
         shared = ft.weight.shape == fi.weight.shape and x_path.is_cuda and not x_path.requires_grad
         if shared:
+            self.pathomic_net_tumor.prefetch(x_path.shape[1])       # parameter-only work of both branches, beside the shared first layer
+            self.pathomic_net_immune.prefetch(x_path.shape[1])
             pf_t, pf_i = Fh.dual_linear_relu(x_path.float(), ft.weight, ft.bias, fi.weight, fi.bias)
         omic_vec_tumor, _, _ = self.omic_net_tumor(x_omic=kwargs['x_omic_tumor'])
         rt = self.pathomic_net_tumor.forward_features(pf_t, omic_vec_tumor) if shared else self.pathomic_net_tumor(path=x_path, omic=omic_vec_tumor)

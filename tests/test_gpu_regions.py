@@ -37,31 +37,29 @@ def _mlp_weights(kind, gen):
 
 
 def _lookup(view, p):
-    """The region kernels' lookup restated in torch: p [n, 2] fp32 on the device -> region id per point (0xFFFF: evaluate the MLP)."""
-    G, SUB = Fh.REGION_GRID, Fh.REGION_SUB
+    """The region kernels' lookup restated in torch: p [n, 2] fp32 on the device -> region id per point (0xFFFF: evaluate the MLP) and the
+    kind of the point's first-level cell (0 region, 1 kink record, 2 refined, 3 MLP)."""
+    G, SUB, S0, E0, NE = Fh.REGION_GRID, Fh.REGION_SUB, Fh.REGION_CODE_SUB0, Fh.REGION_CODE_EDGE0, Fh.REGION_EDGES
     cs, co = view["cs"], view["co"]
     u = torch.addcmul(torch.full_like(p, co), p, torch.full_like(p, cs))
     cell = u.to(torch.int32).clamp(0, G - 1).long()
-    e = view["t0"][cell[:, 1], cell[:, 0]].long() & 0xFFFFFFFF
-    kind, pay = e >> 30, e & 0x3FFFFFFF
-    is_sub = kind == 2
+    e = view["t0"][cell[:, 1], cell[:, 0]].long() & 0xFFFF
+    kind0 = torch.where(e < S0, 0, torch.where(e < E0, 2, torch.where(e < E0 + NE, 1, 3)))
+    is_sub = (e >= S0) & (e < E0)
     if bool(is_sub.any()):
         sx = ((u - cell.float()) * SUB).to(torch.int32).clamp(0, SUB - 1).long()
-        e1 = view["t1"][pay[is_sub], sx[is_sub, 1] * SUB + sx[is_sub, 0]].long() & 0xFFFFFFFF
+        e1 = view["t1"][e[is_sub] - S0, sx[is_sub, 1] * SUB + sx[is_sub, 0]].long() & 0xFFFF
         e = e.clone()
         e[is_sub] = e1
-        kind, pay = e >> 30, e & 0x3FFFFFFF
-    rid = e & 0xFFFF
-    is_edge = kind == 1
+    rid = e.clone()
+    is_edge = (e >= E0) & (e < E0 + NE)
     if bool(is_edge.any()):
-        rec = view["edge"][pay[is_edge]]
+        rec = view["edge"][e[is_edge] - E0]
         pe = p[is_edge]
         g = torch.addcmul(torch.addcmul(rec[:, 2], rec[:, 1], pe[:, 1]), rec[:, 0], pe[:, 0])
         bits = rec[:, 3].contiguous().view(torch.int32).long() & 0xFFFFFFFF
-        rid = rid.clone()
         rid[is_edge] = torch.where(g > 0, bits >> 16, bits & 0xFFFF)
-    rid = torch.where(kind == 3, torch.full_like(rid, 0xFFFF), rid)
-    return rid, kind
+    return rid, kind0
 
 
 @pytest.mark.parametrize("kind", ["bench", "torch", "random", "star"])
@@ -212,4 +210,8 @@ def test_region_core_headline_shape(cuda):
         scale = max(float(b[n].abs().max()), 1e-30)
         err = float((a[n] - b[n]).abs().max()) / scale
         print(f"  {n}: {err:.2e} of its scale between the two paths")
-        assert err <= (2e-5 if n in ("out", "q", "k", "v") else 5e-4), f"{n} differs by {err:.2e}"
+        # d vs and the six MLP gradients are sums over up to 10 000 queries in which every pair whose pre-activation lies within fp32
+        # rounding of zero may take the other branch in the other kernel family (3.2e9 decisions here: ~1e3 such ties); one flipped term
+        # is ~1e-2 of a key's sum.  Both families are held to the fp64 oracle with their OWN decisions imposed (tests above, and
+        # tests/test_gpu_configs.py at full size); against each other only the decision-continuous tensors are compared tightly.
+        assert err <= (2e-5 if n in ("out", "q", "k", "v") else 2e-2), f"{n} differs by {err:.2e}"
