@@ -11,7 +11,7 @@
  *     Python side); the library never allocates, frees or retains device memory;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant;
  *   - return value 0 = ok, negative = error; the message is read with smml_last_error()
- *     (thread-local); no exception crosses the boundary;
+ *     (thread-local: the one piece of per-thread state the library keeps); no exception crosses the boundary;
  *   - "accumulated into" outputs must be zeroed (or hold a running sum) by the caller;
  *   - fixed widths of the two fused attention families (no other value is built, the entry points return an error):
  *     head dim 64; position-bias MLP posdim -> 32 -> 32 -> heads / groups (the reference's dim = 128), heads / groups <= 2.
@@ -128,22 +128,15 @@ int smml_offsets_out_len(int s, int ks, int r);
 int smml_offsets_fwd_f32(const float* q, const float* w0, const float* b0, const float* w2, float* vgrid,
                          float* vs, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
                          float offset_scale, void* stream);
-/* upstream gradient = dvgrid (direct, nullable) + 2/max(t-1,1) * dvs (nullable); dq, dw0, db0, dw2 are overwritten
- * (gather formulation, no atomics); workspace: smml_offsets_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
+/* upstream gradient = dvgrid (direct, nullable) + 2/max(t-1,1) * dvs (nullable); dw0, db0, dw2 are overwritten (gather formulation, no
+ * atomics); dq is overwritten, or - accumulate_dq = 1 - ADDED to: dq then already holds the gradient q received from its other consumer,
+ * the fused attention core (one pass over the [B, N, 512] tensor instead of a store plus an elementwise add).
+ * workspace: smml_offsets_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
 size_t smml_offsets_bwd_workspace_bytes(int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim);
 int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const float* w2,
                          const float* dvgrid, const float* dvs, float* dq, float* dw0, float* db0,
                          float* dw2, void* workspace, size_t workspace_bytes, int B, int Hh, int Ww, int G, int dg,
-                         int ks, int r, int posdim, float offset_scale, void* stream);
-/* 1: the NEXT smml_offsets_bwd_f32 call of this host thread ADDS the gradient of q into dq (which already holds the gradient q received from
- * its other consumer, the fused attention core) instead of overwriting it - one pass over the [B, N, 512] tensor instead of a store plus an
- * elementwise add; 0 (default) restores overwriting.  Thread-local, like smml_deform_attn_set_seed_offset. */
-void smml_offsets_bwd_accumulate_dq(int on);
-/* Position transform of the continuous position bias: log_distance = 0 makes the fused-attention launches (fp32-grade and 16-bit, forward, backward
- * and smml_deform_attn_relu1_masks) of this host thread with posdim 1 feed the bias MLP the raw offset gq - vs instead of
- * sign(d) log(|d| + 1) - DeformableAttention1D.py:92 with cpb_log_distance = False; 1 (default) restores the signed log.  posdim 2 has no such
- * switch in the reference; the table modes are signed-log only. */
-void smml_deform_attn_set_log_distance(int log_distance);
+                         int ks, int r, int posdim, float offset_scale, int accumulate_dq, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear sampling = F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) of the
@@ -159,6 +152,23 @@ int smml_bilinear_sample_bwd_f32(const float* x, const float* vs, const float* d
  * in the order (x0,y0) (x1,y0) (x0,y1) (x1,y1) for n sample points vs [n, posdim]. */
 int smml_bilinear_corners_f32(const float* vs, int* cx, int* cy, unsigned char* cm, int n, int Hh, int Ww,
                               int posdim, void* stream);
+
+#ifndef SMML_DEFORM_OPTS_DEFINED
+#define SMML_DEFORM_OPTS_DEFINED
+/* Optional behaviour of ONE fused deformable-attention launch (trailing `opts` argument of the entry points below; NULL = all defaults).
+ * Passed by the caller with every call: the library keeps no per-thread or global launch state. */
+typedef struct SmmlDeformOpts {
+  const unsigned long long* seed_offset; /* device-resident offset hashed into dropout_seed when the kernel RUNS (a launch captured in a hipGraph
+                                            bakes dropout_seed in; the offset lets every replay draw a new mask), or NULL */
+  int raw_distance;                      /* 1: posdim-1 launches feed the bias MLP the raw offset gq - vs (DeformableAttention1D.py:92,
+                                            cpb_log_distance = False); 0: its signed log (the reference's default; posdim 2 has no such switch) */
+  const unsigned short* mask_table;      /* smml_deform_attn16_bwd with relu_masks == NULL: layer-2 ReLU decisions from this table (filled by
+                                            smml_cpb_mask_table with mask_table_pmax), or NULL = recompute layer 2 per pair */
+  float mask_table_pmax;
+  unsigned short* export_masks;          /* tests: smml_deform_attn16_bwd with relu_masks == NULL also writes the decisions it used here
+                                            ([B, H, nst / 32, J, 2, 32] u16, the forward's layout), or NULL */
+} SmmlDeformOpts;
+#endif
 
 /* ------------------------------------------------------------------------------------------------
  * Fused deformable cross-attention core: softmax(scale q k^T + CPB(gq - vs)) v with the continuous
@@ -179,7 +189,7 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
                              unsigned short* relu_masks, int B, int N, int J, int H, int G, int posdim, float scale,
-                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
+                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 /* scratch the backward needs: position-bias gradient slabs, the per-wave d vs rows and the query-sliced dK / dV partial sums;
  * 16-byte aligned */
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H);
@@ -192,7 +202,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* dlogits_t, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
-                             void* ev_start, void* ev_stop, void* stream);
+                             void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 /* The same fused core with the position bias evaluated EXACTLY PER LINEAR REGION of its MLP (csrc/cpb_regions.h; round 5).  The MLP of
  * models/DeformableAttention2D.py:129-152 is piecewise affine in the signed-log offsets (:148): smml_cpb_regions_build tabulates, for the
  * current parameters, which linear piece every cell of [-pmax, pmax]^2 lies in (cells a ReLU kink crosses carry the kink's line, cells
@@ -213,7 +223,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                     const float* b3, const void* tables, float* out, float* lse, float* logits_t,
                                     unsigned short* region_ids, int B, int N, int J, int H, float scale, float dropout_p,
-                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 size_t smml_deform_attn_region_bwd_workspace_bytes(int B, int N, int J, int H);
 int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float* v, const float* vs, const float* gq,
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
@@ -221,7 +231,7 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
                                     const float* logits_t, const unsigned short* region_ids, float* dlogits_t, float* dq, float* dk,
                                     float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                                     void* workspace, size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
-                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream);
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 /* 16-bit compute mode of the same fused core (csrc/deform_attn16.hip; BASELINE config 4 names bf16, config 5 fp16): the op sequence of
  * smml_deform_attn_fwd_f32 / _bwd_f32 (models/DeformableAttention2D.py:120-157,284-312; DeformableAttention1D.py:60-102,205-232) with
  * single-term 16-bit operands on the matrix pipe - dtype 0 = bf16, 1 = fp16 for forward-range operands (q, k, v, probabilities, the
@@ -236,27 +246,25 @@ int smml_deform_attn16_fwd(const float* q, const float* k, const float* v, const
                            const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, float* out,
                            float* lse, unsigned short* logits16, unsigned short* relu_masks, int B, int N, int J, int H, int G,
                            int posdim, float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start,
-                           void* ev_stop, void* stream);
+                           void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
                            const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const float* out,
                            const float* dout, const float* lse, const unsigned short* logits16, const unsigned short* relu_masks,
                            unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1,
                            float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
                            int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
-                           int dtype, void* ev_start, void* ev_stop, void* stream);
+                           int dtype, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 /* relu_masks == NULL in smml_deform_attn16_bwd: the forward ran without the MLP (smml_deform_attn_table_fwd below) and saved no ReLU bits -
- * the backward recomputes layer 2 per pair (one bf16 term) and differentiates the per-pair MLP exactly as with saved bits.  Tests: the next
- * such call of this host thread also writes its layer-2 decisions to `out` (relu_masks' layout); NULL switches the export off. */
-void smml_deform_attn16_export_masks(unsigned short* out);
+ * the backward recomputes layer 2 per pair (one bf16 term) and differentiates the per-pair MLP exactly as with saved bits
+ * (opts->export_masks: tests read the decisions it used). */
 /* Mask table: instead of recomputing layer 2 per pair, a relu_masks == NULL backward can take the layer-2 decisions from a table of the sign
  * pattern of W2 relu(W1 p + b1) + b2 at the centres of cells^posdim cells over [-pmax, pmax]^posdim (cells = smml_cpb_mask_table_cells(posdim):
  * 1024 per axis in 2-D, 16384 in 1-D; `table` = cells^posdim 32-bit words = two u16 lane-half words in relu_masks' bit layout).  A pair's
  * decision then differs from its own pre-activation's sign only where a layer-2 kink crosses its cell (|x2| <= |grad x2| x 1.8e-3), the size of the
- * decision noise of the single-term bf16 product.  smml_deform_attn16_set_mask_table applies to the NEXT such backward of this host thread. */
+ * decision noise of the single-term bf16 product.  Handed to the backward as opts->mask_table / opts->mask_table_pmax. */
 int smml_cpb_mask_table_cells(int posdim);
 int smml_cpb_mask_table(const float* w1, const float* b1, const float* w2, const float* b2, unsigned short* table, int posdim, float pmax,
                         void* stream);
-void smml_deform_attn16_set_mask_table(const unsigned short* table, float pmax);
 /* Table mode of the 16-bit core (csrc/deform_attn16.hip, "table mode"): the continuous position bias CPB(slog(gq - vs)) of
  * models/DeformableAttention2D.py:120-157 / DeformableAttention1D.py:60-102 is ONE function of the posdim signed-log offsets for every
  * pair of a launch, so the caller evaluates the MLP once on a grid - `table` [H / G, points^posdim] fp32, point (i0, i1) at index
@@ -274,26 +282,20 @@ size_t smml_deform_attn_table_bwd_workspace_bytes(int B, int N, int J, int H, in
 int smml_deform_attn_table_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
                                float* out, float* lse, unsigned short* logits16, int B, int N, int J, int H, int G, int posdim,
                                int table_g, float table_pmax, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
-                               void* ev_start, void* ev_stop, void* stream);
+                               void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
                                const float* out, const float* dout, const float* lse, const unsigned short* logits16,
                                unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dtable, void* workspace,
                                size_t workspace_bytes, int B, int N, int J, int H, int G, int posdim, int table_g, float table_pmax,
                                int grid_h, int grid_w, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
-                               void* ev_start, void* ev_stop, void* stream);
+                               void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
 
-/* hipGraph support for attention dropout.  `dropout_seed` is a host value and is baked into a captured launch; to give every
- * replay its own mask, point the calling thread at a device-resident 64-bit offset first: the forward / backward / mask
- * launches issued by this thread afterwards add *device_offset to dropout_seed when they RUN (the pointer is never dereferenced
- * on the host).  The forward and the backward of one call must see the same value, so hand each call its own copy of the counter.
- * nullptr (the default) restores the plain host seed.  Thread-local. */
-void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset);
 
 /* attention dropout (nn.Dropout on the probabilities, DeformableAttention2D.py:309 / 1D :229): dropout_p in
  * [0, 1) and a 64-bit seed select a counter-based keep decision per (b, h, query, key); pass the same pair to
  * forward and backward.  The mask itself (0 / 1 floats [B, H, N, J]) is only materialised for tests: */
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p,
-                                      unsigned long long dropout_seed, void* stream);
+                                      unsigned long long dropout_seed, void* stream, const SmmlDeformOpts* opts);
 
 /* decision export (parity tests only): the ReLU decisions [W1 p + b1 > 0] of the position bias's FIRST layer
  * (DeformableAttention2D.py:129-131, 1D :69-71) bit for bit as the fused forward and the position-bias backward evaluate them,
@@ -301,7 +303,7 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
  * and smml_bilinear_corners_f32 (the sampler's cells) this is every piecewise-linear decision of the module; tests impose
  * them on the fp64 oracle so that gradient comparisons do not depend on rounding-level ties. */
 int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* w1, const float* b1, unsigned short* masks,
-                                 int B, int N, int J, int G, int posdim, void* stream);
+                                 int B, int N, int J, int G, int posdim, void* stream, const SmmlDeformOpts* opts);
 
 /* ------------------------------------------------------------------------------------------------
  * Nystrom landmark self-attention, HBM-bound pieces (the contractions of models/NystromAttention.py:86,

@@ -15,7 +15,18 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMML_LIB") or os.path.join(_PKG, "lib", "libsmml_hip.so")
 
 _f = C.c_void_p          # device pointers travel as void*
+
+
+class DeformOpts(C.Structure):
+    """SmmlDeformOpts of include/smml.h: optional behaviour of ONE fused deformable-attention launch, passed with the call."""
+    _fields_ = [("seed_offset", C.c_void_p), ("raw_distance", C.c_int), ("mask_table", C.c_void_p), ("mask_table_pmax", C.c_float),
+                ("export_masks", C.c_void_p)]
+
+
+_o = C.POINTER(DeformOpts)
 _i, _ll, _fl, _sz = C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+ABI_VERSION = 2          # smml_abi_version() of the library this binding is written against
 
 # name -> (restype, argtypes); mirrors include/smml.h one to one
 SIGNATURES = {
@@ -49,34 +60,29 @@ SIGNATURES = {
     "smml_offsets_out_len": (_i, [_i, _i, _i]),
     "smml_offsets_fwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
     "smml_offsets_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "smml_offsets_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f]),
-    "smml_offsets_bwd_accumulate_dq": (None, [_i]),
+    "smml_offsets_bwd_f32": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _f]),
     "smml_bilinear_sample_fwd_f32": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
     "smml_bilinear_sample_bwd_f32": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f]),
     "smml_bilinear_corners_f32": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _f]),
     "smml_deform_attn_nst": (_i, [_i]),
-    "smml_deform_attn_fwd_f32": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
-    "smml_deform_attn_set_seed_offset": (None, [_f]),
-    "smml_deform_attn_dropout_mask_f32": (_i, [_f, _i, _i, _i, _i, _fl, C.c_ulonglong, _f]),
-    "smml_deform_attn_relu1_masks": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "smml_deform_attn_fwd_f32": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
+    "smml_deform_attn_dropout_mask_f32": (_i, [_f, _i, _i, _i, _i, _fl, C.c_ulonglong, _f] + [_o]),
+    "smml_deform_attn_relu1_masks": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f] + [_o]),
     "smml_deform_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "smml_deform_attn_bwd_f32": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
+    "smml_deform_attn_bwd_f32": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
     "smml_cpb_regions_bytes": (_sz, []),
     "smml_cpb_regions_build": (_i, [_f] * 6 + [_fl, _f, _sz, _f]),
-    "smml_deform_attn_region_fwd_f32": (_i, [_f] * 16 + [_i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
+    "smml_deform_attn_region_fwd_f32": (_i, [_f] * 16 + [_i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
     "smml_deform_attn_region_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "smml_deform_attn_region_bwd_f32": (_i, [_f] * 28 + [_f, _sz, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f]),
-    "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
-    "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
-    "smml_deform_attn_set_log_distance": (None, [_i]),
-    "smml_deform_attn16_export_masks": (None, [_f]),
+    "smml_deform_attn_region_bwd_f32": (_i, [_f] * 28 + [_f, _sz, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
+    "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
+    "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
     "smml_cpb_mask_table_cells": (_i, [_i]),
     "smml_cpb_mask_table": (_i, [_f, _f, _f, _f, _f, _i, _fl, _f]),
-    "smml_deform_attn16_set_mask_table": (None, [_f, _fl]),
     "smml_deform_attn_table_points": (_i, [_i]),
     "smml_deform_attn_table_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "smml_deform_attn_table_fwd": (_i, [_f] * 9 + [_i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
-    "smml_deform_attn_table_bwd": (_i, [_f] * 16 + [_f, _sz, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f]),
+    "smml_deform_attn_table_fwd": (_i, [_f] * 9 + [_i, _i, _i, _i, _i, _i, _i, _fl, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
+    "smml_deform_attn_table_bwd": (_i, [_f] * 16 + [_f, _sz, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
     "smml_softmax_fwd_f32": (_i, [_f, _f, _ll, _i, _f]),
     "smml_softmax_bwd_f32": (_i, [_f, _f, _f, _ll, _i, _f]),
     "smml_tile_rows_f32": (_i, [_f, _f, _ll, _i, _i, _fl, _f]),
@@ -119,12 +125,26 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)      # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if handle.smml_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} implements C-ABI version {handle.smml_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
         if os.environ.get("SMML_GEMM_MODE"):       # measurement switch: 1 = fp32-MFMA GEMM only, 2 = split-bf16 wherever it applies
             handle.smml_gemm_set_mode(int(os.environ["SMML_GEMM_MODE"]))
         if os.environ.get("SMML_GEMM_SMALL_TILE"):  # measurement switch: 1 = never the 64-row tile, 2 = wherever it applies
             handle.smml_gemm_set_small_tile(int(os.environ["SMML_GEMM_SMALL_TILE"]))
         _lib = handle
     return _lib
+
+
+def deform_opts(seed_offset: Optional[torch.Tensor] = None, log_distance: bool = True, mask_table: Optional[torch.Tensor] = None,
+                mask_table_pmax: float = 0.0, export_masks: Optional[torch.Tensor] = None):
+    """The `opts` argument of a fused deformable-attention entry point (byref of a DeformOpts), or None when every field is at its default.
+    The struct is read during the call only; the tensors it points at must outlive the launch (the callers keep them)."""
+    if seed_offset is None and log_distance and mask_table is None and export_masks is None:
+        return None
+    if seed_offset is not None and (seed_offset.dtype != torch.int64 or seed_offset.numel() != 1):
+        raise RuntimeError("dropout_seed_offset must be a device int64 tensor with one element")
+    o = DeformOpts(ptr(seed_offset), 0 if log_distance else 1, ptr(mask_table), float(mask_table_pmax), ptr(export_masks))
+    return C.byref(o)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -22,6 +22,7 @@
 // LDS reads of V^T reproduce).  head dim 64; 32 queries per wave, 4 waves per workgroup, 32-key tiles, double-buffered
 // LDS with the next tile's global loads in flight during the MFMAs.
 #include <algorithm>
+#include <atomic>     // process-wide measurement switches (set once from the environment or a test hook): plain atomics, no launch state
 #include <cstdlib>
 #include "smml_common.h"
 
@@ -1060,8 +1061,8 @@ static int attn16_parts(int BH, int Lq, int Lk) {
 // (profiles/r03_nystrom16_notes.md): the two-pass kernel issues 13 vector instructions per MFMA instead of 24, and is SLOWER (69 vs 54
 // us): with fp32 storage this launch moves 252 MB (q in, residual in, out out) - 4.7 TB/s at 54 us - i.e. the [n', m] side of the Nystrom
 // block is HBM-bound, not issue-bound, and one 8-wave workgroup per CU (86 KB of LDS) keeps fewer bytes in flight than two 4-wave ones.
-static int g_fewkeys = -1;
-static int g_q2 = 1;              // queries-long bf16-storage forward: 0 one query block per wave, 1 (default) two blocks per wave where the
+static std::atomic<int> g_fewkeys{-1};
+static std::atomic<int> g_q2{1};              // queries-long bf16-storage forward: 0 one query block per wave, 1 (default) two blocks per wave where the
                                   // 256-query workgroups still cover the chip twice over, 2 always (smml_attn16_set_query_blocks)
 
 extern "C" {

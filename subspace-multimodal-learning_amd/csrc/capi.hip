@@ -18,7 +18,7 @@ extern "C" {
 
 const char* smml_last_error(void) { return g_err; }
 
-int smml_abi_version(void) { return 1; }
+int smml_abi_version(void) { return 2; }   // 2: per-call SmmlDeformOpts instead of per-thread setters, region entry points (round 5)
 
 // 0 when a gfx950 device is usable by this process, negative (with message) otherwise
 int smml_device_check(int device) {

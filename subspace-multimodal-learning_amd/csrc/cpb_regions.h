@@ -645,7 +645,6 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     }
     if (tid < KT) { vsl[(kt + 1) & 1][tid][0] = vsn.x; vsl[(kt + 1) & 1][tid][1] = vsn.y; }     // the NEXT tile's sample positions
     lds_barrier();
-    fetch_kv(j0 + KT);                                 // the next tile's K / V rows and the sample positions after it, in flight during this tile
 
     // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
@@ -664,30 +663,30 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     //   reads one (record 0 where it needs none: one address, no traffic); (c) the side of the kink, the region's (a, c) from LDS.
     const int nk = min(KT, J - j0);
     unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
+    unsigned e1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {             // (a) issue: the sub-cell codes of the refined cells (none is consumed inside this loop)
+      const unsigned e = ent[r];
+      e1[r] = 0u;
+#if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
+      const bool sub = e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0;
+      if (__ballot(sub)) {                     // wave-uniform: a third of the (wave, pair) steps
+        const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
+        int cx, cy;
+        region_cell_index(u0, u1, cx, cy);
+        const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
+        const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
+        e1[r] = rv.t1[sub ? (size_t)(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx : (size_t)0];
+      }
+#endif
+    }
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
-      unsigned e8[8], e1[8];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {         // (a) issue: the sub-cell codes of the refined cells (none is consumed inside this loop)
-        const int r = 8 * g8 + r8;
-        const unsigned e = ent[r];
-        e1[r8] = 0u;
-#if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
-        const bool sub = e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0;
-        if (__ballot(sub)) {                   // wave-uniform: a third of the (wave, pair) steps
-          const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
-          int cx, cy;
-          region_cell_index(u0, u1, cx, cy);
-          const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
-          const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
-          e1[r8] = rv.t1[sub ? (size_t)(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx : (size_t)0];
-        }
-#endif
-      }
+      unsigned e8[8];
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const unsigned e = ent[8 * g8 + r8];
-        e8[r8] = (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) ? e1[r8] : e;
+        e8[r8] = (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) ? e1[8 * g8 + r8] : e;
       }
       float4 rec8[8];
 #pragma unroll
@@ -739,6 +738,11 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       }
       wave_lds_fence();
     }
+    // the next tile's K / V rows (and the sample positions of the tile after it): in flight during the softmax, the P V products and
+    // the next tile's first step.  Issued only now: vector-memory operations retire in order and the waits above count the operations
+    // behind the one they wait for - behind branches the compiler has to assume the fewest, so younger loads in flight there would be
+    // waited for as well (measured: 0.8 ms of this kernel with the prefetch in front of the lookup stages)
+    fetch_kv(j0 + KT);
     // pairs without a region (~1e-4 of all): the MLP itself, one pair at a time, by the whole wave - outside the unrolled loops
     for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
       const int l = __ffsll((long long)todo) - 1;

@@ -1130,12 +1130,6 @@ __global__ void drop_mask_kernel(float* __restrict__ mask, unsigned long long to
 
 }  // namespace
 
-// seed offset of the calling host thread's next launches (read by make_drop in deform_common.h, also from deform_attn16.hip)
-static thread_local const unsigned long long* t_seed_offset = nullptr;
-const unsigned long long* smml_internal_seed_offset() { return t_seed_offset; }
-static thread_local int t_raw_distance = 0;       // smml_deform_attn_set_log_distance
-int smml_internal_pdx(int posdim) { return posdim == 2 ? 2 : (t_raw_distance ? 3 : 1); }
-
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
@@ -1145,31 +1139,26 @@ extern "C" {
 // without per-lane bounds checks (columns >= N are padding nobody reads)
 int smml_deform_attn_nst(int N) { return (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
 
-void smml_deform_attn_set_seed_offset(const unsigned long long* device_offset) { t_seed_offset = device_offset; }
-// log_distance = 0: the fused-attention launches of this host thread with posdim 1 feed the bias MLP the RAW offset gq - vs instead of its signed
-// log (DeformableAttention1D.py:92, cpb_log_distance = False); 1 (default): the signed log.  posdim 2 has no such switch in the reference.
-void smml_deform_attn_set_log_distance(int log_distance) { t_raw_distance = log_distance ? 0 : 1; }
-
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
-                                      void* stream) {
+                                      void* stream, const SmmlDeformOpts* opts) {
   SMML_REQUIRE(mask && B > 0 && N > 0 && J > 0 && H > 0 && dropout_p >= 0.f && dropout_p < 1.f,
                "smml_deform_attn_dropout_mask_f32: bad argument");
   const unsigned long long total = (unsigned long long)B * H * N * J;
   hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total, J,
-                     make_drop(dropout_p, dropout_seed));
+                     make_drop(dropout_p, dropout_seed, opts));
   SMML_LAUNCH_CHECK("smml_deform_attn_dropout_mask_f32");
   return SMML_OK;
 }
 
 int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* w1, const float* b1, unsigned short* masks, int B,
-                                 int N, int J, int G, int posdim, void* stream) {
+                                 int N, int J, int G, int posdim, void* stream, const SmmlDeformOpts* opts) {
   SMML_REQUIRE(vs && gq && w1 && b1 && masks && B > 0 && N > 0 && J > 0 && G > 0 && (posdim == 1 || posdim == 2) && B <= 65535 &&
                    G <= 65535, "smml_deform_attn_relu1_masks: bad argument");
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), G, B), block(256);
   const int nst = smml_deform_attn_nst(N);
   if (posdim == 2)
     hipLaunchKernelGGL(relu1_masks_kernel<2>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
-  else if (smml_internal_pdx(posdim) == 3)
+  else if (pdx_of(posdim, opts) == 3)
     hipLaunchKernelGGL(relu1_masks_kernel<3>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
   else
     hipLaunchKernelGGL(relu1_masks_kernel<1>, grid, block, 0, (hipStream_t)stream, vs, gq, w1, b1, masks, N, J, G, nst);
@@ -1195,10 +1184,10 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* w3, const float* b3, float* out, float* lse, float* logits_t,
                              unsigned short* relu_masks, int B, int N, int J, int H, int G, int posdim, float scale,
-                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+                             float dropout_p, unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check_common("smml_deform_attn_fwd_f32", B, N, J, H, G, posdim);
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_fwd_f32: dropout_p must be in [0, 1)");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   if (rc) return rc;
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && lse,
                "smml_deform_attn_fwd_f32: null pointer");
@@ -1215,10 +1204,10 @@ int smml_deform_attn_fwd_f32(const float* q, const float* k, const float* v, con
   else if (posdim == 2)
     hipLaunchKernelGGL((deform_attn_fwd_kernel<2, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
                        relu_masks, N, J, H, G, nst, scale, dc);
-  else if (smml_internal_pdx(posdim) == 3 && relu_masks)         // 1-D, raw offsets (cpb_log_distance = False)
+  else if (pdx_of(posdim, opts) == 3 && relu_masks)         // 1-D, raw offsets (cpb_log_distance = False)
     hipLaunchKernelGGL((deform_attn_fwd_kernel<3, true>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
                        relu_masks, N, J, H, G, nst, scale, dc);
-  else if (smml_internal_pdx(posdim) == 3)
+  else if (pdx_of(posdim, opts) == 3)
     hipLaunchKernelGGL((deform_attn_fwd_kernel<3, false>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, logits_t,
                        relu_masks, N, J, H, G, nst, scale, dc);
   else if (relu_masks)
@@ -1240,10 +1229,10 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
                              float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
                              float* db3, void* workspace, size_t workspace_bytes, int B, int N, int J, int H,
                              int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
-                             void* ev_start, void* ev_stop, void* stream) {
+                             void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check_common("smml_deform_attn_bwd_f32", B, N, J, H, G, posdim);
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_bwd_f32: dropout_p must be in [0, 1)");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   if (rc) return rc;
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && dout && lse && logits_t &&
                    relu_masks && dlogits_t && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
@@ -1285,7 +1274,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
     if (posdim == 2)
       hipLaunchKernelGGL(cpb_bwd_kernel<2>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
                          wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
-    else if (smml_internal_pdx(posdim) == 3)
+    else if (pdx_of(posdim, opts) == 3)
       hipLaunchKernelGGL(cpb_bwd_kernel<3>, dim3(qtiles, H, B), block, lds, st, dlogits_t, relu_masks, logits_t, lse,
                          wsf + wsl.rho, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst);
     else
@@ -1372,7 +1361,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                     const float* b3, const void* tables, float* out, float* lse, float* logits_t,
                                     unsigned short* region_ids, int B, int N, int J, int H, float scale, float dropout_p,
-                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check_region("smml_deform_attn_region_fwd_f32", B, N, J, H);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_region_fwd_f32: dropout_p must be in [0, 1)");
@@ -1380,7 +1369,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
                "smml_deform_attn_region_fwd_f32: null pointer");
   SMML_REQUIRE((logits_t == nullptr) == (region_ids == nullptr),
                "smml_deform_attn_region_fwd_f32: logits_t and region_ids are saved together (training) or not at all");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   const RegionView rv = region_view(const_cast<void*>(tables));
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B), block(256);
@@ -1409,7 +1398,7 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
                                     const float* logits_t, const unsigned short* region_ids, float* dlogits_t, float* dq, float* dk,
                                     float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                                     void* workspace, size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
-                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream) {
+                                    unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check_region("smml_deform_attn_region_bwd_f32", B, N, J, H);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_region_bwd_f32: dropout_p must be in [0, 1)");
@@ -1420,7 +1409,7 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
   SMML_REQUIRE(workspace_bytes >= pl.total, "smml_deform_attn_region_bwd_f32: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
   SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 255) == 0, "smml_deform_attn_region_bwd_f32: workspace must be 256-byte aligned");
   SMML_REQUIRE(pl.wpk >= 1, "smml_deform_attn_region_bwd_f32: too many keys (%d)", J);
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   hipStream_t st = (hipStream_t)stream;
   const int nst = smml_deform_attn_nst(N);

@@ -1395,25 +1395,21 @@ int check16(const char* fn, int B, int N, int J, int H, int G, int posdim, int d
 template <typename T>
 void launch_fwd16(dim3 grid, hipStream_t st, bool save, int posdim, const float* q, const float* k, const float* v, const float* vs,
                   const float* gq, CpbParams cp, float* out, float* lse, u16* lt, u16* mk, int N, int J, int H, int G, int nst,
-                  float scale, DropCfg dc) {
+                  float scale, DropCfg dc, const SmmlDeformOpts* opts) {
   dim3 block(256);
   if (posdim == 2 && save)
     hipLaunchKernelGGL((deform16_fwd_kernel<2, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else if (posdim == 2)
     hipLaunchKernelGGL((deform16_fwd_kernel<2, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
-  else if (smml_internal_pdx(posdim) == 3 && save)              // 1-D, raw offsets (cpb_log_distance = False)
+  else if (pdx_of(posdim, opts) == 3 && save)              // 1-D, raw offsets (cpb_log_distance = False)
     hipLaunchKernelGGL((deform16_fwd_kernel<3, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
-  else if (smml_internal_pdx(posdim) == 3)
+  else if (pdx_of(posdim, opts) == 3)
     hipLaunchKernelGGL((deform16_fwd_kernel<3, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else if (save)
     hipLaunchKernelGGL((deform16_fwd_kernel<1, true, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
   else
     hipLaunchKernelGGL((deform16_fwd_kernel<1, false, T>), grid, block, 0, st, q, k, v, vs, gq, cp, out, lse, lt, mk, N, J, H, G, nst, scale, dc);
 }
-
-thread_local const u16* g_mask_table = nullptr;  // smml_deform_attn16_set_mask_table: mask table of the next recomputation-free table-forward backward
-thread_local float g_mask_table_pmax = 0.f;
-thread_local u16* g_export_masks = nullptr;      // smml_deform_attn16_export_masks: where the next recomputing backward of this thread writes its layer-2 decisions
 
 constexpr int TABLE_G2 = 96;      // grid points per axis of the 2-D table (36 KB in LDS: two forward workgroups per CU)
 constexpr int TABLE_G1 = 1024;    // points of the 1-D table
@@ -1463,8 +1459,8 @@ TableWorkspace table_workspace(int B, int N, int J, int H, int cells) {
   w.total = w.slab + (size_t)B * H * nslab * cells;
   return w;
 }
-int check_table(const char* fn, int posdim, int table_g, float pmax) {
-  SMML_REQUIRE(smml_internal_pdx(posdim) != 3, "%s: the table modes are built for the signed-log position transform (log_distance) only", fn);
+int check_table(const char* fn, int posdim, int table_g, float pmax, const SmmlDeformOpts* opts) {
+  SMML_REQUIRE(pdx_of(posdim, opts) != 3, "%s: the table modes are built for the signed-log position transform (log_distance) only", fn);
   SMML_REQUIRE(table_g == (posdim == 2 ? TABLE_G2 : TABLE_G1), "%s: the table kernels are built for %d grid points per axis with posdim %d (got %d)",
                fn, posdim == 2 ? TABLE_G2 : TABLE_G1, posdim, table_g);
   SMML_REQUIRE(pmax > 0.f, "%s: table_pmax must be positive", fn);
@@ -1485,21 +1481,21 @@ int smml_deform_attn16_fwd(const float* q, const float* k, const float* v, const
                            const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, float* out,
                            float* lse, unsigned short* logits16, unsigned short* relu_masks, int B, int N, int J, int H, int G,
                            int posdim, float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start,
-                           void* ev_stop, void* stream) {
+                           void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check16("smml_deform_attn16_fwd", B, N, J, H, G, posdim, dtype);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_fwd: dropout_p must be in [0, 1)");
   SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && out && lse, "smml_deform_attn16_fwd: null pointer");
   SMML_REQUIRE((logits16 == nullptr) == (relu_masks == nullptr),
                "smml_deform_attn16_fwd: logits16 and relu_masks are saved together (training) or not at all");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B);
   const int nst = smml_deform_attn_nst(N);
   hipStream_t st = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  if (dtype == 1) launch_fwd16<_Float16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc);
-  else launch_fwd16<__bf16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc);
+  if (dtype == 1) launch_fwd16<_Float16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc, opts);
+  else launch_fwd16<__bf16>(grid, st, relu_masks != nullptr, posdim, q, k, v, vs, gq, cp, out, lse, logits16, relu_masks, N, J, H, G, nst, scale, dc, opts);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   SMML_LAUNCH_CHECK("smml_deform_attn16_fwd");
   return SMML_OK;
@@ -1511,7 +1507,7 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
                            unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dw1, float* db1,
                            float* dw2, float* db2, float* dw3, float* db3, void* workspace, size_t workspace_bytes, int B, int N,
                            int J, int H, int G, int posdim, float scale, float dropout_p, unsigned long long dropout_seed,
-                           int dtype, void* ev_start, void* ev_stop, void* stream) {
+                           int dtype, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check16("smml_deform_attn16_bwd", B, N, J, H, G, posdim, dtype);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_bwd: dropout_p must be in [0, 1)");
@@ -1522,7 +1518,7 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
                "smml_deform_attn16_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                smml_deform_attn_bwd_workspace_bytes(B, N, J, H));
   SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_deform_attn16_bwd: workspace must be 16-byte aligned");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   hipStream_t st = (hipStream_t)stream;
   const int nst = smml_deform_attn_nst(N);
@@ -1555,20 +1551,20 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     float* slab = wsf;
     const size_t lds = ((size_t)CPB2_TAB + WAVES * CPB2_WAVE_LDS + WAVES * CPB_SLAB) * sizeof(float);
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);   // brackets the position-bias backward kernel only
-    u16* mko = g_export_masks;
+    u16* mko = opts ? opts->export_masks : nullptr;
     const dim3 gc(qtiles, H, B);
     if (relu_masks) {
       if (posdim == 2)
         hipLaunchKernelGGL((cpb16_bwd_kernel<2>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
-      else if (smml_internal_pdx(posdim) == 3)
+      else if (pdx_of(posdim, opts) == 3)
         hipLaunchKernelGGL((cpb16_bwd_kernel<3>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
       else
         hipLaunchKernelGGL((cpb16_bwd_kernel<1>), gc, block, lds, st, dlogits16, relu_masks, vs, gq, cp, slab, wsf + wsl.dvs, N, J, H, G, nst, mko);
-    } else if (g_mask_table) {          // decisions from the mask table
+    } else if (opts && opts->mask_table) {          // decisions from the mask table
       const int cells = posdim == 2 ? 1024 : 16384;
       MaskTab mt;
-      mt.tab = g_mask_table;
-      mt.invh = (float)((double)cells / (2.0 * (double)g_mask_table_pmax));
+      mt.tab = opts->mask_table;
+      mt.invh = (float)((double)cells / (2.0 * (double)opts->mask_table_pmax));
       mt.off = 0.5f * (float)cells;
       mt.imax = (float)cells - 0.5f;
       if (posdim == 2 && mko)
@@ -1622,14 +1618,6 @@ int smml_cpb_mask_table(const float* w1, const float* b1, const float* w2, const
   SMML_LAUNCH_CHECK("smml_cpb_mask_table");
   return SMML_OK;
 }
-// the next smml_deform_attn16_bwd call of this host thread with relu_masks == NULL takes its layer-2 decisions from `table` (filled by
-// smml_cpb_mask_table with the same pmax); NULL: such calls recompute layer 2 per pair
-void smml_deform_attn16_set_mask_table(const unsigned short* table, float pmax) { g_mask_table = table; g_mask_table_pmax = pmax; }
-
-// tests: the next smml_deform_attn16_bwd call of this host thread that recomputes layer 2 (relu_masks == NULL) also writes its decisions to
-// `out` ([B, H, nst / 32, J, 2, 32] u16, the forward's layout); NULL switches the export off again
-void smml_deform_attn16_export_masks(unsigned short* out) { g_export_masks = out; }
-
 // ---- table mode (tabulated position bias): same contract as the two entry points above with `table` [o, table_g^posdim] in place of
 // the six MLP tensors and d table in place of their gradients
 int smml_deform_attn_table_points(int posdim) { return posdim == 2 ? TABLE_G2 : TABLE_G1; }
@@ -1641,14 +1629,14 @@ size_t smml_deform_attn_table_bwd_workspace_bytes(int B, int N, int J, int H, in
 int smml_deform_attn_table_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* table,
                                float* out, float* lse, unsigned short* logits16, int B, int N, int J, int H, int G, int posdim,
                                int table_g, float table_pmax, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
-                               void* ev_start, void* ev_stop, void* stream) {
+                               void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check16("smml_deform_attn_table_fwd", B, N, J, H, G, posdim, dtype);
   if (rc) return rc;
-  rc = check_table("smml_deform_attn_table_fwd", posdim, table_g, table_pmax);
+  rc = check_table("smml_deform_attn_table_fwd", posdim, table_g, table_pmax, opts);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_table_fwd: dropout_p must be in [0, 1)");
   SMML_REQUIRE(q && k && v && vs && gq && table && out && lse, "smml_deform_attn_table_fwd: null pointer");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   const TabCfg tc = make_tab(table, table_g, table_pmax);
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B);
   const int nst = smml_deform_attn_nst(N);
@@ -1666,10 +1654,10 @@ int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, c
                                unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs, float* dtable, void* workspace,
                                size_t workspace_bytes, int B, int N, int J, int H, int G, int posdim, int table_g, float table_pmax,
                                int grid_h, int grid_w, float scale, float dropout_p, unsigned long long dropout_seed, int dtype,
-                               void* ev_start, void* ev_stop, void* stream) {
+                               void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts) {
   int rc = check16("smml_deform_attn_table_bwd", B, N, J, H, G, posdim, dtype);
   if (rc) return rc;
-  rc = check_table("smml_deform_attn_table_bwd", posdim, table_g, table_pmax);
+  rc = check_table("smml_deform_attn_table_bwd", posdim, table_g, table_pmax, opts);
   if (rc) return rc;
   SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn_table_bwd: dropout_p must be in [0, 1)");
   SMML_REQUIRE(q && k && v && vs && gq && table && out && dout && lse && logits16 && dlogits16 && dq && dk && dv && dvs && dtable && workspace,
@@ -1677,7 +1665,7 @@ int smml_deform_attn_table_bwd(const float* q, const float* k, const float* v, c
   const size_t need = smml_deform_attn_table_bwd_workspace_bytes(B, N, J, H, posdim);
   SMML_REQUIRE(workspace_bytes >= need, "smml_deform_attn_table_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
   SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "smml_deform_attn_table_bwd: workspace must be 16-byte aligned");
-  const DropCfg dc = make_drop(dropout_p, dropout_seed);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
   const TabCfg tc = make_tab(table, table_g, table_pmax);
   hipStream_t st = (hipStream_t)stream;
   const int nst = smml_deform_attn_nst(N);

@@ -479,16 +479,13 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   return w;
 }
 
-// Device-resident seed offset of the NEXT fused-attention launches issued by this host thread (smml_deform_attn_set_seed_offset,
-// defined in deform_attn.hip): read into the launch's DropCfg, never dereferenced on the host.
-}  // namespace
-const unsigned long long* smml_internal_seed_offset();
-int smml_internal_pdx(int posdim);       // posdim (1 | 2) -> PDX (PosCfg), from the host thread's log-distance switch (deform_attn.hip)
-namespace {
-DropCfg make_drop(float p, unsigned long long seed) {
+// position-dimension template value of a launch (PosCfg): 2 | 1 | 3 = one dimension, raw offsets (opts->raw_distance)
+int pdx_of(int posdim, const SmmlDeformOpts* opts) { return posdim == 2 ? 2 : ((opts && opts->raw_distance) ? 3 : 1); }
+// opts->seed_offset is read into the launch's DropCfg and dereferenced on the device only
+DropCfg make_drop(float p, unsigned long long seed, const SmmlDeformOpts* opts) {
   DropCfg dc;
   dc.seed = seed;
-  dc.seed_dev = smml_internal_seed_offset();
+  dc.seed_dev = opts ? opts->seed_offset : nullptr;
   dc.thresh = (p > 0.f) ? (unsigned)fmax(1.0, (double)p * 65536.0) : 0u;
   dc.keep_scale = (p > 0.f) ? (float)(65536.0 / (65536.0 - (double)dc.thresh)) : 1.0f;
   return dc;

@@ -11,6 +11,7 @@
 // accumulators); operands are staged k-major in LDS so that the 32 lanes of a half-wave read
 // consecutive banks.
 #include "smml_common.h"
+#include <atomic>     // process-wide measurement switches (set once from the environment or a test hook): plain atomics, no launch state
 
 namespace {
 
@@ -559,14 +560,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(GemmArgs g) {
 
 }  // namespace
 
-static int g_force_generic = 0;   // test hook: route everything through the generic kernel
-static int g_mode = 0;            // 0: automatic, 1: fp32-MFMA tiled kernel only, 2: split-bf16 kernel wherever it applies,
+static std::atomic<int> g_force_generic{0};   // test hook: route everything through the generic kernel
+static std::atomic<int> g_mode{0};            // 0: automatic, 1: fp32-MFMA tiled kernel only, 2: split-bf16 kernel wherever it applies,
                                   // 3: single-term bf16 kernel wherever it applies (16-bit compute mode: 8-bit operand mantissas)
                                   // 4: single-term fp16 kernel (11-bit operand mantissas, fp16's range: forward-range operands only)
 extern "C" void smml_gemm_force_generic(int on) { g_force_generic = on; }
 extern "C" void smml_gemm_set_mode(int mode) { g_mode = mode; }
 extern "C" int smml_gemm_get_mode(void) { return g_mode; }
-static int g_small_tile = 0;      // 0: automatic, 1: never use the 64-row tile, 2: use it wherever it applies (measurement hooks)
+static std::atomic<int> g_small_tile{0};      // 0: automatic, 1: never use the 64-row tile, 2: use it wherever it applies (measurement hooks)
 extern "C" void smml_gemm_set_small_tile(int v) { g_small_tile = v; }
 
 extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,

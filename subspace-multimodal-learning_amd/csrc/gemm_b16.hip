@@ -15,6 +15,7 @@
 // Workgroup ids are remapped so that each XCD walks a contiguous range of tiles (column tiles fastest): the column tiles of one row panel
 // share the panel through one L2 instead of eight.
 #include <algorithm>
+#include <atomic>     // process-wide measurement switches (set once from the environment or a test hook): plain atomics, no launch state
 #include <cmath>
 #include <cstdlib>
 #include "smml_common.h"
@@ -397,8 +398,8 @@ __global__ __launch_bounds__(512, 1) void gemm_b16_big_kernel(B16Args g) {
     }
 }
 
-static int g_b16_slice_major = 1;   // measurement switch (smml_gemm_b16_set_slice_major): 0 = slices of a split reduction spread over the XCDs
-static int g_b16_tile = -1;      // -1: read SMML_B16_TILE; 0: automatic; 1: the 128 x 128 kernel only; 2: the 256-row kernel wherever it applies
+static std::atomic<int> g_b16_slice_major{1};   // measurement switch (smml_gemm_b16_set_slice_major): 0 = slices of a split reduction spread over the XCDs
+static std::atomic<int> g_b16_tile{-1};      // -1: read SMML_B16_TILE; 0: automatic; 1: the 128 x 128 kernel only; 2: the 256-row kernel wherever it applies
 
 }  // namespace
 

@@ -366,11 +366,6 @@ static int offsets_geometry(const char* fn, int Hh, int Ww, int dg, int ks, int 
   return SMML_OK;
 }
 
-// dq of the NEXT smml_offsets_bwd_f32 call of this host thread is accumulated into (the caller hands over a buffer that already holds
-// another consumer's gradient of q) instead of overwritten
-static thread_local int t_accumulate_dq = 0;
-void smml_offsets_bwd_accumulate_dq(int on) { t_accumulate_dq = on; }
-
 // out-length of the strided offset conv along one axis of size s (0 if it does not fit)
 int smml_offsets_out_len(int s, int ks, int r) {
   const int pad = (ks - r) / 2;
@@ -414,7 +409,7 @@ size_t smml_offsets_bwd_workspace_bytes(int B, int Hh, int Ww, int G, int dg, in
 int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const float* w2, const float* dvgrid,
                          const float* dvs, float* dq, float* dw0, float* db0, float* dw2, void* workspace,
                          size_t workspace_bytes, int B, int Hh, int Ww, int G, int dg, int ks, int r, int posdim,
-                         float offset_scale, void* stream) {
+                         float offset_scale, int accumulate_dq, void* stream) {
   SMML_REQUIRE(q && w0 && b0 && w2 && dq && dw0 && db0 && dw2 && workspace, "smml_offsets_bwd_f32: null pointer");
   SMML_REQUIRE(dvgrid || dvs, "smml_offsets_bwd_f32: no upstream gradient");
   SMML_REQUIRE(ks == 6, "smml_offsets_bwd_f32: only offset_kernel_size = 6 is instantiated (got %d)", ks);
@@ -448,7 +443,7 @@ int smml_offsets_bwd_f32(const float* q, const float* w0, const float* b0, const
   // grid.x: slices of a (b, y) row; few enough that the weight staging is amortised, enough rows x slices to fill the chip
   const int row_threads = Ww * (G * dg / 4);
   const int slices = max(1, min((row_threads + 255) / 256, (4096 + B * Hh - 1) / (B * Hh)));
-  if (t_accumulate_dq)
+  if (accumulate_dq)   // dq already holds the gradient q received from its other consumer (the fused attention core): add, do not overwrite
     hipLaunchKernelGGL(offsets_bwd_gather_kernel<true>, dim3(slices, B * Hh), block, (size_t)dg * kh * ks * sizeof(float), st, dyb, w0, dq, Hh,
                        Ww, G, dg, kh, ks, rh, r, ph, pw, th, tw);
   else

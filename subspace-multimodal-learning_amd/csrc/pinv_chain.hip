@@ -10,6 +10,7 @@
 //   dzk = 3.25 dz - 0.25 dz b^T      db = -0.25 z^T dz         dxz = 15 db - db a^T        da = -xz^T db
 //   dxz += 7 da - da xz^T - xz^T da  dx += dxz z^T             dz_k = dzk + x^T dxz
 #include <cstdlib>
+#include <atomic>     // process-wide measurement switches (set once from the environment or a test hook): plain atomics, no launch state
 #include "smml_common.h"
 
 extern "C" int smml_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N, int K,
@@ -419,7 +420,7 @@ int split_p(const float* x, __bf16* P, int NB, void* st) {
 // 2 the two-plane form on the 16-bit pipe (m = 256, only where the caller asked for reduced precision: the 16-bit compute mode).
 // The switch (smml_newton_schulz_set_fast / SMML_CHAIN_FAST): 0 = form 0 everywhere, 1 = form 1 also where reduced precision was asked for,
 // 2 (default) = as described.
-static int g_chain_fast = -1;
+static std::atomic<int> g_chain_fast{-1};
 static int chain_form(int m, int reduced) {
   if (g_chain_fast < 0) { const char* e = getenv("SMML_CHAIN_FAST"); g_chain_fast = e ? atoi(e) : 2; }
   if (m != CM || g_chain_fast == 0) return 0;

@@ -11,6 +11,23 @@
 
 void smml_set_error(const char* fmt, ...);
 
+#ifndef SMML_DEFORM_OPTS_DEFINED
+#define SMML_DEFORM_OPTS_DEFINED
+/* Optional behaviour of ONE fused deformable-attention launch (trailing `opts` argument of the entry points below; NULL = all defaults).
+ * Passed by the caller with every call: the library keeps no per-thread or global launch state. */
+typedef struct SmmlDeformOpts {
+  const unsigned long long* seed_offset; /* device-resident offset hashed into dropout_seed when the kernel RUNS (a launch captured in a hipGraph
+                                            bakes dropout_seed in; the offset lets every replay draw a new mask), or NULL */
+  int raw_distance;                      /* 1: posdim-1 launches feed the bias MLP the raw offset gq - vs (DeformableAttention1D.py:92,
+                                            cpb_log_distance = False); 0: its signed log (the reference's default; posdim 2 has no such switch) */
+  const unsigned short* mask_table;      /* smml_deform_attn16_bwd with relu_masks == NULL: layer-2 ReLU decisions from this table (filled by
+                                            smml_cpb_mask_table with mask_table_pmax), or NULL = recompute layer 2 per pair */
+  float mask_table_pmax;
+  unsigned short* export_masks;          /* tests: smml_deform_attn16_bwd with relu_masks == NULL also writes the decisions it used here
+                                            ([B, H, nst / 32, J, 2, 32] u16, the forward's layout), or NULL */
+} SmmlDeformOpts;
+#endif
+
 #define SMML_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -77,12 +77,9 @@ def relu1_masks(vs, gq, w1, b1, *, B: int, N: int, J: int, groups: int, log_dist
     L = capi.lib()
     nst = L.smml_deform_attn_nst(N)
     out = torch.empty(B * groups, J, 2, nst, device=vs.device, dtype=torch.int16)
-    L.smml_deform_attn_set_log_distance(int(bool(log_distance)))
-    try:
-        capi.check(L.smml_deform_attn_relu1_masks(capi.fptr(_c(vs)), capi.fptr(_c(gq)), capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.ptr(out),
-                                                  B, N, J, groups, vs.shape[-1], capi.stream()), "relu1_masks")
-    finally:
-        L.smml_deform_attn_set_log_distance(1)
+    capi.check(L.smml_deform_attn_relu1_masks(capi.fptr(_c(vs)), capi.fptr(_c(gq)), capi.fptr(_c(w1)), capi.fptr(_c(b1)), capi.ptr(out),
+                                              B, N, J, groups, vs.shape[-1], capi.stream(), capi.deform_opts(log_distance=bool(log_distance))),
+               "relu1_masks")
     return out
 
 
@@ -729,7 +726,7 @@ class GradFork:
     """q feeds two consumers - the offsets network and the fused attention core - and autograd would add their two [B, N, 512] gradients with
     an elementwise kernel (492 MB of traffic per 8-bag step).  The attention's backward always runs first (the offsets network's backward
     needs the d vs it produces): it parks its dq here, the offsets backward ADDS its own contribution into that buffer in place
-    (smml_offsets_bwd_accumulate_dq) and reports no gradient of its own for q.  One object per forward call; None = plain autograd."""
+    (smml_offsets_bwd_f32, accumulate_dq = 1) and reports no gradient of its own for q.  One object per forward call; None = plain autograd."""
     __slots__ = ("dq",)
 
     def __init__(self):
@@ -777,14 +774,10 @@ class _Offsets(torch.autograd.Function):
         L = capi.lib()
         wsb = L.smml_offsets_bwd_workspace_bytes(B, Hh, Ww, groups, dg, ks, r, posdim)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
-        L.smml_offsets_bwd_accumulate_dq(1 if acc else 0)
-        try:
-            capi.check(L.smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
-                                              capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
-                                              capi.fptr(db0), capi.fptr(dw2), capi.fptr(ws), wsb, B, Hh, Ww, groups, dg, ks, r,
-                                              posdim, offset_scale, capi.stream()), "offsets_bwd")
-        finally:
-            L.smml_offsets_bwd_accumulate_dq(0)
+        capi.check(L.smml_offsets_bwd_f32(capi.fptr(q), capi.fptr(w0), capi.fptr(b0), capi.fptr(w2),
+                                          capi.fptr(dvgrid), capi.fptr(dvs), capi.fptr(dq), capi.fptr(dw0),
+                                          capi.fptr(db0), capi.fptr(dw2), capi.fptr(ws), wsb, B, Hh, Ww, groups, dg, ks, r,
+                                          posdim, offset_scale, 1 if acc else 0, capi.stream()), "offsets_bwd")
         # acc: the contribution went into the attention's dq in place - autograd already holds that tensor as q's gradient
         return (None if acc else dq), dw0, db0, dw2, None, None, None, None, None, None
 
@@ -1002,14 +995,12 @@ class _DeformAttn(torch.autograd.Function):
                 nst = L.smml_deform_attn_nst(N)
                 logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32)
                 rid = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.int16)      # the linear piece of every pair
-            _set_seed_offset(L, seed_offset)
             capi.check(L.smml_deform_attn_region_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                                          capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                                          capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.fptr(logits),
                                                          capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
-                                                         *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream()),
-                       "deform_attn_region_fwd")
-            _set_seed_offset(L, None)
+                                                         *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream(),
+                                                         capi.deform_opts(seed_offset)), "deform_attn_region_fwd")
             ctx.seed_offset = seed_offset
             ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
             ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, rid, tables)
@@ -1026,8 +1017,7 @@ class _DeformAttn(torch.autograd.Function):
                 masks = torch.empty(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)   # layer-2 ReLU decisions of the bias MLP
             elif DECISION_TAP is not None:            # tests: the backward writes the decisions it recomputed here
                 ctx.export_masks = torch.zeros(B, heads, nst // 32, J, 2, 32, device=q.device, dtype=torch.int16)
-        _set_seed_offset(L, seed_offset)
-        L.smml_deform_attn_set_log_distance(int(ctx.log_distance))
+        opts = capi.deform_opts(seed_offset, ctx.log_distance)
         if tabfwd:
             if m16 is None:
                 raise ValueError("cpb_table belongs to the 16-bit compute modes: pass compute_dtype='bf16' or 'fp16'")
@@ -1037,23 +1027,21 @@ class _DeformAttn(torch.autograd.Function):
             capi.check(L.smml_deform_attn_table_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table),
                                                     capi.fptr(out), capi.fptr(lse), capi.ptr(logits), B, N, J, heads, groups, posdim, points,
                                                     float(table_pmax_fwd), float(scale), float(dropout_p), int(dropout_seed), m16[0],
-                                                    *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream()), "deform_attn_table_fwd")
+                                                    *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream(), opts), "deform_attn_table_fwd")
         elif m16 is None:
             capi.check(L.smml_deform_attn_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                                   capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                                   capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J,
                                                   heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed),
-                                                  *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream()),
+                                                  *TIMER.events("deform_attn_fwd", B * heads * N * J), capi.stream(), opts),
                        "deform_attn_fwd")
         else:
             capi.check(L.smml_deform_attn16_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
                                                 capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
                                                 capi.fptr(b3), capi.fptr(out), capi.fptr(lse), capi.ptr(logits), capi.ptr(masks), B, N, J,
                                                 heads, groups, posdim, float(scale), float(dropout_p), int(dropout_seed), m16[0],
-                                                *TIMER.events("deform16_fwd", B * heads * N * J), capi.stream()),
+                                                *TIMER.events("deform16_fwd", B * heads * N * J), capi.stream(), opts),
                        "deform_attn16_fwd")
-        _set_seed_offset(L, None)
-        L.smml_deform_attn_set_log_distance(1)
         ctx.seed_offset = seed_offset           # a device int64 [1] owned by this call (hipGraph replays: deform_attention)
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
         ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, masks)
@@ -1080,8 +1068,6 @@ class _DeformAttn(torch.autograd.Function):
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         wsb = L.smml_deform_attn_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
-        _set_seed_offset(L, ctx.seed_offset)
-        L.smml_deform_attn_set_log_distance(int(ctx.log_distance))
         if m16 is None:
             capi.check(L.smml_deform_attn_bwd_f32(
                 capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
@@ -1090,10 +1076,8 @@ class _DeformAttn(torch.autograd.Function):
                 capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
                 capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed,
                 *TIMER.events("cpb_bwd", B * heads * N * J),
-                capi.stream()), "deform_attn_bwd")
+                capi.stream(), capi.deform_opts(ctx.seed_offset, ctx.log_distance)), "deform_attn_bwd")
         else:
-            if ctx.export_masks is not None:
-                L.smml_deform_attn16_export_masks(capi.ptr(ctx.export_masks))
             mtab = None
             if masks is None and TABLE_FORWARD_MASKS == "table":
                 # table-forward call: layer-2 decisions from a mask table (include/smml.h) built from the current weights - one small launch
@@ -1101,7 +1085,6 @@ class _DeformAttn(torch.autograd.Function):
                 mtab = torch.empty(cells ** posdim, device=q.device, dtype=torch.int32)
                 capi.check(L.smml_cpb_mask_table(capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.ptr(mtab), posdim,
                                                  float(ctx.table_pmax), capi.stream()), "cpb_mask_table")
-                L.smml_deform_attn16_set_mask_table(capi.ptr(mtab), float(ctx.table_pmax))
             capi.check(L.smml_deform_attn16_bwd(
                 capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1),
                 capi.fptr(w2), capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
@@ -1109,13 +1092,8 @@ class _DeformAttn(torch.autograd.Function):
                 capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3),
                 capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, scale, dropout_p, dropout_seed, m16[0],
                 *TIMER.events("cpb16_bwd", B * heads * N * J),
-                capi.stream()), "deform_attn16_bwd")
-            if ctx.export_masks is not None:
-                L.smml_deform_attn16_export_masks(None)
-            if mtab is not None:
-                L.smml_deform_attn16_set_mask_table(None, 0.0)
-        _set_seed_offset(L, None)
-        L.smml_deform_attn_set_log_distance(1)
+                capi.stream(), capi.deform_opts(ctx.seed_offset, ctx.log_distance, mtab, float(ctx.table_pmax or 0.0), ctx.export_masks)),
+                "deform_attn16_bwd")
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)          # parked for the offsets network's backward (GradFork); still returned to autograd
         return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None
@@ -1134,15 +1112,13 @@ class _DeformAttn(torch.autograd.Function):
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         wsb = L.smml_deform_attn_region_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty(wsb, device=q.device, dtype=torch.uint8)
-        _set_seed_offset(L, ctx.seed_offset)
         capi.check(L.smml_deform_attn_region_bwd_f32(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1), capi.fptr(w2),
             capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
             capi.fptr(logits), capi.ptr(rid), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
             capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3), capi.ptr(ws), wsb,
-            B, N, J, heads, scale, dropout_p, dropout_seed, *TIMER.events("cpb_region_bwd", B * heads * N * J), capi.stream()),
-            "deform_attn_region_bwd")
-        _set_seed_offset(L, None)
+            B, N, J, heads, scale, dropout_p, dropout_seed, *TIMER.events("cpb_region_bwd", B * heads * N * J), capi.stream(),
+            capi.deform_opts(ctx.seed_offset)), "deform_attn_region_bwd")
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)
         return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None
@@ -1205,12 +1181,11 @@ class _DeformAttnTable(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             nst = L.smml_deform_attn_nst(N)
             logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float16)
-        _set_seed_offset(L, seed_offset)
         capi.check(L.smml_deform_attn_table_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table),
                                                 capi.fptr(out), capi.fptr(lse), capi.ptr(logits), B, N, J, heads, groups, posdim, points,
                                                 float(pmax), float(scale), float(dropout_p), int(dropout_seed), m16[0],
-                                                *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream()), "deform_attn_table_fwd")
-        _set_seed_offset(L, None)
+                                                *TIMER.events("deform_table_fwd", B * heads * N * J), capi.stream(), capi.deform_opts(seed_offset)),
+                   "deform_attn_table_fwd")
         ctx.seed_offset = seed_offset
         ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16, points, float(pmax))
         ctx.save_for_backward(q, k, v, vs, gq, table, out, lse, logits)
@@ -1232,14 +1207,12 @@ class _DeformAttnTable(torch.autograd.Function):
         dq, dk, dv, dvs, dtable = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(vs), torch.empty_like(table)
         wsb = L.smml_deform_attn_table_bwd_workspace_bytes(B, N, J, heads, posdim)
         ws = torch.empty((wsb + 3) // 4, device=q.device, dtype=torch.float32)
-        _set_seed_offset(L, ctx.seed_offset)
         capi.check(L.smml_deform_attn_table_bwd(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(table), capi.fptr(out), capi.fptr(dout),
             capi.fptr(lse), capi.ptr(logits), capi.ptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
             capi.fptr(dtable), capi.fptr(ws), wsb, B, N, J, heads, groups, posdim, points, pmax, ctx.grid[0], ctx.grid[1], scale, dropout_p,
             dropout_seed, m16[0],
-            *TIMER.events("cpb_table_bwd", B * heads * N * J), capi.stream()), "deform_attn_table_bwd")
-        _set_seed_offset(L, None)
+            *TIMER.events("cpb_table_bwd", B * heads * N * J), capi.stream(), capi.deform_opts(ctx.seed_offset)), "deform_attn_table_bwd")
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)
         return dq, dk, dv, dvs, None, dtable, None, None, None, None, None, None, None, None, None, None
@@ -1248,15 +1221,6 @@ class _DeformAttnTable(torch.autograd.Function):
 def table_pmax(gq_bound: float, vs_bound: float) -> float:
     """Half-width of the table in signed-log units for |gq| <= gq_bound, |vs| <= vs_bound (positions beyond it take the edge value)."""
     return float(__import__("math").log1p(gq_bound + vs_bound) * 1.0001)
-
-
-def _set_seed_offset(L, t):
-    if t is None:
-        L.smml_deform_attn_set_seed_offset(None)
-    else:
-        if t.dtype != torch.int64 or t.numel() != 1:
-            raise RuntimeError("dropout_seed_offset must be a device int64 tensor with one element")
-        L.smml_deform_attn_set_seed_offset(capi.ptr(t))
 
 
 _REPLAY_COUNTER = {}         # device index -> int64 [1]: bumped once per dropout call inside a captured graph
@@ -1318,7 +1282,10 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
     region_pmax = None
     if (use_regions and compute_dtype is None and log_distance and vs.shape[-1] == 2 and heads == groups and k.shape[1] <= REGION_MAX_KEYS
             and tuple(w3.shape) == (1, 32)):
-        region_pmax = cpb_region_pmax if cpb_region_pmax is not None else table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))
+        if cpb_region_pmax is not None:
+            region_pmax = cpb_region_pmax
+        elif not torch.cuda.is_current_stream_capturing():         # from the data: a host sync, impossible inside a hipGraph capture - such a
+            region_pmax = table_pmax(float(gq.detach().abs().max()), float(vs.detach().abs().max()))   # call keeps the per-pair kernels
     return _DeformAttn.apply(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, heads, groups, scale, dropout_p, dropout_seed,
                              dropout_seed_offset, compute_dtype, fork, None, log_distance, region_pmax, cpb_region_prefetch)
 
@@ -1327,12 +1294,8 @@ def deform_attention_dropout_mask(B: int, N: int, J: int, H: int, dropout_p: flo
     """The keep mask (0 / 1) [B, H, N, J] a launch with this (p, seed[, device-resident replay offset]) applies; tests only."""
     mask = torch.empty(B, H, N, J, device=device, dtype=torch.float32)
     L = capi.lib()
-    _set_seed_offset(L, seed_offset)
-    try:
-        capi.check(L.smml_deform_attn_dropout_mask_f32(capi.fptr(mask), B, N, J, H, float(dropout_p), int(dropout_seed),
-                                                       capi.stream()), "dropout_mask")
-    finally:
-        _set_seed_offset(L, None)
+    capi.check(L.smml_deform_attn_dropout_mask_f32(capi.fptr(mask), B, N, J, H, float(dropout_p), int(dropout_seed),
+                                                   capi.stream(), capi.deform_opts(seed_offset)), "dropout_mask")
     return mask
 
 

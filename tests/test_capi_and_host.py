@@ -28,7 +28,11 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(handle, s), f"{s} declared in include/smml.h but not exported"
     assert sorted(smml.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert smml.lib().smml_abi_version() == 1
+    assert smml.lib().smml_abi_version() == 2 == smml._capi.ABI_VERSION
+    # no per-thread launch state: the only thread_local of the library is the error text
+    import glob
+    tl = [l.strip() for f in glob.glob(os.path.join(ROOT, "subspace-multimodal-learning_amd", "csrc", "*.h*")) for l in open(f) if re.search(r"\bthread_local\b", l) and not l.strip().startswith("//")]
+    assert len(tl) == 1 and "g_err" in tl[0], tl
 
 
 def test_argument_counts_match_header():

@@ -150,7 +150,7 @@ def test_wrap_pad_to_square(cuda):
 
 def test_dropout_mask_changes_between_graph_replays(cuda):
     """A training-mode DeformCrossAttention2D captured in a hipGraph: the host seed is baked into the captured launches, the
-    device-resident offset (include/smml.h: smml_deform_attn_set_seed_offset; functional.graph_seed_offset) makes every replay draw
+    device-resident offset (include/smml.h: SmmlDeformOpts.seed_offset; functional.graph_seed_offset) makes every replay draw
     a new dropout mask, and forward / backward of one call agree on it (the gradient of a replay matches an eager call that is
     given the replay's effective seed)."""
     import torch

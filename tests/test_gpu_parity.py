@@ -658,7 +658,7 @@ def test_saved_relu_masks_match_reference(cuda):
     masks = torch.zeros(B, H, nst // 32, J, 2, 32, device=cuda, dtype=torch.int16)
     capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
                                           capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
-                                          0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")
+                                          0.125, 0.0, 0, None, None, capi.stream(), None), "deform_attn_fwd")
     torch.cuda.synchronize()
     r = {n: x.to(cuda, torch.float64) for n, x in t.items()}
     pos = r["gq"][None, :, None, :] - r["vs"].view(B * G, 1, J, PD)
@@ -701,7 +701,7 @@ def test_saved_relu_masks_statistics_at_scale(cuda):
     masks = torch.zeros(B, H, nst // 32, J, 2, 32, device=cuda, dtype=torch.int16)
     capi.check(L.smml_deform_attn_fwd_f32(*(capi.fptr(d[n]) for n in ("q", "k", "v", "vs", "gq", "w1", "b1", "w2", "b2", "w3", "b3")),
                                           capi.fptr(out), capi.fptr(lse), capi.fptr(logits), capi.ptr(masks), B, N, J, H, G, PD,
-                                          0.125, 0.0, 0, None, None, capi.stream()), "deform_attn_fwd")
+                                          0.125, 0.0, 0, None, None, capi.stream(), None), "deform_attn_fwd")
     torch.cuda.synchronize()
 
     def pre(dt):
