@@ -42,7 +42,8 @@ CPB16_BWD_MFMAS = 10                # cpb16_bwd_kernel (16-bit compute mode): 1 
 CPB16_FWD_MFMAS = 3                 # deform16_fwd_kernel: 1 (layer 1) + 2 (layer 2, one term) + 8/32 for QK^T / PV
 CPB_FWD_FLOP_PER_PAIR = 2 * 2 * 32 + 2 * 32 * 32 + 2 * 32     # 2 -> 32 -> 32 -> 1 MLP = 2240
 ATTN_FLOP_PER_PAIR = 2 * (2 * 64)                               # QK^T + AV per (query, key) pair and head
-TRAFFIC_FILE = "r03_hbm_traffic.json"
+TRAFFIC_FILE = "r05_hbm_traffic.json"
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s peak (~6.3 TB/s achievable)
 
 
 def measured_traffic(kernel, bags):
@@ -174,7 +175,36 @@ def cpu_baseline(pkg, in_dim, S, seconds_budget=90.0):
                       f"after 1 warm-up, {dt:.2f} s/bag, torch.set_num_threads({cores})"}
 
 
-def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
+def timed_steps(step, steps, warmup):
+    """Runs `step` warmup + steps times on the current stream.  Returns what a reader needs to tell a GPU-bound leg from a host-bound
+    one: wall time per step between two synchronisations, the time the HOST needed to enqueue a step (the loop without the final
+    synchronisation), and the GPU time of every single step from HIP events recorded on the launch stream (min / median / max)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "step_ms_events": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
+            "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
+            "host_gap_ms": max(0.0, 1e3 * dt / steps - per[len(per) // 2]),
+            "host_bound": bool(t_enq > 0.9 * dt)}, dt
+
+
+def kernel_event_sum(kt, steps):
+    """ms per step spent in the kernels the package brackets with HIP events (the fused attention family)."""
+    return sum(n * ms for n, ms, _ in kt.values()) / max(steps, 1)
+
+
+def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=10):
     """NystromAttention(dim 512, 8 heads x 64, 256 landmarks) forward + backward on B bags of n x 512 in `dtype` (BASELINE config
     2 shape and the N = 10 000 bag; a bf16 / fp16 bag selects the block's 16-bit compute mode): ms per step from HIP events on
     the launch stream, algorithmic flops per SURVEY.md 8(d)."""
@@ -186,21 +216,15 @@ def nystrom_leg(pkg, dev, B, n, dtype=torch.bfloat16, steps=10, warmup=3):
         mod.zero_grad(set_to_none=True); x.grad = None
         mod(x).pow(2).mean().backward()
 
-    for _ in range(warmup):
-        step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(steps):
-        step()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
+    timing, _ = timed_steps(step, steps, warmup)
+    ms = timing["step_ms_events"]["median"]
     total, qkav = nystrom_flop(n)
     tf = 3 * total * B / (ms * 1e-3) / 1e12
     pipe = mod.matrix_pipe(dtype)                                    # which matrix pipe the contractions issue on
     peak = F16_MFMA_PEAK_TFLOPS if pipe != "f32" else F32_MFMA_PEAK_TFLOPS
     return {"workload": f"NystromAttention fwd+bwd, {B} x {n} x 512 {str(dtype).replace('torch.', '')}, 256 landmarks", "ms_per_step": ms, "bags_per_s": B / (ms * 1e-3),
             "algorithmic_TFLOPs": tf, "pipe": pipe, "peak_TFLOPs": peak, "frac": tf / peak,
-            "qkav_share_of_flops": qkav / total}
+            "qkav_share_of_flops": qkav / total, "timing": timing}
 
 
 def make_adam(params, capturable=False):
@@ -227,7 +251,7 @@ def nystrom_legs(pkg, dev):
     return legs
 
 
-def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_table=False):
+def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=10, cpb_table=False):
     """The headline training step (same model, parameters, bags, losses, Adam) with the fused attention core in its 16-bit compute
     mode (csrc/deform_attn16.hip; BASELINE config 4 names bf16): ms per step by wall clock between synchronisations, the two dominant
     kernels by HIP events on their launch stream, algorithmic flops as for the fp32-grade line.  Not part of `value`."""
@@ -251,20 +275,25 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_t
         opt.step()
         return loss
 
+    last = {}
+
+    def one():
+        last["loss"] = step()
+
     for _ in range(warmup):
-        step()
+        one()
     torch.cuda.synchronize()
     Fh.TIMER.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    timing, dt = timed_steps(one, steps, 0)
     Fh.TIMER.enabled = False
     kt = Fh.TIMER.collect()
+    loss = last["loss"]
+    timing["warmup"] = warmup
+    timing["package_kernel_events_ms_per_step"] = kernel_event_sum(kt, steps)
     out = {"workload": f"the headline step with DeformCrossAttention2D(compute_dtype='{dtype}'): {B} bags of {N} x {in_dim} per step, "
                        f"fwd + bwd + Adam, CE + BatchLoss; parameters, inputs, outputs and gradients fp32 in memory",
-           "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
+           "dtype": dtype, "steps": steps, "ms_per_step": 1e3 * dt / steps, "bags_per_s": B * steps / dt, "loss_finite": bool(torch.isfinite(loss).item()),
+           "timing": timing}
     if cpb_table == "forward":
         out["workload"] += ("; the FORWARD takes the position bias from a table of the MLP (cpb_table='forward': evaluated once per call on a 96 x 96 grid, "
                             "interpolated per pair, |error| <= ~1e-3 of the bias range); the backward differentiates the per-pair MLP itself (layer-2 decisions from a 1024 x 1024 mask table): "
@@ -293,8 +322,75 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=3, cpb_t
         out["roofline_fwd"] = {"kernel": "deform16_fwd_kernel<2, true>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12,
                                "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                "avg_ms": ms, "launches": n, "flop_per_launch": flop, "mfmas_per_key_and_32_queries": CPB16_FWD_MFMAS}
-    del mil, opt
+    del mil, opt, bloss, path, omic, label
+    torch.cuda.empty_cache()
     return out
+
+
+def dp_overhead_child(pkg, dev, B, S, in_dim, steps, warmup):
+    """Child-process body of the `data_parallel_at_world_1` leg: the headline step plain and wrapped in BagDataParallel over a ONE-rank
+    RCCL group (every bucket all-reduced with ReduceOp.AVG from the gradient hooks while backward runs; the average over one rank is
+    the identity), A/B in one process on one box.  Prints one JSON object."""
+    import datetime
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=90))
+    N = S * S
+    res = {}
+    for name in ("plain", "wrapped", "plain_again"):
+        torch.manual_seed(42)
+        mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
+        mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
+        mil = mil.to(dev).train()
+        model = pkg.BagDataParallel(mil, collectives_at_world_1=True) if name == "wrapped" else mil
+        opt = make_adam(mil.parameters())
+        bloss = pkg.BatchLoss(B, 1)
+        path = pkg.synth.bag(B, N, in_dim, 42, "bench:bag").to(dev)
+        omic = torch.relu(pkg.synth.normal((B, 128), 42, "bench:omicvec")).to(dev)
+        label = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(0)).to(dev)
+
+        def step():
+            enc, logits, _, omic_t, vgrid = model(path, omic)
+            loss = torch.nn.functional.cross_entropy(logits, label) + torch.sum(bloss(omic_t, vgrid))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+
+        timing, _ = timed_steps(step, steps, warmup)
+        res[name] = timing
+        if name == "wrapped":
+            res["reducer"] = {k: model.stats.get(k) for k in ("buckets", "launched_in_backward", "skipped", "hook_host_ms")} | model.timing()
+        del step, model, mil, opt, bloss, path, omic, label
+        torch.cuda.empty_cache()
+    dist.destroy_process_group()
+    # medians of the per-step event times: one slow step (a watchdog tick, the first collective) would otherwise decide a 10-step mean
+    med = lambda k: res[k]["step_ms_events"]["median"]
+    res["overhead_vs_plain"] = med("wrapped") / (0.5 * (med("plain") + med("plain_again"))) - 1.0
+    res["overhead_vs_plain_wall"] = res["wrapped"]["ms_per_step"] / (0.5 * (res["plain"]["ms_per_step"] + res["plain_again"]["ms_per_step"])) - 1.0
+    print(json.dumps(res))
+
+
+def dp_overhead_leg(pkg, dev, B, S, in_dim, headline_ms, timeout=240):
+    """Runs dp_overhead_child in a child process (subprocess, nothing exec'd from this GPU-initialised process): an RCCL
+    initialisation that hangs can then cost this leg, not the line."""
+    import signal, subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-child", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim), "--steps", "10", "--warmup", "10"]
+    child = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True, text=True)
+    try:
+        so, _ = child.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return {"error": f"CHILD_TIMEOUT: the one-rank RCCL child exceeded {timeout} s and its process group was killed"}
+    if child.returncode != 0:
+        return {"error": f"child exited with code {child.returncode}"}
+    res = json.loads(so.strip().splitlines()[-1])
+    res["what"] = ("the headline step wrapped in BagDataParallel over a one-rank RCCL group (collectives_at_world_1): every bucket all-reduced with ReduceOp.AVG from "
+                   "the gradient hooks while backward runs; `overhead_vs_plain` = median step of wrapped / mean(median step of plain before, after) - 1 (HIP events per step), all three in one child process; `_wall` = the same from the 10-step wall means")
+    return res
 
 
 def main():
@@ -310,13 +406,19 @@ def main():
                     "bias (approximate mode; `--deform-table forward`: table in the forward only, exact backward; the default run reports both in the extra keys `deform16_table` / `deform16_tabfwd`)")
     ap.add_argument("--no-deform16", action="store_true", help="skip the 16-bit-compute-mode leg of the headline step (extra key `deform16`, not part of `value`)")
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
+    ap.add_argument("--no-dp-overhead", action="store_true", help="skip the leg that wraps the headline step in a one-rank RCCL group (extra key `data_parallel_at_world_1`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
     ap.add_argument("--deform-dtype", default=None, choices=[None, "bf16", "fp16"],
                     help="measurement switch: run the HEADLINE step itself with the fused attention core in its 16-bit compute mode (the "
                          "default line stays fp32-grade; the default run reports the 16-bit step in the extra key `deform16`)")
     ap.add_argument("--graph", action="store_true", help="one GPU only: capture the step in a hipGraph and time replays (the per-kernel "
                     "HIP-event times of `roofline` then come from the eager warm-up steps)")
+    ap.add_argument("--dp-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.dp_child:
+        torch.cuda.set_device(0)
+        dp_overhead_child(importlib.import_module(PKG), torch.device("cuda", 0), a.bags, a.grid, a.in_dim, a.steps, a.warmup)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -420,7 +522,9 @@ def main():
         # wrapper's counters of the LAST step (buckets launched while backward was still running, buckets skipped as grad-less,
         # host time spent inside the gradient hooks)
         st = dict(getattr(model, "stats", {}))
-        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "device_index": local, "buckets": st.get("buckets"),
+        st.update(model.timing() if hasattr(model, "timing") else {})
+        mine = {"rank": rank, "exposed_wait_ms": st.get("exposed_wait_ms"), "allreduce_span_ms": st.get("allreduce_span_ms"),
+                "hidden_share": st.get("hidden_share"), "device": torch.cuda.get_device_name(dev), "device_index": local, "buckets": st.get("buckets"),
                 "launched_in_backward": st.get("launched_in_backward"), "skipped": st.get("skipped"),
                 "hook_host_ms_per_step": st.get("hook_host_ms")}
         gathered = [None] * world
@@ -439,68 +543,94 @@ def main():
                        "parallelism": f"dp{world} (whole bags per rank, RCCL gradient all-reduce)" + (", step replayed from one hipGraph" if use_graph else "")},
         }
         out["kernel_events"] = {k: {"launches": v[0], "avg_ms": v[1], "pairs_per_launch": v[2]} for k, v in kt.items()}   # HIP events on the launch stream
-        if "cpb_bwd" in kt:
+        H = 8
+        regions = "deform_region_fwd" in kt            # the position bias per linear region of its MLP (csrc/cpb_regions.h): the default fp32-grade path
+        if regions:
+            # Dominant kernel: the fused forward.  With the per-pair MLP gone it is a memory kernel: per (query, key) pair and head it writes
+            # the pre-softmax score (4 B, saved for the backward, the dropout decision in its lowest bit) and the pair's region id (2 B);
+            # per (bag, head): q read + out written (2 x 256 B per query, + 4 B lse), k + v + sample positions read (520 B per key).
+            n, ms, pairs = kt["deform_region_fwd"]
+            abytes = pairs * 6 + B * H * N * (512 + 4) + B * H * J * (512 + 8)
+            ach = abytes / (ms * 1e-3) / 1e9
+            flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
+            out["roofline"] = {"kernel": "deform_region_fwd_kernel<true>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected (--no-traffic, or N > 1)",
+                               "launches": n, "avg_ms": ms, "algorithmic_bytes_per_launch": abytes,
+                               "reference_flops_view": {"flop_per_launch": flop, "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12,
+                                                        "frac_of_16bit_mfma_peak": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                                                        "note": "the reference's op count (2496 flop per pair: bias MLP 2240 + QK^T / PV 256) over this kernel's time - "
+                                                                "the kernel no longer executes the MLP's flops (one table lookup + 2 FMAs per pair)"},
+                               "note": "achieved = algorithmic bytes (6 B per pair: saved score + region id; q / k / v / out once) / HIP-event time of the kernel, "
+                                       "against the HBM peak of MI355X_MICROARCH.md (8 TB/s; ~6.3 TB/s achievable).  What bounds it today is the latency of the "
+                                       "dependent table gathers at two waves per SIMD (WAIT_ANY 0.6-0.7 of wave cycles, profiles/r05_pmc_notes.md), not HBM."}
+            if "cpb_region_bwd" in kt:
+                n2, ms2, pairs2 = kt["cpb_region_bwd"]
+                b2 = pairs2 * 6 + B * H * J * 8 * 2
+                out["roofline_bwd"] = {"kernel": "cpb_region_bwd_kernel", "bound": "hbm", "achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": n2, "avg_ms": ms2, "algorithmic_bytes_per_launch": b2,
+                                       "note": "position-bias backward per linear region: reads d score (4 B) + region id (2 B) per pair, three 64-bit integer LDS adds per "
+                                               "run of pairs in one region; bound by LDS atomics and vector issue, not by HBM"}
+        elif "cpb_bwd" in kt:
             n, ms, pairs = kt["cpb_bwd"]
             flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops (4480 per pair), recompute not counted
             ach = flop / (ms * 1e-3) / 1e12
             issued = (pairs / 32.0) * CPB_BWD_MFMAS * 32768 / (ms * 1e-3) / 1e12   # what the kernel executes: 12 MFMAs of 2 * 16384 flop
-            kname = "cpb_bwd_kernel<2>"
-            # dominant kernel.  Every contraction issues on the 16-bit matrix pipe (split fp16 / bf16 products, fp32-grade
-            # results), so the algorithmic flops are priced against THAT pipe's dense peak; what actually bounds the kernel is
-            # vector issue (VALU + MFMA issue add up on a gfx950 SIMD): ~265 vector instructions per 12 MFMAs.
-            traffic, tsrc = None, "not collected (--no-traffic, or N > 1)"
-            if world == 1 and not a.no_deform16 and not a.deform_dtype:
-                # BASELINE config 4 as stated (bf16 compute): the same step with the fused core in its 16-bit mode, driver-run
-                try:                                  # an extra leg must never cost the headline line
-                    out["deform16"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3)
-                    out["deform16"]["speedup_vs_fp32_line"] = out["deform16"]["bags_per_s"] / out["value"]
-                except Exception as e:
-                    out["deform16"] = {"error": f"{type(e).__name__}: {e}"}
-                try:        # the 16-bit step with the forward's bias from the table, exact per-pair backward (parity-grade; extra key)
-                    out["deform16_tabfwd"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3, cpb_table="forward")
-                    out["deform16_tabfwd"]["speedup_vs_fp32_line"] = out["deform16_tabfwd"]["bags_per_s"] / out["value"]
-                except Exception as e:
-                    out["deform16_tabfwd"] = {"error": f"{type(e).__name__}: {e}"}
-                try:        # the same step with the tabulated position bias (approximate mode; extra key, never part of `value`)
-                    out["deform16_table"] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), warmup=3, cpb_table=True)
-                    out["deform16_table"]["speedup_vs_fp32_line"] = out["deform16_table"]["bags_per_s"] / out["value"]
-                except Exception as e:
-                    out["deform16_table"] = {"error": f"{type(e).__name__}: {e}"}
-            if world == 1 and not a.no_nystrom:
-                # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
-                # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
-                out["nystrom"] = nystrom_legs(pkg, dev)
-            if world == 1 and not a.no_traffic:
-                traffic, tsrc = live_traffic("cpb_bwd_kernel", ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom",
-                                                                "--no-traffic", "--no-deform16", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
-            if tsrc.startswith(("CHILD_TIMEOUT", "CHILD_SIGNAL")):
-                out["pmc_child_failed"] = tsrc           # a hung / crashed profiler child is surfaced, not folded into a fallback
-            if traffic is None and world == 1 and not a.no_traffic and (S, in_dim) == (100, 512):
-                traffic = measured_traffic(kname, B)
-                tsrc = f"replayed from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, committed); live collection: {tsrc}"
-            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
-                               "traffic": traffic, "traffic_source": tsrc,
+            out["roofline"] = {"kernel": "cpb_bwd_kernel<2>", "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": "not collected",
                                "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                               "issued_16bit": {"achieved": issued, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                "frac": issued / F16_MFMA_PEAK_TFLOPS},
-                               "note": "achieved = algorithmic flops (4480 per (query, key) pair and head, SURVEY 8(d), recompute not counted) / "
-                                       "HIP-event time of the kernel, against the dense 16-bit MFMA peak (the pipe its 12 MFMAs per (key, 32 "
-                                       "queries) issue on); issued_16bit prices the MFMAs actually executed.  The kernel is vector-issue "
-                                       "bound: ~265 VALU instructions per 12 MFMAs, two waves per SIMD."}
-        if "deform_attn_fwd" in kt:
-            n, ms, pairs = kt["deform_attn_fwd"]
-            flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
-            ach = flop / (ms * 1e-3) / 1e12
-            out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2, true>", "bound": "mfma", "achieved": ach,
-                                   "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TFLOPS,
-                                   "launches": n, "avg_ms": ms, "flop_per_launch": flop,
-                                   "note": f"2496 algorithmic flop per pair (position-bias MLP 2240 + QK^T / PV 256) against the dense 16-bit "
-                                           f"MFMA peak; {CPB_FWD_MFMAS} + 24/32 16-bit MFMAs + ~170 vector instructions per (key, 32 queries)"}
-        if world == 1 and not a.no_nystrom and "nystrom" not in out:
-            out["nystrom"] = nystrom_legs(pkg, dev)
+                               "issued_16bit": {"achieved": issued, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / F16_MFMA_PEAK_TFLOPS},
+                               "note": "per-pair MLP kernels (SMML_CPB_REGIONS=0 or a 16-bit mode): algorithmic flops (4480 per pair and head, SURVEY 8(d)) / HIP-event "
+                                       "time, against the dense 16-bit MFMA peak; the kernel is vector-issue bound (~265 VALU per 12 MFMAs)"}
+            if "deform_attn_fwd" in kt:
+                n, ms, pairs = kt["deform_attn_fwd"]
+                flop = pairs * (CPB_FWD_FLOP_PER_PAIR + ATTN_FLOP_PER_PAIR)
+                out["roofline_fwd"] = {"kernel": "deform_attn_fwd_kernel<2, true>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12,
+                                       "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                                       "launches": n, "avg_ms": ms, "flop_per_launch": flop}
         if world > 1:
             out["data_parallel"] = dp_info               # what the collective backend saw + per-rank overlap counters: a SCALE run checks itself
+        # the headline is measured: persist it before anything else can go wrong (an extra leg must never cost the line)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_headline.json"), "w") as f:
+                f.write(json.dumps(out) + "\n")
+        except OSError:
+            pass
+        print("HEADLINE " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step")}), file=sys.stderr, flush=True)
+        # everything below runs on a GPU the headline model no longer occupies
+        del step, model, mil, opt, bloss, path, omic, label
+        if use_graph:
+            del graph
+        torch.cuda.empty_cache()
+        if world == 1 and not a.no_dp_overhead and not a.deform_dtype:
+            try:
+                out["data_parallel_at_world_1"] = dp_overhead_leg(pkg, dev, B, S, in_dim, out["ms_per_step"])
+            except Exception as e:
+                out["data_parallel_at_world_1"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not a.no_deform16 and not a.deform_dtype:
+            # BASELINE config 4 as stated (bf16 compute) and its table variants: the same step with the fused core in its 16-bit mode
+            for key, kw in (("deform16", {}), ("deform16_tabfwd", {"cpb_table": "forward"}), ("deform16_table", {"cpb_table": True})):
+                try:
+                    out[key] = deform16_leg(pkg, dev, B, S, in_dim, "bf16", steps=max(5, min(a.steps, 20)), **kw)
+                    out[key]["speedup_vs_fp32_line"] = out[key]["bags_per_s"] / out["value"]
+                except Exception as e:
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not a.no_nystrom:
+            # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
+            # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
+            out["nystrom"] = nystrom_legs(pkg, dev)
+        if world == 1 and "roofline" in out:
+            kname = "deform_region_fwd_kernel" if regions else "cpb_bwd_kernel"
+            traffic, tsrc = None, "not collected (--no-traffic)"
+            if not a.no_traffic:
+                traffic, tsrc = live_traffic(kname, ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-nystrom", "--no-traffic", "--no-deform16",
+                                                     "--no-dp-overhead", "--bags", str(B), "--grid", str(S), "--in-dim", str(in_dim)])
+                if tsrc.startswith(("CHILD_TIMEOUT", "CHILD_SIGNAL")):
+                    out["pmc_child_failed"] = tsrc           # a hung / crashed profiler child is surfaced, not folded into a fallback
+                if traffic is None and (S, in_dim) == (100, 512):
+                    traffic = measured_traffic(kname, B)
+                    tsrc = f"replayed from profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, committed); live collection: {tsrc}"
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic, tsrc
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, in_dim, S)

@@ -96,6 +96,18 @@ class BagDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def timing(self):
+        """Event times of the LAST backward (synchronises): `exposed_wait_ms` = GPU time between the end of the backward kernels and the
+        completion of the last all-reduce on the compute stream (what the overlap did NOT hide), `allreduce_span_ms` = first bucket
+        launch -> last completion (the collectives' wall span, most of it under the backward), and their quotient."""
+        ev = getattr(self, "_ev", None)
+        if not ev or "reduced" not in ev or ev.get("first_launch") is None:
+            return {}
+        torch.cuda.synchronize()
+        span = ev["first_launch"].elapsed_time(ev["reduced"])
+        exposed = ev["backward_end"].elapsed_time(ev["reduced"])
+        return {"exposed_wait_ms": exposed, "allreduce_span_ms": span, "hidden_share": (1.0 - exposed / span) if span > 0 else None}
+
     def reset_unused(self):
         """Forget which parameters are grad-less (after the model's control flow changed); the next step re-learns the set."""
         self._known = False
@@ -109,6 +121,7 @@ class BagDataParallel(nn.Module):
             self._armed = True
             self._hook_s = 0.0
             self._next = 0
+            self._ev = {"first_launch": None}         # HIP events of this backward on the compute stream (timing())
             self.stats["launched_in_backward"] = 0
             for b in self._buckets:
                 b.ready = [False] * len(b.params)
@@ -179,11 +192,18 @@ class BagDataParallel(nn.Module):
         op, scale = self._reduce_op(b.flat)
         if scale is not None:
             b.flat.mul_(scale)
+        if b.flat.is_cuda and self._ev.get("first_launch") is None:
+            self._ev["first_launch"] = torch.cuda.Event(enable_timing=True)
+            self._ev["first_launch"].record()
         b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
     def _finalize(self):
         # runs at the end of backward(): flush buckets that could not complete in the hooks (first step: grad-less parameters
         # are not known yet), wait, and hand every parameter the bucket's view as its .grad (no copy back, no arithmetic)
+        on_gpu = self._buckets[0].params[0].is_cuda
+        if on_gpu:                                    # the compute stream has every backward kernel queued: what follows it is exposed
+            self._ev["backward_end"] = torch.cuda.Event(enable_timing=True)
+            self._ev["backward_end"].record()
         for b in self._buckets:
             if b.work is None and not b.skip:
                 self._launch(b)
@@ -193,6 +213,9 @@ class BagDataParallel(nn.Module):
             for p, v, r in zip(b.params, b.views or [], b.ready):
                 if r and p.grad is not None:
                     p.grad = v
+        if on_gpu:                                    # the compute stream now waits for the last collective
+            self._ev["reduced"] = torch.cuda.Event(enable_timing=True)
+            self._ev["reduced"].record()
         if not self._known:
             used = [bool(r and p.grad is not None) for b in self._buckets for p, r in zip(b.params, b.ready)]
             if self.world > 1 or self._reduce_at_1:
