@@ -337,12 +337,14 @@ def dp_overhead_child(pkg, dev, B, S, in_dim, steps, warmup):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=90))
     N = S * S
     res = {}
-    for name in ("plain", "wrapped", "plain_again"):
+    for name in ("plain", "wrapped", "wrapped_2MiB_buckets", "plain_again"):
         torch.manual_seed(42)
         mil = pkg.DeformCrossTransMIL(mil_args(in_dim))
         mil.load_state_dict(pkg.synth.fill_params({k: tuple(v.shape) for k, v in mil.state_dict().items()}, 42, "bench"))
         mil = mil.to(dev).train()
-        model = pkg.BagDataParallel(mil, collectives_at_world_1=True) if name == "wrapped" else mil
+        model = mil
+        if name.startswith("wrapped"):
+            model = pkg.BagDataParallel(mil, collectives_at_world_1=True, **({"bucket_bytes": 2 << 20} if "2MiB" in name else {}))
         opt = make_adam(mil.parameters())
         bloss = pkg.BatchLoss(B, 1)
         path = pkg.synth.bag(B, N, in_dim, 42, "bench:bag").to(dev)
@@ -358,14 +360,15 @@ def dp_overhead_child(pkg, dev, B, S, in_dim, steps, warmup):
 
         timing, _ = timed_steps(step, steps, warmup)
         res[name] = timing
-        if name == "wrapped":
-            res["reducer"] = {k: model.stats.get(k) for k in ("buckets", "launched_in_backward", "skipped", "hook_host_ms")} | model.timing()
+        if name.startswith("wrapped"):
+            res["reducer" + name[len("wrapped"):]] = {k: model.stats.get(k) for k in ("buckets", "launched_in_backward", "skipped", "hook_host_ms")} | model.timing()
         del step, model, mil, opt, bloss, path, omic, label
         torch.cuda.empty_cache()
     dist.destroy_process_group()
     # medians of the per-step event times: one slow step (a watchdog tick, the first collective) would otherwise decide a 10-step mean
     med = lambda k: res[k]["step_ms_events"]["median"]
     res["overhead_vs_plain"] = med("wrapped") / (0.5 * (med("plain") + med("plain_again"))) - 1.0
+    res["overhead_vs_plain_2MiB_buckets"] = med("wrapped_2MiB_buckets") / (0.5 * (med("plain") + med("plain_again"))) - 1.0
     res["overhead_vs_plain_wall"] = res["wrapped"]["ms_per_step"] / (0.5 * (res["plain"]["ms_per_step"] + res["plain_again"]["ms_per_step"])) - 1.0
     print(json.dumps(res))
 

@@ -9,11 +9,10 @@ Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exa
     oracle against an fp64 evaluation of the same quantity = its `noise`) gets max(1e-4, NOISE_FACTOR x noise) with
     NOISE_FACTOR = 2, never more than NOISE_CAP - except where the reference's own noise already exceeds the cap / 2
     (then 2 x noise, flagged `ill` in the report: the fixture itself cannot be reproduced closer by any fp32 program);
-  * the full-size model test (config 4, 100 x 100) also runs the oracle in fp32 on the GPU's ATen kernels: that second noise figure is
-    RECORDED beside every tensor (round 3 used the larger of the two as the yardstick; since round 4 the bound is the host figure again).
-    Five gradients of the tumor branch's query path are NAMED exceptions with an explicit 2.5e-4 bound: their fp32 evaluations scatter
-    between realisations (HIP / host-fp32 error ratio 0.9 ... 4.3 over four seeds, profiles/r04_fp32_scatter.txt) and the test's seed
-    happens to be the draw where the host run is most accurate; no precision variant of the kernels moves them (same file);
+  * the full-size model test (config 4, 100 x 100: gradients that are sums over 10 000 queries, whose fp32 evaluations scatter by 5 x
+    between realisations, profiles/r04_fp32_scatter.txt) judges every tensor on the MEDIAN over four realisations:
+    median(HIP error) <= max(1e-4, 1.5 x median(error of the oracle in fp32 on this GPU's ATen kernels)), no realisation beyond 1e-3;
+    no tensor is named, no bound is set by hand (tests/test_gpu_configs.py; round 4 had five named 2.5e-4 bounds);
   * where an fp64 truth is available the HIP result is ALSO held to the reference's own accuracy in the l2 norm:
     l2(hip - fp64) <= max(1e-4, L2_FACTOR x l2(fp32 - fp64)) with L2_FACTOR = 1.5 - the kernels may not be noisier than
     1.5 x torch's fp32 evaluation (VERDICT r01 item 1);
@@ -23,8 +22,9 @@ Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exa
     2e-2 sanity bound whenever a sample position sat within 2e-5 of a pixel boundary).  The module is piecewise linear in the two
     ReLU layers of the position-bias MLP and in the cell a bilinear sample falls into; where a pre-activation / pixel coordinate is
     within fp32 rounding of the kink two fp32 programs may decide differently and the gradient jumps.  The tests now export the
-    decisions the kernels took (functional.DECISION_TAP: the sampler's cells from smml_bilinear_corners_f32, layer-1 masks from
-    smml_deform_attn_relu1_masks, the saved layer-2 masks) and impose them on the fp32 AND fp64 oracle runs (oracle.deform.DECISIONS,
+    decisions the kernels took (functional.DECISION_TAP: the sampler's cells from smml_bilinear_corners_f32; the ReLU decisions of the
+    position bias = the patterns of each pair's linear region (region kernels) or layer-1 masks from smml_deform_attn_relu1_masks + the
+    saved layer-2 masks (per-pair MLP kernels)) and impose them on the fp32 AND fp64 oracle runs (oracle.deform.DECISIONS,
     `Decisions` below): forward values move by at most the rounding-level pre-activation, gradients are compared on the same
     branch, under the plain rules above.  That the exported decisions themselves are right is tested separately
     (test_saved_relu_masks_match_reference, ..._statistics_at_scale, test_exported_decisions_match_fp64: they may differ from an
@@ -81,13 +81,11 @@ def assert_close(name, got, ref, tol=TOL):
     assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
 
 
-def assert_calibrated(name, got, ref32, ref64, floor=TOL, ref32_alt=None, scatter_bound=None):
+def assert_calibrated(name, got, ref32, ref64, floor=TOL, ref32_alt=None):
     """HIP result against the fp64 oracle: max-norm within max(floor, 2 x noise) (capped, see module docstring) and l2-norm
     within max(floor, 1.5 x the fp32 oracle's own l2 distance to fp64); noise = the distance of the fp32 oracle ON THE HOST to fp64.
     `ref32_alt`: a second fp32 evaluation of the oracle on another back end (the GPU's ATen kernels) - RECORDED in the parity report
-    (kind `alt fp32 noise`) and not part of any bound (round 3 took the larger of the two as the noise).
-    `scatter_bound`: an explicit bound for a NAMED tensor whose fp32 evaluations scatter between realisations by more than the one
-    host run shows (tests/test_gpu_configs.py CFG4_FP32_SCATTER, profiles/r04_fp32_scatter.txt)."""
+    (kind `alt fp32 noise`) and not part of any bound (round 3 took the larger of the two as the noise)."""
     if float(ref64.detach().abs().max()) < 1e-12:        # identically zero in exact arithmetic (e.g. one sampled key: d scores = 0)
         gm = float(got.detach().abs().max())
         record(name, gm, None, 1e-3, "zero")
@@ -97,13 +95,11 @@ def assert_calibrated(name, got, ref32, ref64, floor=TOL, ref32_alt=None, scatte
     if ref32_alt is not None:
         record(name, rel_err(ref32_alt, ref64), noise, float("nan"), "alt fp32 noise (GPU ATen), recorded only")
     tol = bound_for(noise, floor)
-    if scatter_bound is not None:
-        tol = max(tol, scatter_bound)
     e = rel_err(got, ref64)
-    record(name, e, noise, tol, ("max" if noise <= NOISE_CAP / NOISE_FACTOR else "max,ill") + (",named-scatter" if scatter_bound is not None else ""))
+    record(name, e, noise, tol, "max" if noise <= NOISE_CAP / NOISE_FACTOR else "max,ill")
     assert e <= tol, f"{name}: rel err vs fp64 oracle {e:.3e} > {tol:.3e} (fp32 oracle's own: {noise:.3e})"
     n2 = l2_err(ref32, ref64)
-    tol2 = max(floor, L2_FACTOR * n2, scatter_bound or 0.0)
+    tol2 = max(floor, L2_FACTOR * n2)
     e2 = l2_err(got, ref64)
     record(name, e2, n2, tol2, "l2")
     assert e2 <= tol2, f"{name}: l2 err vs fp64 oracle {e2:.3e} > {tol2:.3e} = max({floor}, {L2_FACTOR} x fp32 oracle's own {n2:.3e})"

@@ -14,7 +14,7 @@ from oracle.losses import batch_loss, orthogonal_loss
 from oracle.mil import deform_pathomic_net
 from oracle.nystrom import nystrom_attention
 from test_gpu_parity import _compare_param_grads, _load, cpb_probe
-from test_oracle_golden import pathomic_args
+from test_oracle_golden import ZERO_GRADS, pathomic_args
 
 pytestmark = pytest.mark.gpu
 Fh = smml.functional
@@ -88,31 +88,16 @@ def test_cfg5_nystrom_long_bag_50000(cuda):
         assert_close("linear in v", out3 - b, 3.0 * (out1 - b), 2e-5)
 
 
-# Named exceptions of the full-size case: gradients on the tumor branch's QUERY path - d(fused features) and what hangs below
-# it.  Their fp32 evaluations scatter between realisations: over four (parameters, bag) seeds the error of d to_offsets.2.weight through this
-# path is 1.9e-5 ... 5.1e-5 on the HIP kernels and 7.2e-6 ... 4.9e-5 for the oracle in fp32 on the host (ratio 0.9 ... 4.3), and seed 17 - this
-# test's - is the draw with the smallest host error and the largest HIP one (profiles/r04_fp32_scatter.txt; the error enters through dk, and
-# no precision variant of the kernels - three-term dkv / dQ products, re-centred or two-sweep delta, libm math, five-term layer 2 - moves it).
-# One host run therefore underestimates the fp32 noise of these tensors; they get an explicit bound instead of the larger-of-two-back-ends
-# yardstick of round 3 (the GPU-ATen fp32 figure is still recorded beside every tensor).
-CFG4_FP32_SCATTER = {p: 2.5e-4 for p in ("omic_net_tumor.encoder.", "pathomic_net_tumor.fusion_layer.", "pathomic_net_tumor.layer3.norm.",
-                                          "pathomic_net_tumor.layer3.attn2d.to_offsets.", "pathomic_net_tumor.layer3.attn2d.to_q.")}
-
-
-@pytest.mark.parametrize("B,S", [(2, 24), (1, 100)])
-def test_cfg4_full_fusion_10000x512(cuda, B, S):
-    """BASELINE config 4 (per-rank slice): full two-branch DeformPathomicNet on bags of 10 000 x 512 (100 x 100 grid, 625
-    sampled keys) + cross-entropy + both BatchLosses + an OrthogonalLoss term on the two branch vectors, forward and every
-    parameter gradient against the oracle (fp32 + fp64 host runs: ~3 minutes of host time for ONE bag, which is why the
-    full-size case runs B = 1 - a 1 x 1 BatchLoss is identically zero - and the two-bag case, where the BatchLosses
-    contribute, runs on a 24 x 24 grid).  The data-parallel side of config 4 is tests/test_gpu_data_parallel.py (2 ranks)
-    and tests/test_data_parallel_gloo.py."""
+def _cfg4_once(cuda, B, S, seed, host_fp32):
+    """One realisation of BASELINE config 4 (per-rank slice): full two-branch DeformPathomicNet on B bags of S*S x 512 + cross-entropy + both
+    BatchLosses + an OrthogonalLoss term, on the HIP path and on the oracle with the HIP path's piecewise-linear decisions imposed:
+    fp32 (on the host if host_fp32, else on the GPU's ATen kernels) and fp64.  -> dict of the tensors to compare."""
     args = pathomic_args(input_path_dim=512, batch_size=B)
     net = smml.DeformPathomicNet(args)
-    params = params_for(net, 17, "cfg4")
+    params = params_for(net, seed, "cfg4")
     net = _load(net, params, cuda)
-    x_path = synth.bag(B, S * S, 512, 17, "cfg4:bag")
-    x_t = synth.normal((B, 59), 17, "cfg4:tumor"); x_i = synth.normal((B, 361), 17, "cfg4:immune")
+    x_path = synth.bag(B, S * S, 512, seed, "cfg4:bag")
+    x_t = synth.normal((B, 59), seed, "cfg4:tumor"); x_i = synth.normal((B, 361), seed, "cfg4:immune")
     label = torch.tensor([2, 0])[:B]
 
     def total(feats, vt, vi, lg, bl, ol):
@@ -120,49 +105,122 @@ def test_cfg4_full_fusion_10000x512(cuda, B, S):
         return (torch.nn.functional.cross_entropy(lg[2], label.to(lg[2].device)) + 0.5 * l_t.sum() + 0.5 * l_i.sum()
                 + 0.1 * ol(vt, vi, vi, vt).sum()), l_t, l_i
 
-    # HIP first: the piecewise-linear decisions of its two attention calls (sampler cells, ReLU masks of the position bias) are
-    # imposed on both oracle runs, so every gradient is held to the plain rule - no boundary / flip exemption (helpers.py)
+    # HIP first: the piecewise-linear decisions of its two attention calls (sampler cells, the ReLU decisions of the position bias = the
+    # patterns of each pair's linear region) are imposed on the oracle runs, so every gradient is held to the plain rule (helpers.py)
     with decision_tap() as tap:
         feats, vt, vi, lg, _, _, _ = net(x_path=x_path.to(cuda), x_omic=None, x_omic_tumor=x_t.to(cuda), x_omic_immune=x_i.to(cuda))
     bl, ol = smml.BatchLoss(B, 1), smml.OrthogonalLoss()
     loss, l_t, l_i = total(feats, vt, vi, lg, bl, ol)
     loss.backward()
     assert len(tap.decisions()) == 2                       # tumor branch, immune branch (model.py:494,497) - the oracle's order too
-    run = {}
+    assert lg[4].shape == (B * 8, 2, S // 4, S // 4)
+    out = {"net": net, "hip": (feats, lg[2], lg[4], lg[6], l_t, l_i, loss), "params": params, "tap": tap, "total": total,
+           "inputs": (x_path, x_t, x_i)}
+    runs = [("f32", torch.float32, "cpu" if host_fp32 else cuda), ("f64", torch.float64, cuda if S >= 100 else "cpu")]
+    if host_fp32:
+        runs.insert(1, ("g32", torch.float32, cuda))           # recorded beside the host figure (the back end the reference trains on)
     with cpb_probe() as probe:
-        # three evaluations of the oracle: fp32 on the host (the reference's arithmetic), fp32 on the GPU's ATen kernels (the back end the
-        # reference trains on: its fp32 noise is what the HIP path may reasonably be held to, helpers.assert_calibrated) and fp64 (truth)
-        # (the fp64 run of the full-size case uses the GPU's fp64 ATen kernels: the same truth to ~1e-13, and two minutes less of host time)
-        for key, dt, dev in (("cpu32", torch.float32, "cpu"), ("gpu32", torch.float32, cuda), ("cpu64", torch.float64, cuda if S >= 100 else "cpu")):
+        for key, dt, dev in runs:
             p = {k: (v.clone().to(dev, dt).requires_grad_() if v.dtype.is_floating_point else v.to(dev)) for k, v in params.items()}
             odeform.DECISIONS = tap.decisions()
             o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024)
             assert not odeform.DECISIONS
             o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
             o_loss.backward()
-            run[key] = (o_feats.detach().cpu(), o_lg[2].detach().cpu(), o_lg[4].detach().cpu(), o_lg[6].detach().cpu(), o_lt.detach().cpu(),
+            out[key] = (o_feats.detach().cpu(), o_lg[2].detach().cpu(), o_lg[4].detach().cpu(), o_lg[6].detach().cpu(), o_lt.detach().cpu(),
                         o_li.detach().cpu(), o_loss.detach().cpu(), p)
-    r32, r64, g32 = run["cpu32"], run["cpu64"], run["gpu32"]
-    for name, got, i in (("features", feats, 0), ("haz", lg[2], 1), ("vgrid_t", lg[4], 2), ("vgrid_i", lg[6], 3),
-                         ("batchloss_t", l_t, 4), ("batchloss_i", l_i, 5), ("loss", loss, 6)):
-        assert_calibrated("cfg4 " + name, got, r32[i], r64[i], ref32_alt=g32[i])
-    assert lg[4].shape == (B * 8, 2, S // 4, S // 4)
+    out["probe"] = probe
+    return out
+
+
+VALUE_NAMES = ("features", "haz", "vgrid_t", "vgrid_i", "batchloss_t", "batchloss_i", "loss")
+
+
+def test_cfg4_two_bags_24x24(cuda):
+    """Config 4 with two bags on a 24 x 24 grid (the BatchLosses contribute: a 1 x 1 BatchLoss is identically zero): forward values and
+    every parameter gradient against the oracle - fp32 on the host (the noise yardstick), fp32 on the GPU's ATen kernels (recorded), fp64."""
+    B, S = 2, 24
+    r = _cfg4_once(cuda, B, S, 17, host_fp32=True)
+    for i, name in enumerate(VALUE_NAMES):
+        assert_calibrated("cfg4 " + name, r["hip"][i], r["f32"][i], r["f64"][i], ref32_alt=r["g32"][i])
+    net = r["net"]
     with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
-    assert with_grad == {k for k, v in r64[7].items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
-    _compare_param_grads(net, r32[7], r64[7], skip=("cls_token",), probe=probe, p32_alt=g32[7], scatter=CFG4_FP32_SCATTER if S >= 100 else None)
-    if S >= 100:
-        # VERDICT r03 "weak" 2: the full-size comparison above imposes the kernels' decisions on the oracle.  Forward VALUES do not need that -
-        # ReLU and the bilinear interpolant are continuous across their kinks - so they are also asserted against an fp64 oracle run with NOTHING
-        # imposed; the gradients of that run (which differ from the imposed run wherever a rounding-level tie fell the other way) are recorded.
-        p = {k: (v.clone().to(cuda, torch.float64).requires_grad_() if v.dtype.is_floating_point else v.to(cuda)) for k, v in params.items()}
-        odeform.DECISIONS = None
-        u_feats, u_vt, u_vi, u_lg = deform_pathomic_net(x_path.to(cuda, torch.float64), x_t.to(cuda, torch.float64), x_i.to(cuda, torch.float64), p,
-                                                       grid_hw=(S, S), q_chunk=1024)
-        u_loss, _, _ = total(u_feats, u_vt, u_vi, u_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
-        u_loss.backward()
-        for name, got, ref in (("features", feats, u_feats), ("haz", lg[2], u_lg[2]), ("vgrid_t", lg[4], u_lg[4]), ("vgrid_i", lg[6], u_lg[6]), ("loss", loss, u_loss)):
-            assert_close("cfg4 nothing imposed: " + name, got, ref.detach(), 1e-4)
-        for k, q in net.named_parameters():
-            if q.grad is not None and getattr(p[k], "grad", None) is not None and not k.endswith(("cls_token", "rel_pos_bias.mlp.2.bias")):
-                helpers.record("cfg4 nothing imposed: d" + k, rel_err(q.grad, p[k].grad), rel_err(r64[7][k].grad, p[k].grad.cpu()), float("nan"),
-                               "recorded only (noise column = imposed vs un-imposed fp64 oracle)")
+    assert with_grad == {k for k, v in r["f64"][7].items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
+    _compare_param_grads(net, r["f32"][7], r["f64"][7], skip=("cls_token",), probe=r["probe"], p32_alt=r["g32"][7])
+
+
+def test_cfg4_full_fusion_10000x512(cuda):
+    """BASELINE config 4 at full size: one bag of 10 000 x 512 (100 x 100 grid, 625 sampled keys) per realisation, FOUR realisations
+    (parameters + bag + omic vectors from seeds 17, 23, 29, 31).
+
+    Yardstick (no named tensors, no hand-set bound): one fp32 run is a poor estimate of fp32 noise for gradients that
+    are sums over 10 000 queries - over seeds the distance of an fp32 evaluation to fp64 scatters by 5 x for the same tensor
+    (profiles/r04_fp32_scatter.txt).  So every tensor is judged on the MEDIAN over the four realisations:
+        median(HIP error)  <=  max(1e-4, 1.5 x median(error of the oracle evaluated in fp32 on this GPU's ATen kernels)),
+    errors = max-norm distance to the fp64 oracle relative to the tensor's scale, same decisions imposed on all three; and no single
+    realisation may be further than 1e-3 (a gross error on one seed cannot hide in a median).  Forward values are asserted per realisation
+    under the plain rule.  The data-parallel side of config 4 is tests/test_gpu_data_parallel.py and tests/test_data_parallel_gloo.py."""
+    import statistics
+    B, S = 1, 100
+    seeds = (17, 23, 29, 31)
+    e_hip, e_f32 = {}, {}
+    first = None
+    for seed in seeds:
+        r = _cfg4_once(cuda, B, S, seed, host_fp32=False)
+        for i, name in enumerate(VALUE_NAMES):
+            assert_calibrated(f"cfg4 seed {seed} {name}", r["hip"][i], r["f32"][i], r["f64"][i])
+        net, p32, p64 = r["net"], r["f32"][7], r["f64"][7]
+        with_grad = {k for k, p in net.named_parameters() if p.grad is not None}
+        assert with_grad == {k for k, v in p64.items() if getattr(v, "grad", None) is not None}, "set of parameters receiving a gradient differs"
+        for k, p in net.named_parameters():
+            if k.endswith("cls_token") or p.grad is None:
+                continue
+            if k.endswith(ZERO_GRADS):                      # exactly zero in exact arithmetic (softmax shift invariance): held to its natural scale
+                helpers.assert_zero_grad(f"seed {seed} d{k}", p.grad, r["probe"].scale(p64[k]))
+                continue
+            e_hip.setdefault(k, []).append(rel_err(p.grad, p64[k].grad))
+            e_f32.setdefault(k, []).append(rel_err(p32[k].grad, p64[k].grad))
+        if first is None:
+            first = r
+        else:
+            del r
+        torch.cuda.empty_cache()
+    failures = []
+    for k in e_hip:
+        mh, m32 = statistics.median(e_hip[k]), statistics.median(e_f32[k])
+        bound = max(1e-4, 1.5 * m32)
+        helpers.record("cfg4 d" + k, mh, m32, bound, f"median of {len(seeds)} realisations (noise = fp32 oracle on GPU ATen)")
+        if mh > bound:
+            failures.append(f"d{k}: median error {mh:.3e} > {bound:.3e} = max(1e-4, 1.5 x fp32 oracle's {m32:.3e}); per seed {['%.2e' % e for e in e_hip[k]]}")
+        if max(e_hip[k]) > 1e-3:
+            failures.append(f"d{k}: error {max(e_hip[k]):.3e} on one realisation")
+    assert not failures, f"{len(failures)} parameter gradients out of tolerance:\n  " + "\n  ".join(failures)
+
+    # VERDICT r03 "weak" 2 / r04 item 4: the comparisons above impose the kernels' decisions on the oracle.  Against an fp64 oracle run with
+    # NOTHING imposed (first realisation): forward VALUES need no imposed decisions (ReLU and the bilinear interpolant are continuous across
+    # their kinks) and are asserted at 1e-4; a GRADIENT may differ from that run by what the decisions that differ are worth - measured
+    # exactly as the distance between the imposed and the un-imposed fp64 oracle - plus the plain bound (triangle inequality, asserted so
+    # that the conditioning of the claim is explicit; that the decisions which differ are rounding-level ties is asserted where the
+    # problem is small enough to hold every pre-activation in fp64: tests/test_gpu_regions.py, tests/test_gpu_parity.py).
+    r = first
+    net, params, total = r["net"], r["params"], r["total"]
+    x_path, x_t, x_i = r["inputs"]
+    p = {k: (v.clone().to(cuda, torch.float64).requires_grad_() if v.dtype.is_floating_point else v.to(cuda)) for k, v in params.items()}
+    odeform.DECISIONS = None
+    u_feats, u_vt, u_vi, u_lg = deform_pathomic_net(x_path.to(cuda, torch.float64), x_t.to(cuda, torch.float64), x_i.to(cuda, torch.float64), p,
+                                                   grid_hw=(S, S), q_chunk=1024)
+    u_loss, _, _ = total(u_feats, u_vt, u_vi, u_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
+    u_loss.backward()
+    hip = r["hip"]
+    for name, got, ref in (("features", hip[0], u_feats), ("haz", hip[1], u_lg[2]), ("vgrid_t", hip[2], u_lg[4]), ("vgrid_i", hip[3], u_lg[6]), ("loss", hip[6], u_loss)):
+        assert_close("cfg4 nothing imposed: " + name, got, ref.detach(), 1e-4)
+    bad = []
+    for k, q in net.named_parameters():
+        if q.grad is not None and getattr(p[k], "grad", None) is not None and not k.endswith(("cls_token", "rel_pos_bias.mlp.2.bias")):
+            worth = rel_err(r["f64"][7][k].grad, p[k].grad.cpu())              # what the differing decisions move this gradient by
+            e = rel_err(q.grad, p[k].grad)
+            bound = worth + max(1e-4, 1.5 * e_f32[k][0])
+            helpers.record("cfg4 nothing imposed: d" + k, e, worth, bound, "vs un-imposed fp64 (noise column = imposed vs un-imposed fp64 oracle)")
+            if e > bound:
+                bad.append(f"d{k}: {e:.3e} > {bound:.3e}")
+    assert not bad, "gradients vs the un-imposed fp64 oracle:\n  " + "\n  ".join(bad)
