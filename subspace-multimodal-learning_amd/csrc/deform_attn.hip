@@ -1137,11 +1137,11 @@ extern "C" {
 
 // row stride of the key-major score / mask tensors: whole 128-query workgroup tiles, so that the forward stores its rows
 // without per-lane bounds checks (columns >= N are padding nobody reads)
-int smml_deform_attn_nst(int N) { return (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
+int smml_deform_attn_nst(int N) { return (N <= 0 || N > SMML_MAX_QUERIES) ? 0 : (N + QT * WAVES - 1) / (QT * WAVES) * (QT * WAVES); }
 
 int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, float dropout_p, unsigned long long dropout_seed,
                                       void* stream, const SmmlDeformOpts* opts) {
-  SMML_REQUIRE(mask && B > 0 && N > 0 && J > 0 && H > 0 && dropout_p >= 0.f && dropout_p < 1.f,
+  SMML_REQUIRE(mask && deform_dims_ok(B, N, J, H) && dropout_p >= 0.f && dropout_p < 1.f,
                "smml_deform_attn_dropout_mask_f32: bad argument");
   const unsigned long long total = (unsigned long long)B * H * N * J;
   hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, total, J,
@@ -1152,8 +1152,8 @@ int smml_deform_attn_dropout_mask_f32(float* mask, int B, int N, int J, int H, f
 
 int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* w1, const float* b1, unsigned short* masks, int B,
                                  int N, int J, int G, int posdim, void* stream, const SmmlDeformOpts* opts) {
-  SMML_REQUIRE(vs && gq && w1 && b1 && masks && B > 0 && N > 0 && J > 0 && G > 0 && (posdim == 1 || posdim == 2) && B <= 65535 &&
-                   G <= 65535, "smml_deform_attn_relu1_masks: bad argument");
+  SMML_REQUIRE(vs && gq && w1 && b1 && masks && deform_dims_ok(B, N, J, G) && (posdim == 1 || posdim == 2),
+               "smml_deform_attn_relu1_masks: bad argument");
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), G, B), block(256);
   const int nst = smml_deform_attn_nst(N);
   if (posdim == 2)
@@ -1167,7 +1167,7 @@ int smml_deform_attn_relu1_masks(const float* vs, const float* gq, const float* 
 }
 
 size_t smml_deform_attn_bwd_workspace_bytes(int B, int N, int J, int H) {
-  if (B <= 0 || N <= 0 || J <= 0 || H <= 0) return 0;
+  if (!deform_dims_ok(B, N, J, H)) return 0;
   return bwd_workspace(B, N, J, H).total * sizeof(float);
 }
 
@@ -1176,7 +1176,7 @@ static int check_common(const char* fn, int B, int N, int J, int H, int G, int p
   SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
   SMML_REQUIRE(H / G <= 2, "%s: at most 2 heads per offset group are supported (got %d)", fn, H / G);
   SMML_REQUIRE(posdim == 1 || posdim == 2, "%s: posdim must be 1 or 2 (got %d)", fn, posdim);
-  SMML_REQUIRE(B <= 65535 && H <= 65535, "%s: batch/heads exceed the grid limits", fn);
+  SMML_REQUIRE(deform_dims_ok(B, N, J, H), "%s: B, H <= 65535, N <= 2^26, J <= 2^22 (got B %d N %d J %d H %d)", fn, B, N, J, H);
   return SMML_OK;
 }
 
@@ -1388,7 +1388,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
 }
 
 size_t smml_deform_attn_region_bwd_workspace_bytes(int B, int N, int J, int H) {
-  if (B <= 0 || N <= 0 || J <= 0 || H <= 0) return 0;
+  if (!deform_dims_ok(B, N, J, H) || J > 768) return 0;
   return region_bwd_plan(B, N, J, H).total;
 }
 

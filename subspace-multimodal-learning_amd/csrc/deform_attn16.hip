@@ -1387,7 +1387,7 @@ int check16(const char* fn, int B, int N, int J, int H, int G, int posdim, int d
   SMML_REQUIRE(H % G == 0, "%s: heads (%d) must be divisible by offset groups (%d)", fn, H, G);
   SMML_REQUIRE(H / G <= 2, "%s: at most 2 heads per offset group are supported (got %d)", fn, H / G);
   SMML_REQUIRE(posdim == 1 || posdim == 2, "%s: posdim must be 1 or 2 (got %d)", fn, posdim);
-  SMML_REQUIRE(B <= 65535 && H <= 65535, "%s: batch/heads exceed the grid limits", fn);
+  SMML_REQUIRE(deform_dims_ok(B, N, J, H), "%s: B, H <= 65535, N <= 2^26, J <= 2^22 (got B %d N %d J %d H %d)", fn, B, N, J, H);
   SMML_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype must be 0 (bf16) or 1 (fp16), got %d", fn, dtype);
   return SMML_OK;
 }
@@ -1623,6 +1623,7 @@ int smml_cpb_mask_table(const float* w1, const float* b1, const float* w2, const
 int smml_deform_attn_table_points(int posdim) { return posdim == 2 ? TABLE_G2 : TABLE_G1; }
 
 size_t smml_deform_attn_table_bwd_workspace_bytes(int B, int N, int J, int H, int posdim) {
+  if (!deform_dims_ok(B, N, J, H)) return 0;
   return table_workspace(B, N, J, H, posdim == 2 ? TABLE_G2 * TABLE_G2 : TABLE_G1).total * sizeof(float);
 }
 

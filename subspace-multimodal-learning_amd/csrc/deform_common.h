@@ -479,6 +479,13 @@ static BwdWorkspace bwd_workspace(int B, int N, int J, int H) {
   return w;
 }
 
+// Sizes the fused attention families accept: grid dimensions B, H <= 65535, N <= 2^26 queries, J <= 2^22 keys - every index and size
+// expression of the launch geometry then stays inside 63 bits (and the int ones inside 31); larger values are refused, not wrapped
+// (tests/test_host_sanitizers.py walks the entry points under UBSan).
+constexpr int SMML_MAX_QUERIES = 1 << 26, SMML_MAX_KEYS = 1 << 22;
+bool deform_dims_ok(int B, int N, int J, int H) {
+  return B > 0 && N > 0 && J > 0 && H > 0 && B <= 65535 && H <= 65535 && N <= SMML_MAX_QUERIES && J <= SMML_MAX_KEYS;
+}
 // position-dimension template value of a launch (PosCfg): 2 | 1 | 3 = one dimension, raw offsets (opts->raw_distance)
 int pdx_of(int posdim, const SmmlDeformOpts* opts) { return posdim == 2 ? 2 : ((opts && opts->raw_distance) ? 3 : 1); }
 // opts->seed_offset is read into the launch's DropCfg and dereferenced on the device only

@@ -368,9 +368,10 @@ static int offsets_geometry(const char* fn, int Hh, int Ww, int dg, int ks, int 
 
 // out-length of the strided offset conv along one axis of size s (0 if it does not fit)
 int smml_offsets_out_len(int s, int ks, int r) {
+  if (s <= 0 || ks <= 0 || r <= 0 || ks < r) return 0;
   const int pad = (ks - r) / 2;
-  const int t = (s + 2 * pad - ks) / r + 1;
-  return (s + 2 * pad - ks) < 0 ? 0 : t;
+  const long long span = (long long)s + 2 * pad - ks;
+  return span < 0 ? 0 : (int)(span / r + 1);
 }
 
 int smml_offsets_fwd_f32(const float* q, const float* w0, const float* b0, const float* w2, float* vgrid, float* vs,

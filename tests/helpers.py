@@ -11,7 +11,7 @@ Tolerance policy (north_star: "fp32 within 1e-4 relative", integer paths bit-exa
     (then 2 x noise, flagged `ill` in the report: the fixture itself cannot be reproduced closer by any fp32 program);
   * the full-size model test (config 4, 100 x 100: gradients that are sums over 10 000 queries, whose fp32 evaluations scatter by 5 x
     between realisations, profiles/r04_fp32_scatter.txt) judges every tensor on the MEDIAN over four realisations:
-    median(HIP error) <= max(1e-4, 1.5 x median(error of the oracle in fp32 on this GPU's ATen kernels)), no realisation beyond 1e-3;
+    median(HIP error) <= max(1e-4, 1.5 x median(error of the oracle in fp32 on this GPU's ATen kernels)), no realisation beyond max(1e-3, 3 x that oracle's own error);
     no tensor is named, no bound is set by hand (tests/test_gpu_configs.py; round 4 had five named 2.5e-4 bounds);
   * where an fp64 truth is available the HIP result is ALSO held to the reference's own accuracy in the l2 norm:
     l2(hip - fp64) <= max(1e-4, L2_FACTOR x l2(fp32 - fp64)) with L2_FACTOR = 1.5 - the kernels may not be noisier than
@@ -185,10 +185,12 @@ class Decisions:
         if a.get("region_ids") is not None:   # region kernels (csrc/cpb_regions.h): a pair's decisions are the ReLU patterns of its linear piece
             rid = a["region_ids"]
             nst = rid.shape[2] * 32
-            self.regions = {"rid": (rid.view(B, H, nst // 32, J, 32).permute(0, 1, 3, 2, 4).reshape(B * H, J, nst)).cpu(),
-                            "pat": Fh.region_tables_view(a["tables"])["pat"].cpu(),
-                            "w": [a[k].detach().double().cpu() for k in ("w1", "b1", "w2", "b2")], "vs": a["vs"].detach().double().cpu(),
-                            "gq": a["gq"].detach().double().cpu()}
+            # kept on the device: decoding 5e7 region ids per bag into 64 booleans each is a gather + shifts - seconds on the GPU,
+            # minutes on the host (the oracle moves the masks to wherever it runs)
+            self.regions = {"rid": rid.view(B, H, nst // 32, J, 32).permute(0, 1, 3, 2, 4).reshape(B * H, J, nst).contiguous(),
+                            "pat": Fh.region_tables_view(a["tables"])["pat"].clone(),
+                            "w": [a[k].detach().double() for k in ("w1", "b1", "w2", "b2")], "vs": a["vs"].detach().double(),
+                            "gq": a["gq"].detach().double(), "device": rid.device}
             return
         if a["masks2"] is None:           # table mode of the 16-bit core: the MLP runs on grid points only, no per-pair ReLU decisions
             return
@@ -210,7 +212,7 @@ class Decisions:
 
     def relu_masks(self, i0, i1, device="cpu"):
         if self.regions is not None:
-            return region_decisions(self.regions, i0, i1, device)
+            return region_decisions(self.regions, i0, i1, self.regions["device"])
         if self.m2 is None:
             return None
         return self.decode(self.m1, i0, i1, device), self.decode(self.m2, i0, i1, device)

@@ -123,7 +123,7 @@ def _cfg4_once(cuda, B, S, seed, host_fp32):
         for key, dt, dev in runs:
             p = {k: (v.clone().to(dev, dt).requires_grad_() if v.dtype.is_floating_point else v.to(dev)) for k, v in params.items()}
             odeform.DECISIONS = tap.decisions()
-            o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024)
+            o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024 if dev == "cpu" else 2500)
             assert not odeform.DECISIONS
             o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
             o_loss.backward()
@@ -151,14 +151,14 @@ def test_cfg4_two_bags_24x24(cuda):
 
 def test_cfg4_full_fusion_10000x512(cuda):
     """BASELINE config 4 at full size: one bag of 10 000 x 512 (100 x 100 grid, 625 sampled keys) per realisation, FOUR realisations
-    (parameters + bag + omic vectors from seeds 17, 23, 29, 31).
+    (parameters + bag + omic vectors from seeds 17, 23, 29, 31; a realisation costs two full-size oracle runs on the GPU, ~15 s).
 
     Yardstick (no named tensors, no hand-set bound): one fp32 run is a poor estimate of fp32 noise for gradients that
     are sums over 10 000 queries - over seeds the distance of an fp32 evaluation to fp64 scatters by 5 x for the same tensor
-    (profiles/r04_fp32_scatter.txt).  So every tensor is judged on the MEDIAN over the four realisations:
+    (profiles/r04_fp32_scatter.txt).  So every tensor is judged on the MEDIAN over the realisations:
         median(HIP error)  <=  max(1e-4, 1.5 x median(error of the oracle evaluated in fp32 on this GPU's ATen kernels)),
     errors = max-norm distance to the fp64 oracle relative to the tensor's scale, same decisions imposed on all three; and no single
-    realisation may be further than 1e-3 (a gross error on one seed cannot hide in a median).  Forward values are asserted per realisation
+    realisation may be further than max(1e-3, 3 x the fp32 oracle's own error on it) (a gross error on one seed cannot hide in a median).  Forward values are asserted per realisation
     under the plain rule.  The data-parallel side of config 4 is tests/test_gpu_data_parallel.py and tests/test_data_parallel_gloo.py."""
     import statistics
     B, S = 1, 100
@@ -192,8 +192,9 @@ def test_cfg4_full_fusion_10000x512(cuda):
         helpers.record("cfg4 d" + k, mh, m32, bound, f"median of {len(seeds)} realisations (noise = fp32 oracle on GPU ATen)")
         if mh > bound:
             failures.append(f"d{k}: median error {mh:.3e} > {bound:.3e} = max(1e-4, 1.5 x fp32 oracle's {m32:.3e}); per seed {['%.2e' % e for e in e_hip[k]]}")
-        if max(e_hip[k]) > 1e-3:
-            failures.append(f"d{k}: error {max(e_hip[k]):.3e} on one realisation")
+        worst = max(range(len(seeds)), key=lambda i: e_hip[k][i] / max(1e-3, 3.0 * e_f32[k][i]))
+        if e_hip[k][worst] > max(1e-3, 3.0 * e_f32[k][worst]):
+            failures.append(f"d{k}: error {e_hip[k][worst]:.3e} on seed {seeds[worst]} (fp32 oracle's own: {e_f32[k][worst]:.3e})")
     assert not failures, f"{len(failures)} parameter gradients out of tolerance:\n  " + "\n  ".join(failures)
 
     # VERDICT r03 "weak" 2 / r04 item 4: the comparisons above impose the kernels' decisions on the oracle.  Against an fp64 oracle run with
@@ -208,7 +209,7 @@ def test_cfg4_full_fusion_10000x512(cuda):
     p = {k: (v.clone().to(cuda, torch.float64).requires_grad_() if v.dtype.is_floating_point else v.to(cuda)) for k, v in params.items()}
     odeform.DECISIONS = None
     u_feats, u_vt, u_vi, u_lg = deform_pathomic_net(x_path.to(cuda, torch.float64), x_t.to(cuda, torch.float64), x_i.to(cuda, torch.float64), p,
-                                                   grid_hw=(S, S), q_chunk=1024)
+                                                   grid_hw=(S, S), q_chunk=2500)
     u_loss, _, _ = total(u_feats, u_vt, u_vi, u_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
     u_loss.backward()
     hip = r["hip"]
