@@ -49,11 +49,22 @@ def pooler(h, p: Params):
     return torch.tanh(linear(h.mean(dim=1), p, "dense."))
 
 
+# Imposed decisions of the first layer's ReLU (parity tests at the headline size; same idea as oracle.deform.DECISIONS): relu(_fc1(bag)) is
+# piecewise linear in 1.3e6 pre-activations per bag, and one of them within fp32 rounding of zero decides differently in two fp32 programs -
+# which moves one ROW of d _fc1.weight by that token's whole contribution (5e-3 of the row's scale at 10 000 tokens).  A test may queue one
+# bool mask [B, N, C] per deform_cross_trans_mil call (consumed in call order): relu(x) then becomes x * mask.
+FC1_DECISIONS = None
+
+
 def deform_cross_trans_mil(path, omic, p: Params, *, attn_dim: int = 2, grid_hw: Tuple[int, int] = (50, 50),
                            q_chunk: int = 512):
     """path [B, N, F_in], omic [B, C] -> (encoded [B, C], logits [B, n_classes], omic_tiled [B, N, C], vgrid)
     (DeformCrossTransMIL.py:97-160)."""
-    path = torch.relu(linear(_fl(path), p, "_fc1.0."))                 # :100
+    pre = linear(_fl(path), p, "_fc1.0.")
+    if FC1_DECISIONS:
+        path = pre * FC1_DECISIONS.pop(0).to(device=pre.device, dtype=pre.dtype)
+    else:
+        path = torch.relu(pre)                                         # :100
     N = path.shape[1]
     omic_t = _fl(omic).unsqueeze(1).repeat(1, N, 1)                    # :104 (2500 in the reference)
     h = linear(torch.cat((path, omic_t), dim=-1), p, "fusion_layer.fusion_layer.")   # :35-37,110

@@ -9,6 +9,7 @@ import torch
 
 import helpers
 import oracle.deform as odeform
+import oracle.mil as omil
 from helpers import assert_calibrated, assert_close, decision_tap, params_for, rel_err, smml, synth
 from oracle.losses import batch_loss, orthogonal_loss
 from oracle.mil import deform_pathomic_net
@@ -114,6 +115,16 @@ def _cfg4_once(cuda, B, S, seed, host_fp32):
     loss.backward()
     assert len(tap.decisions()) == 2                       # tumor branch, immune branch (model.py:494,497) - the oracle's order too
     assert lg[4].shape == (B * 8, 2, S // 4, S // 4)
+    # the third piecewise-linear place of the model, relu(_fc1(bag)): the decisions of the launch the model itself uses (both branches in
+    # one batched launch) are imposed on the oracle as well, and checked against fp64 - they may differ only at rounding-level ties
+    ft, fi = net.pathomic_net_tumor._fc1[0], net.pathomic_net_immune._fc1[0]
+    with torch.no_grad():
+        pf = smml.functional.dual_linear_relu(x_path.to(cuda), ft.weight, ft.bias, fi.weight, fi.bias)
+        fc1_masks = [t > 0 for t in pf]
+        for m, lin in zip(fc1_masks, (ft, fi)):
+            x64 = x_path.to(cuda, torch.float64) @ lin.weight.double().t() + lin.bias.double()
+            bad = x64[(x64 > 0) != m].abs()
+            assert bad.numel() <= 8 and (bad.numel() == 0 or float(bad.max()) < 2e-6), f"_fc1 ReLU decisions: {bad.numel()} differ from fp64, worst |x| {float(bad.max()) if bad.numel() else 0:.2e}"
     out = {"net": net, "hip": (feats, lg[2], lg[4], lg[6], l_t, l_i, loss), "params": params, "tap": tap, "total": total,
            "inputs": (x_path, x_t, x_i)}
     runs = [("f32", torch.float32, "cpu" if host_fp32 else cuda), ("f64", torch.float64, cuda if S >= 100 else "cpu")]
@@ -123,8 +134,10 @@ def _cfg4_once(cuda, B, S, seed, host_fp32):
         for key, dt, dev in runs:
             p = {k: (v.clone().to(dev, dt).requires_grad_() if v.dtype.is_floating_point else v.to(dev)) for k, v in params.items()}
             odeform.DECISIONS = tap.decisions()
+            omil.FC1_DECISIONS = list(fc1_masks)
             o_feats, o_vt, o_vi, o_lg = deform_pathomic_net(x_path.to(dev, dt), x_t.to(dev, dt), x_i.to(dev, dt), p, grid_hw=(S, S), q_chunk=1024 if dev == "cpu" else 2500)
-            assert not odeform.DECISIONS
+            assert not odeform.DECISIONS and not omil.FC1_DECISIONS
+            omil.FC1_DECISIONS = None
             o_loss, o_lt, o_li = total(o_feats, o_vt, o_vi, o_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
             o_loss.backward()
             out[key] = (o_feats.detach().cpu(), o_lg[2].detach().cpu(), o_lg[4].detach().cpu(), o_lg[6].detach().cpu(), o_lt.detach().cpu(),
@@ -208,6 +221,7 @@ def test_cfg4_full_fusion_10000x512(cuda):
     x_path, x_t, x_i = r["inputs"]
     p = {k: (v.clone().to(cuda, torch.float64).requires_grad_() if v.dtype.is_floating_point else v.to(cuda)) for k, v in params.items()}
     odeform.DECISIONS = None
+    omil.FC1_DECISIONS = None
     u_feats, u_vt, u_vi, u_lg = deform_pathomic_net(x_path.to(cuda, torch.float64), x_t.to(cuda, torch.float64), x_i.to(cuda, torch.float64), p,
                                                    grid_hw=(S, S), q_chunk=2500)
     u_loss, _, _ = total(u_feats, u_vt, u_vi, u_lg, lambda o, v: batch_loss(o, v, B), orthogonal_loss)
