@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256) void grad_modulate_kernel(const float* __restr
       const float ct = ok ? 0.5f * n2[0] / dn[0] : 1.f, ci = ok ? 0.5f * n2[1] / dn[1] : 1.f;
       const float rt = ok ? ct / ci : 1.f;
       ratio[0] = rt; ratio[1] = ok ? 1.f / rt : 1.f;
-      if (info) { info[0] = ct; info[1] = ci; info[2] = ratio[0]; info[3] = ratio[1]; }
+      // info[0..1]: the two concordance indices, or - no modulation happened - the reason: -2 all samples censored (the reference prints
+      // and skips, :127-133), -1 no comparable pair in a branch (scikit-survival raises there: the caller may do the same)
+      if (info) {
+        const float why = (cm == (float)B) ? -2.f : -1.f;
+        info[0] = ok ? ct : why; info[1] = ok ? ci : why; info[2] = ratio[0]; info[3] = ratio[1];
+      }
     }
   }
   __syncthreads();
@@ -163,7 +168,8 @@ int smml_grad_modulate_f32(const float* feat_t, const float* feat_i, const float
 }
 
 // task_type 'survival' (train_test.py:99-102,121-149): the branch scores are concordance indices of risk = -sum_t S_t against
-// (censor, survtime) [B] fp32 each (censor 1 = censored); info[0..1] = cindex_t, cindex_i.  All censored / no comparable pair: no edit.
+// (censor, survtime) [B] fp32 each (censor 1 = censored); info[0..1] = cindex_t, cindex_i.  All censored / no comparable pair: no edit and
+// info[0] = info[1] = -2 / -1 (the reference skips the first case and raises, through scikit-survival, in the second).
 int smml_grad_modulate_survival_f32(const float* feat_t, const float* feat_i, const float* weight, const float* bias,
                                     const float* censor, const float* survtime, float* weight_grad, float* info, int B, int C, int hs,
                                     void* stream) {

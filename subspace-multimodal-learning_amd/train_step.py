@@ -53,7 +53,10 @@ def gradient_modulate(classifier: torch.nn.Module, feat_t: torch.Tensor, feat_i:
 def gradient_modulate_survival(classifier: torch.nn.Module, feat_t: torch.Tensor, feat_i: torch.Tensor, censor: torch.Tensor,
                                survtime: torch.Tensor, hs: Optional[int] = None, return_info: bool = False):
     """task_type 'survival' (train_test.py:99-102,121-149): as gradient_modulate, with the branch scores = concordance index of
-    risk = -sum_t cumprod(1 - sigmoid(out)) against censor (label[:, 9], 1 = censored) and survtime (label[:, 11]), both [B]."""
+    risk = -sum_t cumprod(1 - sigmoid(out)) against censor (label[:, 9], 1 = censored) and survtime (label[:, 11]), both [B].
+    return_info: info[0..1] = the two C-indices, or the reason nothing was modulated: -2 every sample censored (the reference prints and
+    skips), -1 no comparable pair (the reference raises there, through scikit-survival: a caller that wants that behaviour checks
+    `info[0] == -1` - a host sync, which is why it is not done here)."""
     w, b = classifier.weight, classifier.bias
     g = w.grad
     if g is None:

@@ -147,3 +147,46 @@ def test_gradient_modulate_survival_all_censored_is_a_no_op(cuda):
     cls = _classifier(W, b, G, cuda)
     smml.gradient_modulate_survival(cls, ft.to(cuda), fi.to(cuda), censor.to(cuda), time.to(cuda))
     assert torch.equal(cls.weight.grad.cpu(), G)               # train_test.py:127-133: "All samples are censored" -> ratios None -> no edit
+
+
+def _cindex_case(cuda, event, time, risk_t, risk_i):
+    """A cohort whose RISK ORDER is known by construction: the branch vector of sample b is x_b on its first component, the classifier reads
+    that component with weight 1 for every interval and no bias, so hazards = sigmoid(x_b) in every interval and
+    risk = -sum_t prod (1 - hazard) grows strictly with x_b; equal x give exactly equal risks."""
+    B, C, hs = len(event), 4, 8
+    ft, fi = torch.zeros(B, hs), torch.zeros(B, hs)
+    ft[:, 0] = torch.tensor(risk_t); fi[:, 0] = torch.tensor(risk_i)
+    W = torch.zeros(C, 2 * hs); W[:, 0] = 1.0; W[:, hs] = 1.0
+    b = torch.zeros(C)
+    G = torch.randn(C, 2 * hs, generator=torch.Generator().manual_seed(1)) * 0.05
+    cls = _classifier(W, b, G, cuda)
+    censor = torch.tensor([0.0 if e else 1.0 for e in event])
+    info = smml.gradient_modulate_survival(cls, ft.to(cuda), fi.to(cuda), censor.to(cuda), torch.tensor(time, dtype=torch.float32).to(cuda),
+                                           return_info=True).cpu()
+    return float(info[0]), float(info[1]), cls.weight.grad.cpu(), G
+
+
+def test_gradient_modulate_survival_hand_computed_cindex(cuda):
+    """the survival branch is parity-UNPINNED (scikit-survival is absent), so its pair rule is pinned by hand-computed cases on
+    cohorts with a known risk order: ties in time, ties in risk, event / event ties, a censored sample at an event's time, all but one censored,
+    and the two cases in which nothing may be modulated (flagged in info: -2 all censored, -1 no comparable pair)."""
+    T, F = True, False
+    # perfectly ordered (tumor) / reversed (immune): 1.0 and 0.0
+    ct, ci, _, _ = _cindex_case(cuda, [T, T, T], [1, 2, 3], [3.0, 2.0, 1.0], [1.0, 2.0, 3.0])
+    assert ct == 1.0 and ci == 0.0
+    # a tie in risk between the two earliest events counts one half: pairs (0,1) tie, (0,2) and (1,2) concordant -> 2.5 / 3
+    ct, ci, _, _ = _cindex_case(cuda, [T, T, F], [1, 2, 3], [2.0, 2.0, 1.0], [3.0, 2.0, 1.0])
+    assert abs(ct - 2.5 / 3) < 1e-6 and ci == 1.0
+    # event and censoring at the same time: comparable (1 pair); two events at the same time: not comparable with each other
+    ct, ci, _, _ = _cindex_case(cuda, [T, F], [5, 5], [1.0, 0.0], [0.0, 1.0])
+    assert ct == 1.0 and ci == 0.0
+    ct, ci, _, _ = _cindex_case(cuda, [T, T, F], [5, 5, 9], [2.0, 1.0, 0.0], [2.0, 1.0, 3.0])
+    assert ct == 1.0 and ci == 0.0                    # 2 comparable pairs each: (0,2), (1,2)
+    # all but one censored: only the event sample opens pairs, with everyone who outlives it
+    ct, ci, _, _ = _cindex_case(cuda, [F, T, F, F], [1, 2, 3, 4], [9.0, 2.0, 1.0, 3.0], [0.0, 2.0, 2.0, 1.0])
+    assert abs(ct - 0.5) < 1e-6 and abs(ci - 0.75) < 1e-6          # pairs (1,2), (1,3): tumor 1 concordant 1 discordant; immune 1 tie 1 concordant
+    # nothing to modulate: every sample censored (-2), no comparable pair (-1: the only event is the last to leave) - gradients untouched
+    ct, ci, g, G = _cindex_case(cuda, [F, F, F], [1, 2, 3], [1.0, 2.0, 3.0], [1.0, 2.0, 3.0])
+    assert ct == -2.0 and ci == -2.0 and torch.equal(g, G)
+    ct, ci, g, G = _cindex_case(cuda, [F, F, T], [1, 2, 3], [1.0, 2.0, 3.0], [1.0, 2.0, 3.0])
+    assert ct == -1.0 and ci == -1.0 and torch.equal(g, G)
