@@ -858,16 +858,18 @@ struct RegionBwdLds {                    // dynamic LDS of cpb_region_bwd_kernel
 // grid (chunks, H, B); block = 64 * nkb * wpk threads (<= 768): wave w owns the keys lane * nkb + (w % nkb) (lane = key; keys of one
 // wave are nkb apart, so that its lanes fall into different regions: no same-address serialisation of the LDS adds) and every wpk-th
 // query tile (32 queries) of the chunk.  For each of its tiles a lane reads its key's 32 d scores and 32 region ids (one 128-byte and
-// one 64-byte row, the next tile's rows in flight meanwhile) and walks the queries: no cross-lane sums for d vs; the three moments of a
-// RUN of queries in the same region (~4 on the query grid) are summed in registers and go to the region's LDS accumulators with three
-// 64-bit integer adds when the region changes.
+// one 64-byte row, the next tile's rows and query positions in flight meanwhile) and walks the queries: no cross-lane sums for d vs; the
+// three moments of a RUN of queries in the same region (~4 on the query grid) and the run's two d vs sums are kept in registers and go to
+// the region's LDS accumulators with three 64-bit integer adds when the region changes.  The query is the same for all lanes: its position
+// comes from a lane of the tile's position register into scalar registers, the second coordinate's log / reciprocal only when it changes.
 __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const float* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, RegionView rv, const unsigned* __restrict__ AMAX, unsigned long long* __restrict__ HIST, unsigned long long* __restrict__ GRAD,
     float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   RegionBwdLds& L = *reinterpret_cast<RegionBwdLds*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hf = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform in a scalar register: tile indices, bounds and the query positions stay scalar
   const int b = blockIdx.z, h = blockIdx.y, chunk = blockIdx.x;
   const int nthreads = blockDim.x;
   {
@@ -884,7 +886,8 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   float big;
   asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
 
-  const int kb = wave % nkb, tslot = wave / nkb;                   // waves beyond nkb * wpk do not exist (block size)
+  // (the division runs on the vector unit: back to scalar registers)
+  const int kb = __builtin_amdgcn_readfirstlane(wave % nkb), tslot = __builtin_amdgcn_readfirstlane(wave / nkb);   // waves beyond nkb * wpk do not exist (block size)
   const int key = lane * nkb + kb;
   const bool kvalid = key < J;
   const int keyc = min(key, J - 1);
@@ -892,22 +895,35 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   const int ntq = (N + QT - 1) / QT;
   const int t_begin = chunk * tiles_per_chunk, t_end = min(t_begin + tiles_per_chunk, ntq);
   float dv0 = 0.f, dv1 = 0.f;
-  unsigned cur = RG_NONE;                                           // region of the current run of this lane, its three moment sums
-  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-  auto flush = [&](unsigned id, float m0, float m1, float m2) {
-    if (id < (unsigned)RG_LCAP) {
-      atomicAdd(&L.hist[id * 3], (unsigned long long)region_fix(m0, sc.S));
-      atomicAdd(&L.hist[id * 3 + 1], (unsigned long long)region_fix(m1, sc.S));
-      atomicAdd(&L.hist[id * 3 + 2], (unsigned long long)region_fix(m2, sc.S));
-    } else if (id != RG_NONE) {                                     // a region beyond the LDS-resident ones: global memory
-      atomicAdd(&HIST[id * 3], (unsigned long long)region_fix(m0, Sg));
-      atomicAdd(&HIST[id * 3 + 1], (unsigned long long)region_fix(m1, Sg));
-      atomicAdd(&HIST[id * 3 + 2], (unsigned long long)region_fix(m2, Sg));
+  // The current run of this lane: its region, the three moment sums of d bias and the two sums of d bias * d p / d offset (d vs of a run is
+  // -slope of the region * that sum: the slope is read once per run, not per pair).  cur >= RG_NONE: no run (start, pair without a region).
+  unsigned cur = ~0u;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f, u0 = 0.f, u1 = 0.f;
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+  lds_u64* const hist_l = (lds_u64*)L.hist;
+  glb_u64* const hist_g = (glb_u64*)HIST;
+  auto flush = [&]() {
+    if (cur < (unsigned)RG_LCAP) {
+      const float2 a = L.reg2[cur];
+      dv0 = fmaf(-a.x, u0, dv0); dv1 = fmaf(-a.y, u1, dv1);
+      lds_u64* hp = hist_l + cur * 3;
+      __hip_atomic_fetch_add(hp, (unsigned long long)region_fix(r0, sc.S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(hp + 1, (unsigned long long)region_fix(r1, sc.S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(hp + 2, (unsigned long long)region_fix(r2, sc.S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (cur < (unsigned)RG_NONE) {                           // a region beyond the LDS-resident ones: global memory
+      const float4 a = rv.reg[cur];
+      dv0 = fmaf(-a.x, u0, dv0); dv1 = fmaf(-a.y, u1, dv1);
+      glb_u64* hp = hist_g + cur * 3;
+      __hip_atomic_fetch_add(hp, (unsigned long long)region_fix(r0, Sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(hp + 1, (unsigned long long)region_fix(r1, Sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(hp + 2, (unsigned long long)region_fix(r2, Sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
   float4 dbn[8];
   uint4 ridn[4];
+  float2 gqn;                                                       // lane c: position of query c of the tile (one coalesced load per tile)
   auto fetch = [&](int tile) {
     const size_t row = ((size_t)(b * H + h) * NST + (size_t)tile * QT) * J + (size_t)keyc * 32;   // [B, H, nst / 32, J, 32]: this key's 32 queries of the tile
     const float4* dp = reinterpret_cast<const float4*>(dLT + row);
@@ -916,10 +932,11 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     for (int i = 0; i < 8; ++i) dbn[i] = dp[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ridn[i] = rp[i];
+    gqn = reinterpret_cast<const float2*>(GQ)[min(tile * QT + c, N - 1)];
   };
   if (t_begin + tslot < t_end) fetch(t_begin + tslot);
   for (int tile = t_begin + tslot; tile < t_end; tile += wpk) {
-    const int q0 = tile * QT;
+    const int q0 = __builtin_amdgcn_readfirstlane(tile) * QT;        // (the compiler keeps the loop counter in a vector register)
     const int nq = min(QT, N - q0);
     float dbr[32];
     unsigned ridw[16];
@@ -927,35 +944,39 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     for (int i = 0; i < 8; ++i) { dbr[4 * i] = dbn[i].x; dbr[4 * i + 1] = dbn[i].y; dbr[4 * i + 2] = dbn[i].z; dbr[4 * i + 3] = dbn[i].w; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ridw[4 * i] = ridn[i].x; ridw[4 * i + 1] = ridn[i].y; ridw[4 * i + 2] = ridn[i].z; ridw[4 * i + 3] = ridn[i].w; }
+    if (!kvalid) {                                                  // lanes beyond the last key: no region, nothing accumulated
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ridw[i] = 0xFFFFFFFFu;
+    }
+    const int gqx = __float_as_int(gqn.x), gqy = __float_as_int(gqn.y);
     if (tile + wpk < t_end) fetch(tile + wpk);                      // the next tile's rows, in flight during this tile's 32 queries
     unsigned nonemask = 0u;                                         // bit q: this key's pair with query q0 + q has no region
+    int gy_prev = 0;
+    float p1 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-      if (q < nq) {                                                 // uniform
-        const float gx = GQ[(size_t)(q0 + q) * 2], gy = GQ[(size_t)(q0 + q) * 2 + 1];
-        const float d0 = gx - vs0, d1 = gy - vs1;
-        const float p0 = slog1p(d0), p1 = slog1p(d1);
-        const float s0 = dpos_of<false>(d0, big), s1 = dpos_of<false>(d1, big);
-        const unsigned id = kvalid ? ((ridw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) : RG_NONE;
-        const float dbv = kvalid ? dbr[q] : 0.f;
+      if (q < nq) {                                                 // scalar
+        const int gxb = __builtin_amdgcn_readlane(gqx, q), gyb = __builtin_amdgcn_readlane(gqy, q);
+        const float d0 = __int_as_float(gxb) - vs0;
+        const float p0 = slog1p(d0), s0 = dpos_of<false>(d0, big);
+        if (q == 0 || gyb != gy_prev) {                             // scalar: the second coordinate changes once per row of the query grid
+          const float d1 = __int_as_float(gyb) - vs1;
+          p1 = slog1p(d1); s1 = dpos_of<false>(d1, big);
+          gy_prev = gyb;
+        }
+        const unsigned id = (ridw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        const float dbv = dbr[q];
         if (id != cur) {                                            // the run ends: its sums go to the region's accumulators
-          flush(cur, r0, r1, r2);
-          cur = id; r0 = 0.f; r1 = 0.f; r2 = 0.f;
+          flush();
+          if (id == RG_NONE) { nonemask |= 1u << q; cur = ~0u; }    // (the next pair starts a run whatever its id)
+          else cur = id;
+          r0 = 0.f; r1 = 0.f; r2 = 0.f; u0 = 0.f; u1 = 0.f;
         }
         r0 += dbv; r1 = fmaf(dbv, p0, r1); r2 = fmaf(dbv, p1, r2);
-        float a0 = 0.f, a1 = 0.f;
-        if (id < (unsigned)RG_LCAP) {
-          const float2 a = L.reg2[id];
-          a0 = a.x; a1 = a.y;
-        } else if (id != RG_NONE) {
-          const float4 a = rv.reg[id];
-          a0 = a.x; a1 = a.y;
-        }
-        nonemask |= (kvalid && id == RG_NONE) ? (1u << q) : 0u;
-        dv0 = fmaf(-dbv * a0, s0, dv0);
-        dv1 = fmaf(-dbv * a1, s1, dv1);
+        u0 = fmaf(dbv, s0, u0); u1 = fmaf(dbv, s1, u1);
       }
     }
+    if (!kvalid) nonemask = 0u;
     // pairs without a region (~1e-4 of all): the MLP's own backward for that pair, by the whole wave - outside the unrolled loop
     for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
       const int l = __ffsll((long long)todo) - 1;
@@ -997,7 +1018,7 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
       }
     }
   }
-  flush(cur, r0, r1, r2);
+  flush();
   L.dvs[wave][lane] = make_float2(dv0, dv1);
   __syncthreads();
   // d vs of this chunk: the wpk waves of a key block in a fixed order -> slab [chunk][b, h][J]
