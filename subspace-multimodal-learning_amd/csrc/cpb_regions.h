@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 
   floatx16 oacc0 = {0}, oacc1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
+  const unsigned long long drop_row = dc.seed + ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1);   // dropout counter of the row's first pair
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
   float* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;    // this wave's [J][32] block (layout: deform_attn_fwd_kernel)
@@ -610,16 +611,20 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   };
   fetch_kv(0);
   const int ntiles = (J + KT - 1) / KT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int j0 = kt * KT;
-    // position bias of this lane's 16 (key, query) pairs, register r <-> key acc_row(r, hf).  Step 1, before anything else of the
-    // tile: the signed-log offsets and the gathers of the 16 cell codes - they are in flight during the staging of K / V, the barrier
-    // and the S^T products (the sample positions of a tile are staged one tile ahead).
-    float p0[16], p1[16];
-    unsigned ent[16];
+  // Position bias of this lane's 16 (key, query) pairs of a tile, register r <-> key acc_row(r, hf).  The lookup is a chain of up to three
+  // dependent gathers (cell code -> sub-cell code of a refined cell -> kink record); each link is issued one program phase ahead of its
+  // use so that its L2 round trip passes behind other work:
+  //   step 1 (signed-log offsets, the 16 cell codes): for tile kt + 1 at the end of tile kt's lookups - in flight during the softmax and
+  //           the P V products (the sample positions of a tile are staged one tile ahead);
+  //   step 2a (sub-cell codes of the refined cells): at the top of the tile - in flight during the staging of K / V, the barriers and
+  //           the S^T products;
+  //   step 2b (kink records) after the S^T products: the one link still waited for in place (0.07 ms of the kernel).
+  float p0[16], p1[16];
+  unsigned ent[16];
+  auto step1 = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float2 vv = *reinterpret_cast<const float2*>(&vsl[kt & 1][acc_row(r, hf)][0]);
+      const float2 vv = *reinterpret_cast<const float2*>(&vsl[buf][acc_row(r, hf)][0]);
 #if SMML_RGN_EXP == 5
       p0[r] = (gq0 - vv.x) * 0.5f; p1[r] = (gq1 - vv.y) * 0.5f;
 #else
@@ -631,6 +636,26 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       ent[r] = region_cell_index(fmaf(p0[r], cs, co), fmaf(p1[r], cs, co), cx, cy) & 1023u;
 #else
       ent[r] = rv.t0[region_cell_index(fmaf(p0[r], cs, co), fmaf(p1[r], cs, co), cx, cy)];
+#endif
+    }
+  };
+  step1(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT;
+    // Step 2a: code -> region in STAGES, each stage's gathers issued together (a dependent gather inside a per-pair branch would expose
+    // one L2 round trip per pair: measured 2 ms of this kernel's 3.2).  Refined cells (0.7 % of the pairs) take their sub-cell's code.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {             // issue: the sub-cell codes of the refined cells, into the code's own register (none is
+      const unsigned e = ent[r];               // consumed inside this loop; a third of the (wave, pair) steps have a lane that takes one)
+#if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
+      if (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) {
+        const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
+        int cx, cy;
+        region_cell_index(u0, u1, cx, cy);
+        const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
+        const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
+        ent[r] = rv.t1[(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx];
+      }
 #endif
     }
     lds_barrier();                                     // every wave is done with the previous tile's K / V images
@@ -657,37 +682,16 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       s = mfma16(kh, qh[st], s);
     }
 
-    // Step 2: code -> region -> a . p + c, eight pairs at a time and in STAGES, each stage's gathers issued together (a dependent
-    // gather inside a per-pair branch would expose one L2 round trip per pair: measured 2 ms of this kernel's 3.2):
-    //   (a) refined cells (0.7 % of the pairs) take their sub-cell's code; (b) the records of the one-kink cells (8 %) - every lane
-    //   reads one (record 0 where it needs none: one address, no traffic); (c) the side of the kink, the region's (a, c) from LDS.
+    // Step 2b, eight pairs at a time: the records of the one-kink cells (8 %) - every lane reads one (record 0 where it needs none: one
+    // address, no traffic); then the side of the kink and the region's (a, c) from LDS.
     const int nk = min(KT, J - j0);
     unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
-    unsigned e1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {             // (a) issue: the sub-cell codes of the refined cells (none is consumed inside this loop)
-      const unsigned e = ent[r];
-      e1[r] = 0u;
-#if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
-      const bool sub = e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0;
-      if (__ballot(sub)) {                     // wave-uniform: a third of the (wave, pair) steps
-        const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
-        int cx, cy;
-        region_cell_index(u0, u1, cx, cy);
-        const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
-        const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
-        e1[r] = rv.t1[sub ? (size_t)(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx : (size_t)0];
-      }
-#endif
-    }
+    unsigned farmask = 0u;                     // bit r: pair r's region is not LDS-resident
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
       unsigned e8[8];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const unsigned e = ent[8 * g8 + r8];
-        e8[r8] = (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) ? e1[8 * g8 + r8] : e;
-      }
+      for (int r8 = 0; r8 < 8; ++r8) e8[r8] = ent[8 * g8 + r8];
       float4 rec8[8];
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
@@ -707,22 +711,30 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         const unsigned es = e8[r8] - RG_E_EDGE0;
         const unsigned id = es < (unsigned)RG_EDGES ? region_side(rec8[r8], p0[r], p1[r]) : e8[r8];    // region ids and 0xFFFF pass through
 #endif
-        float bias = 0.f;
-        if (id < (unsigned)RG_LCAP) {
+        // (a, c) of the region from LDS, no branch: ids beyond the LDS-resident regions (and "no region") read entry 0 and are fixed up
+        // below, outside the unrolled loop
+        const bool inl = id < (unsigned)RG_LCAP;
 #if SMML_RGN_EXP == 6
-          const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
+        const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
 #else
-          const float4 ac = regl[id];
+        const float4 ac = regl[inl ? id : 0u];
 #endif
-          bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
-        } else if (id != RG_NONE) {
-          const float4 ac = rv.reg[id];
-          bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
-        }
+        const float bias = inl ? fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z)) : 0.f;
         const bool kin = acc_row(r, hf) < nk;
         nonemask |= (id == RG_NONE && kin) ? (1u << r) : 0u;
-        if (SAVE) ridl[wave][acc_row(r, hf)][c] = (unsigned short)id;
+        farmask |= (!inl && id != RG_NONE && kin) ? (1u << r) : 0u;
+        ridl[wave][acc_row(r, hf)][c] = (unsigned short)id;
         s[r] = kin ? s[r] + bias : -INFINITY;
+      }
+    }
+    if (__ballot(farmask != 0u)) {             // regions beyond the LDS-resident ones (none for up to RG_LCAP regions): from global memory
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((farmask >> r) & 1u) {
+          const float4 ac = rv.reg[ridl[wave][acc_row(r, hf)][c]];
+          s[r] += fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
+        }
       }
     }
     if (SAVE) {
@@ -743,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     // behind the one they wait for - behind branches the compiler has to assume the fewest, so younger loads in flight there would be
     // waited for as well (measured: 0.8 ms of this kernel with the prefetch in front of the lookup stages)
     fetch_kv(j0 + KT);
+    if (kt + 1 < ntiles) step1((kt + 1) & 1);  // the next tile's offsets and cell codes (its sample positions were staged above)
     // pairs without a region (~1e-4 of all): the MLP itself, one pair at a time, by the whole wave - outside the unrolled loops
     for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
       const int l = __ffsll((long long)todo) - 1;
@@ -761,10 +774,13 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     unsigned keepbits = 0xFFFFu;              // dropout decisions of this lane's 16 keys (bit r)
     if (dc.thresh) {
-      const unsigned long long base2 = ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1) + (j0 >> 1);
+      // z of the lane's first pair of the tile, pinned in a register pair: the eight pairs are compile-time steps from it (left to itself
+      // the compiler hoists eight loop-invariant 64-bit sums out of the tile loop and spills them)
+      unsigned long long z0 = drop_row + (unsigned)((j0 >> 1) + 2 * hf);
+      asm volatile("" : "+v"(z0));
       keepbits = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) keepbits |= drop_keep2(dc, base2 + (acc_row(r, hf) >> 1)) << r;
+      for (int r = 0; r < 16; r += 2) keepbits |= drop_keep2_z(dc, z0 + (unsigned)(acc_row(r, 0) >> 1)) << r;
     }
     if (SAVE) {                               // rows are padded to whole workgroup tiles: lanes past N write padding
       if (dc.thresh) {

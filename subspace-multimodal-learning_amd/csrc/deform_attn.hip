@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         float dpr = dp[r];
         if (dc.thresh) dpr *= stashed_factor(ltc[r], dc.keep_scale);          // the forward's decision rides in the score's lowest bit
         const float v = p * (dpr - delta);
+#if !SMML_EXP_NODLT
         dLTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = v;
+#endif
         ds[r] = v;
         rho += v;
         amax = fmaxf(amax, fabsf(v));
@@ -620,7 +622,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
     for (int rg = 0; rg < 4; ++rg) {
       const size_t qq = (size_t)q0 * J + 8 * rg + 4 * hf;   // tile q0 / 32 -> (q0 / 32) J 32 floats; 4 consecutive queries of the tile
       ltr[rg] = *reinterpret_cast<const float4*>(LTk + qq);
+#if SMML_EXP_NODLT
+      dlr[rg] = ltr[rg];
+#else
       dlr[rg] = *reinterpret_cast<const float4*>(dLTk + qq);
+#endif
     }
     if (tid < QT) lsereg = LSEb[min(q0 + tid, N - 1)];
   };

@@ -235,6 +235,11 @@ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned 
 // One hash serves the TWO keys 2 jp, 2 jp + 1 of a (bag, head, query) row: its low / high 16 bits are compared with the 16-bit threshold
 // p 2^16 (the drop rate is p to 2^-16; keep_scale uses the rate actually applied).  Pair index = row * ceil(J / 2) + jp.  Halves the
 // mixer work of the forward (the backward passes read the decision from the saved score); -> bit 0: key 2 jp, bit 1: key 2 jp + 1
+// the same decision pair from z = seed + pair index formed by the caller (one 64-bit add per tile, compile-time steps between its pairs)
+__device__ __forceinline__ unsigned drop_keep2_z(const DropCfg& dc, unsigned long long z) {
+  const unsigned h = drop_hash(0ull, z);
+  return ((h & 0xFFFFu) >= dc.thresh ? 1u : 0u) | ((h >> 16) >= dc.thresh ? 2u : 0u);
+}
 __device__ __forceinline__ unsigned drop_keep2(const DropCfg& dc, unsigned long long pair_idx) {
   const unsigned h = drop_hash(dc.seed, pair_idx);
   return ((h & 0xFFFFu) >= dc.thresh ? 1u : 0u) | ((h >> 16) >= dc.thresh ? 2u : 0u);
