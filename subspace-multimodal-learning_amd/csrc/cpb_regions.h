@@ -708,8 +708,12 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #if SMML_RGN_EXP == 2
         const unsigned id = ent[r] & 1023u;
 #else
+        // side of the kink for every lane (record 0 where the code is no record), merged by a bit mask: some lane of the wave needs the
+        // record in 99 % of the steps, so a branch around the three multiply-adds never skips them - and the compiler would move the
+        // record's load into that branch, one exposed round trip per pair
         const unsigned es = e8[r8] - RG_E_EDGE0;
-        const unsigned id = es < (unsigned)RG_EDGES ? region_side(rec8[r8], p0[r], p1[r]) : e8[r8];    // region ids and 0xFFFF pass through
+        const unsigned em = es < (unsigned)RG_EDGES ? 0xFFFFFFFFu : 0u;
+        const unsigned id = (region_side(rec8[r8], p0[r], p1[r]) & em) | (e8[r8] & ~em);    // region ids and 0xFFFF pass through
 #endif
         // (a, c) of the region from LDS, no branch: ids beyond the LDS-resident regions (and "no region") read entry 0 and are fixed up
         // below, outside the unrolled loop
@@ -717,9 +721,9 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #if SMML_RGN_EXP == 6
         const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
 #else
-        const float4 ac = regl[inl ? id : 0u];
+        const float4 ac = regl[id & (unsigned)(RG_LCAP - 1)];
 #endif
-        const float bias = inl ? fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z)) : 0.f;
+        const float bias = __uint_as_float(__float_as_uint(fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z))) & (inl ? 0xFFFFFFFFu : 0u));
         const bool kin = acc_row(r, hf) < nk;
         nonemask |= (id == RG_NONE && kin) ? (1u << r) : 0u;
         farmask |= (!inl && id != RG_NONE && kin) ? (1u << r) : 0u;
