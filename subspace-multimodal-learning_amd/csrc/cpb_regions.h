@@ -27,6 +27,15 @@
 
 namespace {
 
+#ifndef SMML_FWD_MAXID
+#define SMML_FWD_MAXID 0
+#endif
+#ifndef SMML_FWD_LASTTILE
+#define SMML_FWD_LASTTILE 1
+#endif
+#ifndef SMML_FWD_TRUNC
+#define SMML_FWD_TRUNC 1
+#endif
 #ifndef SMML_RGN_EXP
 #define SMML_RGN_EXP 0                   // measurement variants of the region forward (tests/build_variants.py): 1 no cell gather, 2 no record /
 #endif                                   // sub-cell resolution, 3 no score store, 4 no region-id store, 5 no signed logs, 6 no LDS (a, c) read
@@ -685,8 +694,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     // Step 2b, eight pairs at a time: the records of the one-kink cells (8 %) - every lane reads one (record 0 where it needs none: one
     // address, no traffic); then the side of the kink and the region's (a, c) from LDS.
     const int nk = min(KT, J - j0);
-    unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
-    unsigned farmask = 0u;                     // bit r: pair r's region is not LDS-resident
+    unsigned maxid = 0u;                       // largest region id of this lane's pairs: >= RG_LCAP <-> a pair without an LDS-resident region
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
       unsigned e8[8];
@@ -715,28 +723,42 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         const unsigned em = es < (unsigned)RG_EDGES ? 0xFFFFFFFFu : 0u;
         const unsigned id = (region_side(rec8[r8], p0[r], p1[r]) & em) | (e8[r8] & ~em);    // region ids and 0xFFFF pass through
 #endif
-        // (a, c) of the region from LDS, no branch: ids beyond the LDS-resident regions (and "no region") read entry 0 and are fixed up
-        // below, outside the unrolled loop
+        // (a, c) of the region from LDS, no branch.  Ids beyond the LDS-resident regions and "no region" (~1e-4 of the pairs) read some
+        // entry and add nothing here; the running maximum of the ids tells the wave afterwards whether it has such a pair at all
         const bool inl = id < (unsigned)RG_LCAP;
 #if SMML_RGN_EXP == 6
         const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
 #else
         const float4 ac = regl[id & (unsigned)(RG_LCAP - 1)];
 #endif
-        const float bias = __uint_as_float(__float_as_uint(fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z))) & (inl ? 0xFFFFFFFFu : 0u));
-        const bool kin = acc_row(r, hf) < nk;
-        nonemask |= (id == RG_NONE && kin) ? (1u << r) : 0u;
-        farmask |= (!inl && id != RG_NONE && kin) ? (1u << r) : 0u;
+        const float bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
+#if SMML_FWD_MAXID
+        maxid = max(maxid, id);
+#else
+        maxid |= (!inl && acc_row(r, hf) < nk) ? (1u << r) : 0u;
+#endif
         ridl[wave][acc_row(r, hf)][c] = (unsigned short)id;
-        s[r] = kin ? s[r] + bias : -INFINITY;
+#if SMML_FWD_LASTTILE
+        s[r] += inl ? bias : 0.f;
+#else
+        s[r] = acc_row(r, hf) < nk ? s[r] + (inl ? bias : 0.f) : -INFINITY;
+#endif
       }
     }
-    if (__ballot(farmask != 0u)) {             // regions beyond the LDS-resident ones (none for up to RG_LCAP regions): from global memory
+    unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
+#if SMML_FWD_MAXID
+    if (__ballot(maxid >= (unsigned)RG_LCAP)) {      // a tenth of the (wave, tile) steps: which pairs, from the wave's id image
+#else
+    if (__ballot(maxid != 0u)) {
+#endif
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if ((farmask >> r) & 1u) {
-          const float4 ac = rv.reg[ridl[wave][acc_row(r, hf)][c]];
+        const unsigned idr = ridl[wave][acc_row(r, hf)][c];
+        const bool kin = acc_row(r, hf) < nk;
+        if (idr == RG_NONE) nonemask |= kin ? (1u << r) : 0u;
+        else if (idr >= (unsigned)RG_LCAP) {   // a region beyond the LDS-resident ones (none for up to RG_LCAP regions): from global memory
+          const float4 ac = rv.reg[idr];
           s[r] += fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
         }
       }
@@ -754,12 +776,6 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       }
       wave_lds_fence();
     }
-    // the next tile's K / V rows (and the sample positions of the tile after it): in flight during the softmax, the P V products and
-    // the next tile's first step.  Issued only now: vector-memory operations retire in order and the waits above count the operations
-    // behind the one they wait for - behind branches the compiler has to assume the fewest, so younger loads in flight there would be
-    // waited for as well (measured: 0.8 ms of this kernel with the prefetch in front of the lookup stages)
-    fetch_kv(j0 + KT);
-    if (kt + 1 < ntiles) step1((kt + 1) & 1);  // the next tile's offsets and cell codes (its sample positions were staged above)
     // pairs without a region (~1e-4 of all): the MLP itself, one pair at a time, by the whole wave - outside the unrolled loops
     for (unsigned long long todo = __ballot(nonemask != 0u); todo; todo &= todo - 1) {
       const int l = __ffsll((long long)todo) - 1;
@@ -772,6 +788,10 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) s[rr] += (rr == r && lane == l) ? v : 0.f;
       }
+    }
+    if (SMML_FWD_LASTTILE && nk < KT) {       // last tile (uniform): keys past J take no part
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = acc_row(r, hf) < nk ? s[r] : -INFINITY;
     }
     float tmax = -INFINITY;
 #pragma unroll
@@ -791,16 +811,30 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (acc_row(r, hf) < nk) s[r] = stash_keep(s[r], (keepbits >> r) & 1u);
+          if (nk == KT || acc_row(r, hf) < nk) s[r] = SMML_FWD_TRUNC ? stash_keep_trunc(s[r], (keepbits >> r) & 1u) : stash_keep(s[r], (keepbits >> r) & 1u);      // finite scores only
           tmax = fmaxf(tmax, s[r]);
         }
       }
+      if (nk == KT) {                         // interior tile (uniform): no bounds branches around the stores
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = acc_row(r, hf);
-        if (key < nk && SMML_RGN_EXP != 3) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
+        for (int r = 0; r < 16; ++r) if (SMML_RGN_EXP != 3) LTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = s[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = acc_row(r, hf);
+          if (key < nk && SMML_RGN_EXP != 3) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
+        }
       }
     }
+    // The next tile's K / V rows (and the sample positions of the tile after it) and its cell codes: in flight during the softmax, the
+    // P V products and the top of the next tile.  Vector-memory operations - loads AND stores - retire in the order of issue, and a wait
+    // counts the operations behind the one it waits for:
+    //   * issued in front of the lookup stages the prefetch would be waited for with the gathers (behind branches the compiler has to
+    //     assume the fewest operations in between; measured: 0.8 ms of this kernel);
+    //   * issued in front of the score stores, the stores would be the youngest operations at the top of the next tile and its first
+    //     wait (for the cell codes) would be a wait for their completion as well (measured: 0.1 ms).
+    fetch_kv(j0 + KT);
+    if (kt + 1 < ntiles) step1((kt + 1) & 1);  // (the next tile's sample positions were staged above)
     tmax = xhalf_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = sexp(m_run - m_new);

@@ -255,6 +255,11 @@ __device__ __forceinline__ float stash_keep(float x, bool keep) {
   const int dir = (u & 0x7FFFFFFEu) ? (int)(u & 2u) - 1 : 1;            // +1 / -1: independent of the decision (never below +-0)
   return __builtin_bit_cast(float, u + (unsigned)(flip ? dir : 0));
 }
+// one-instruction form (the region forward is bound by its vector instructions): the lowest bit is REPLACED by the decision - the score
+// moves by at most one ulp toward zero (2^-24 relative, against the 1e-4 parity gate); the backward passes read the bit the same way
+__device__ __forceinline__ float stash_keep_trunc(float x, unsigned keep) {
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & 0xFFFFFFFEu) | keep);
+}
 __device__ __forceinline__ float stashed_factor(float x, float keep_scale) {
   return (__builtin_bit_cast(unsigned, x) & 1u) ? keep_scale : 0.f;
 }
