@@ -27,15 +27,6 @@
 
 namespace {
 
-#ifndef SMML_FWD_MAXID
-#define SMML_FWD_MAXID 0
-#endif
-#ifndef SMML_FWD_LASTTILE
-#define SMML_FWD_LASTTILE 1
-#endif
-#ifndef SMML_FWD_TRUNC
-#define SMML_FWD_TRUNC 1
-#endif
 #ifndef SMML_RGN_EXP
 #define SMML_RGN_EXP 0                   // measurement variants of the region forward (tests/build_variants.py): 1 no cell gather, 2 no record /
 #endif                                   // sub-cell resolution, 3 no score store, 4 no region-id store, 5 no signed logs, 6 no LDS (a, c) read
@@ -658,12 +649,12 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       const unsigned e = ent[r];               // consumed inside this loop; a third of the (wave, pair) steps have a lane that takes one)
 #if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
       if (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) {
-        const float u0 = fmaf(p0[r], cs, co), u1 = fmaf(p1[r], cs, co);
-        int cx, cy;
-        region_cell_index(u0, u1, cx, cy);
-        const int sx = min(max((int)((u0 - (float)cx) * (float)RG_SUB), 0), RG_SUB - 1);
-        const int sy = min(max((int)((u1 - (float)cy) * (float)RG_SUB), 0), RG_SUB - 1);
-        ent[r] = rv.t1[(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + sy * RG_SUB + sx];
+        // sub-cell of p: the low bits of floor(RG_SUB u) clamped to the grid - the same cell as clamp(floor(RG_SUB (u - cell)), 0, RG_SUB - 1)
+        // of the table build (RG_SUB u is exact: a power-of-two multiple; inside the grid u - cell is exact too, outside both clamp to
+        // the border sub-cell), in half the instructions
+        const int X = min(max((int)fmaf(p0[r], cs * (float)RG_SUB, co * (float)RG_SUB), 0), RG_G * RG_SUB - 1);
+        const int Y = min(max((int)fmaf(p1[r], cs * (float)RG_SUB, co * (float)RG_SUB), 0), RG_G * RG_SUB - 1);
+        ent[r] = rv.t1[(e - RG_E_SUB0) * (RG_SUB * RG_SUB) + (Y & (RG_SUB - 1)) * RG_SUB + (X & (RG_SUB - 1))];
       }
 #endif
     }
@@ -680,6 +671,25 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     if (tid < KT) { vsl[(kt + 1) & 1][tid][0] = vsn.x; vsl[(kt + 1) & 1][tid][1] = vsn.y; }     // the NEXT tile's sample positions
     lds_barrier();
 
+    // Step 2b: the records of the one-kink cells (8 % of the pairs) - every lane reads one per pair (record 0 where it needs none: one
+    // address, no traffic), four pairs at a time, double-buffered: group 0 is requested in front of the S^T products, group g + 1 before
+    // group g is consumed.  The scheduling barriers pin that order: left to itself the scheduler moves some of the loads down to their
+    // uses, one exposed round trip each - which ones changes with unrelated edits (+-5 % of the kernel).
+    float4 rec[2][4];
+    auto rec_issue = [&](int g, float4 (&dst)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned es = ent[4 * g + i] - RG_E_EDGE0;
+#if SMML_RGN_EXP == 8
+        dst[i] = make_float4(__uint_as_float(es), 1.f, 0.5f, __uint_as_float(0x00010002u));
+#else
+        dst[i] = rv.edge[es < (unsigned)RG_EDGES ? es : 0u];
+#endif
+      }
+    };
+    rec_issue(0, rec[0]);
+    __builtin_amdgcn_sched_barrier(0);
+
     // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
 #pragma unroll
@@ -691,40 +701,27 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       s = mfma16(kh, qh[st], s);
     }
 
-    // Step 2b, eight pairs at a time: the records of the one-kink cells (8 %) - every lane reads one (record 0 where it needs none: one
-    // address, no traffic); then the side of the kink and the region's (a, c) from LDS.
     const int nk = min(KT, J - j0);
-    unsigned maxid = 0u;                       // largest region id of this lane's pairs: >= RG_LCAP <-> a pair without an LDS-resident region
+    unsigned spec = 0u;                        // bit r: pair r has no LDS-resident region (no region at all, or one beyond RG_LCAP)
 #pragma unroll
-    for (int g8 = 0; g8 < 2; ++g8) {
-      unsigned e8[8];
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) rec_issue(g + 1, rec[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) e8[r8] = ent[8 * g8 + r8];
-      float4 rec8[8];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const unsigned es = e8[r8] - RG_E_EDGE0;
-#if SMML_RGN_EXP == 8
-        rec8[r8] = make_float4(__uint_as_float(es), 1.f, 0.5f, __uint_as_float(0x00010002u));
-#else
-        rec8[r8] = rv.edge[es < (unsigned)RG_EDGES ? es : 0u];
-#endif
-      }
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = 8 * g8 + r8;
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const unsigned e = ent[r];
 #if SMML_RGN_EXP == 2
-        const unsigned id = ent[r] & 1023u;
+        const unsigned id = e & 1023u;
 #else
         // side of the kink for every lane (record 0 where the code is no record), merged by a bit mask: some lane of the wave needs the
         // record in 99 % of the steps, so a branch around the three multiply-adds never skips them - and the compiler would move the
-        // record's load into that branch, one exposed round trip per pair
-        const unsigned es = e8[r8] - RG_E_EDGE0;
-        const unsigned em = es < (unsigned)RG_EDGES ? 0xFFFFFFFFu : 0u;
-        const unsigned id = (region_side(rec8[r8], p0[r], p1[r]) & em) | (e8[r8] & ~em);    // region ids and 0xFFFF pass through
+        // record's load into that branch
+        const unsigned em = (e - RG_E_EDGE0) < (unsigned)RG_EDGES ? 0xFFFFFFFFu : 0u;
+        const unsigned id = (region_side(rec[g & 1][i], p0[r], p1[r]) & em) | (e & ~em);    // region ids and 0xFFFF pass through
 #endif
         // (a, c) of the region from LDS, no branch.  Ids beyond the LDS-resident regions and "no region" (~1e-4 of the pairs) read some
-        // entry and add nothing here; the running maximum of the ids tells the wave afterwards whether it has such a pair at all
+        // entry and add nothing here; `spec` tells the wave afterwards whether it has such a pair at all
         const bool inl = id < (unsigned)RG_LCAP;
 #if SMML_RGN_EXP == 6
         const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
@@ -732,25 +729,14 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         const float4 ac = regl[id & (unsigned)(RG_LCAP - 1)];
 #endif
         const float bias = fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
-#if SMML_FWD_MAXID
-        maxid = max(maxid, id);
-#else
-        maxid |= (!inl && acc_row(r, hf) < nk) ? (1u << r) : 0u;
-#endif
+        spec |= (!inl && acc_row(r, hf) < nk) ? (1u << r) : 0u;
         ridl[wave][acc_row(r, hf)][c] = (unsigned short)id;
-#if SMML_FWD_LASTTILE
         s[r] += inl ? bias : 0.f;
-#else
-        s[r] = acc_row(r, hf) < nk ? s[r] + (inl ? bias : 0.f) : -INFINITY;
-#endif
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     unsigned nonemask = 0u;                    // bit r: pair r has no region (evaluates the MLP below)
-#if SMML_FWD_MAXID
-    if (__ballot(maxid >= (unsigned)RG_LCAP)) {      // a tenth of the (wave, tile) steps: which pairs, from the wave's id image
-#else
-    if (__ballot(maxid != 0u)) {
-#endif
+    if (__ballot(spec != 0u)) {                // a tenth of the (wave, tile) steps: which pairs, from the wave's id image
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -789,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         for (int rr = 0; rr < 16; ++rr) s[rr] += (rr == r && lane == l) ? v : 0.f;
       }
     }
-    if (SMML_FWD_LASTTILE && nk < KT) {       // last tile (uniform): keys past J take no part
+    if (nk < KT) {                            // last tile (uniform): keys past J take no part
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = acc_row(r, hf) < nk ? s[r] : -INFINITY;
     }
@@ -811,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (nk == KT || acc_row(r, hf) < nk) s[r] = SMML_FWD_TRUNC ? stash_keep_trunc(s[r], (keepbits >> r) & 1u) : stash_keep(s[r], (keepbits >> r) & 1u);      // finite scores only
+          if (nk == KT || acc_row(r, hf) < nk) s[r] = stash_keep_trunc(s[r], (keepbits >> r) & 1u);      // finite scores only
           tmax = fmaxf(tmax, s[r]);
         }
       }

@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out/r5
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-A="--steps 2 --warmup 1 --no-cpu-baseline --no-nystrom --no-traffic --no-deform16 --no-dp-overhead ${BENCH_ARGS:-}"
+A="--steps 3 --warmup 2 --no-cpu-baseline --no-nystrom --no-traffic --no-deform16 --no-dp-overhead ${BENCH_ARGS:-}"
 run() { # tag counters...
   local tag=$1; shift
   rm -rf gpurun_out/r5/pmc_$tag
