@@ -612,13 +612,13 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   fetch_kv(0);
   const int ntiles = (J + KT - 1) / KT;
   // Position bias of this lane's 16 (key, query) pairs of a tile, register r <-> key acc_row(r, hf).  The lookup is a chain of up to three
-  // dependent gathers (cell code -> sub-cell code of a refined cell -> kink record); each link is issued one program phase ahead of its
-  // use so that its L2 round trip passes behind other work:
-  //   step 1 (signed-log offsets, the 16 cell codes): for tile kt + 1 at the end of tile kt's lookups - in flight during the softmax and
-  //           the P V products (the sample positions of a tile are staged one tile ahead);
-  //   step 2a (sub-cell codes of the refined cells): at the top of the tile - in flight during the staging of K / V, the barriers and
-  //           the S^T products;
-  //   step 2b (kink records) after the S^T products: the one link still waited for in place (0.07 ms of the kernel).
+  // dependent gathers (cell code -> sub-cell code of a refined cell -> kink record); each link is issued a program phase ahead of its
+  // use so that its L2 round trip passes behind other work, in STAGES - all gathers of a link together (a dependent gather inside a
+  // per-pair branch exposes one round trip per pair: measured 2 ms of this kernel's first 3.2):
+  //   step 1  (signed-log offsets, the 16 cell codes) for tile kt + 1 behind tile kt's score stores - in flight during the softmax;
+  //   step 2a (sub-cell codes of the refined cells) for tile kt + 1 behind tile kt's softmax - in flight during the P V products;
+  //   step 2b (kink records), four pairs at a time and double-buffered: the first group at the top of the tile - in flight during the
+  //           staging of K / V, the barriers and the S^T products -, group g + 1 while group g is consumed.
   float p0[16], p1[16];
   unsigned ent[16];
   auto step1 = [&](int buf) {
@@ -639,14 +639,12 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #endif
     }
   };
-  step1(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int j0 = kt * KT;
-    // Step 2a: code -> region in STAGES, each stage's gathers issued together (a dependent gather inside a per-pair branch would expose
-    // one L2 round trip per pair: measured 2 ms of this kernel's 3.2).  Refined cells (0.7 % of the pairs) take their sub-cell's code.
+  // Step 2a: refined cells (0.7 % of the pairs) take their sub-cell's code, loaded into the cell code's own register (a third of the
+  // (wave, pair) steps have a lane that takes one; none is consumed here).
+  auto step2a = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {             // issue: the sub-cell codes of the refined cells, into the code's own register (none is
-      const unsigned e = ent[r];               // consumed inside this loop; a third of the (wave, pair) steps have a lane that takes one)
+    for (int r = 0; r < 16; ++r) {
+      const unsigned e = ent[r];
 #if SMML_RGN_EXP != 2 && SMML_RGN_EXP != 7
       if (e - RG_E_SUB0 < RG_E_EDGE0 - RG_E_SUB0) {
         // sub-cell of p: the low bits of floor(RG_SUB u) clamped to the grid - the same cell as clamp(floor(RG_SUB (u - cell)), 0, RG_SUB - 1)
@@ -658,6 +656,27 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       }
 #endif
     }
+  };
+  // Step 2b: the records of the one-kink cells (8 % of the pairs) - every lane reads one per pair (record 0 where it needs none: one
+  // address, no traffic), four pairs at a time, double-buffered.
+  float4 rec[2][4];
+  auto rec_issue = [&](int g, float4 (&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned es = ent[4 * g + i] - RG_E_EDGE0;
+#if SMML_RGN_EXP == 8
+      dst[i] = make_float4(__uint_as_float(es), 1.f, 0.5f, __uint_as_float(0x00010002u));
+#else
+      dst[i] = rv.edge[es < (unsigned)RG_EDGES ? es : 0u];
+#endif
+    }
+  };
+  step1(0);
+  step2a();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int j0 = kt * KT;
+    rec_issue(0, rec[0]);                      // (the sub-cell codes were requested in front of the previous tile's P V products)
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                                     // every wave is done with the previous tile's K / V images
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -670,25 +689,6 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     }
     if (tid < KT) { vsl[(kt + 1) & 1][tid][0] = vsn.x; vsl[(kt + 1) & 1][tid][1] = vsn.y; }     // the NEXT tile's sample positions
     lds_barrier();
-
-    // Step 2b: the records of the one-kink cells (8 % of the pairs) - every lane reads one per pair (record 0 where it needs none: one
-    // address, no traffic), four pairs at a time, double-buffered: group 0 is requested in front of the S^T products, group g + 1 before
-    // group g is consumed.  The scheduling barriers pin that order: left to itself the scheduler moves some of the loads down to their
-    // uses, one exposed round trip each - which ones changes with unrelated edits (+-5 % of the kernel).
-    float4 rec[2][4];
-    auto rec_issue = [&](int g, float4 (&dst)[4]) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned es = ent[4 * g + i] - RG_E_EDGE0;
-#if SMML_RGN_EXP == 8
-        dst[i] = make_float4(__uint_as_float(es), 1.f, 0.5f, __uint_as_float(0x00010002u));
-#else
-        dst[i] = rv.edge[es < (unsigned)RG_EDGES ? es : 0u];
-#endif
-      }
-    };
-    rec_issue(0, rec[0]);
-    __builtin_amdgcn_sched_barrier(0);
 
     // S^T[key, query] = K . (scale Q)^T
     floatx16 s = {0};
@@ -839,6 +839,8 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc0[r] *= alpha; oacc1[r] *= alpha; }
+    if (kt + 1 < ntiles) step2a();             // the next tile's sub-cell codes: in flight during the P V products
+    __builtin_amdgcn_sched_barrier(0);
 
     // O^T[d, query] += V^T . P^T
 #pragma unroll
