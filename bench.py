@@ -564,15 +564,19 @@ def main():
                                                         "note": "the reference's op count (2496 flop per pair: bias MLP 2240 + QK^T / PV 256) over this kernel's time - "
                                                                 "the kernel no longer executes the MLP's flops (one table lookup + 2 FMAs per pair)"},
                                "note": "achieved = algorithmic bytes (6 B per pair: saved score + region id; q / k / v / out once) / HIP-event time of the kernel, "
-                                       "against the HBM peak of MI355X_MICROARCH.md (8 TB/s; ~6.3 TB/s achievable).  What bounds it today is the latency of the "
-                                       "dependent table gathers at two waves per SIMD (WAIT_ANY 0.6-0.7 of wave cycles, profiles/r05_pmc_notes.md), not HBM."}
+                                       "against the HBM peak of MI355X_MICROARCH.md (8 TB/s; ~6.3 TB/s achievable).  What bounds it today is the issue of ~90 vector "
+                                       "instructions per pair (signed logs, cell index, kink record, region lookup, dropout hash, softmax, fp16 splits) at two "
+                                       "waves per SIMD (256 registers each), not HBM and no longer the latency of the table gathers "
+                                       "(profiles/r05_pmc_summary.txt, DESIGN.md section 5).",
+                               "limiter": "vector issue"}
             if "cpb_region_bwd" in kt:
                 n2, ms2, pairs2 = kt["cpb_region_bwd"]
                 b2 = pairs2 * 6 + B * H * J * 8 * 2
                 out["roofline_bwd"] = {"kernel": "cpb_region_bwd_kernel", "bound": "hbm", "achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": n2, "avg_ms": ms2, "algorithmic_bytes_per_launch": b2,
                                        "note": "position-bias backward per linear region: reads d score (4 B) + region id (2 B) per pair, three 64-bit integer LDS adds per "
-                                               "run of pairs in one region; bound by LDS atomics and vector issue, not by HBM"}
+                                               "run of pairs in one region; bound by vector issue (fp64 conversions of the run flushes) and LDS atomics, not by HBM",
+                                       "limiter": "vector issue + LDS atomics"}
         elif "cpb_bwd" in kt:
             n, ms, pairs = kt["cpb_bwd"]
             flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR           # backward = 2x forward flops (4480 per pair), recompute not counted
