@@ -11,7 +11,8 @@ per GPU: DeformCrossTransMIL forward (fc1 -> fusion -> LayerNorm -> 2-D deformab
 continuous position bias over a 100 x 100 token grid / 625 sampled keys -> pooler -> heads), cross-entropy +
 BatchLoss (gathered over ranks), backward, gradient all-reduce (RCCL), Adam step.  Inputs are resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0.
-After the timed region, at N = 1 only: `roofline.traffic` from two child runs of this script under rocprofv3 --pmc (FETCH_SIZE,
+After the timed region, at N = 1 only: `nystrom[1].kernel_counters` (per kernel of the 4 x 10 000 bf16 Nystrom leg: time, matrix-pipe busy
+share, HBM bytes - three rocprofv3 --pmc child runs of `--nystrom-child`) and `roofline.traffic` from two child runs of this script under rocprofv3 --pmc (FETCH_SIZE,
 WRITE_SIZE; --no-traffic skips them), the Nystrom legs (extra key `nystrom`; --no-nystrom), the CPU baseline (--no-cpu-baseline) and three more
 legs of the SAME step with the fused attention core in its 16-bit compute mode (--no-deform16 skips them; none is part of `value`):
   `deform16`         bf16 compute mode, per-pair position-bias MLP (parity-grade)
@@ -58,57 +59,127 @@ def measured_traffic(kernel, bags):
         return None
 
 
-def live_traffic(kernel_substr, argv_tail, timeout=150):
-    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, collected NOW: two child runs of this script under
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; the
-    children are started as subprocesses - nothing is exec'd from this GPU-initialised process).  gfx950 correction of the guide:
-    FETCH_SIZE counts 128-byte requests as 64 bytes (x 2 for wide coalesced reads); both counters are in KB.
-    -> (bytes per launch, note) or (None, reason)."""
-    import csv, glob, shutil, subprocess, tempfile
+def pmc_child_pass(counters, argv_tail, timeout=150):
+    """ONE child run of this script under `rocprofv3 --pmc <counters> --kernel-trace` (started as a subprocess in its own process group -
+    nothing is exec'd from this GPU-initialised process; killed as a group on a timeout) -> ({kernel name: {counter: [values per
+    dispatch], "_ns": [durations]}}, None) or (None, reason)."""
+    import csv, glob, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    # already running under a profiler / tool library (its environment would be inherited by the children): do not nest
     tooled = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER")) or k == "HSA_TOOLS_LIB"]
     if tooled or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process runs under a profiler (" + ", ".join(tooled[:3] or ["LD_PRELOAD"]) + "): PMC child runs skipped"
-    import signal
+    d = tempfile.mkdtemp(prefix="smml_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), *argv_tail]
+        child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = child.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+            return None, f"CHILD_TIMEOUT: rocprofv3 --pmc {' '.join(counters)} pass exceeded {timeout} s and its process group was killed"
+        if rc != 0:
+            return None, (f"CHILD_SIGNAL: rocprofv3 --pmc pass died by signal {-rc}" if rc < 0 else f"rocprofv3 --pmc {' '.join(counters)} pass failed (rc {rc})")
+        acc = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    k = acc.setdefault(row["Kernel_Name"], {})
+                    k.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    if row["Counter_Name"] == counters[0]:
+                        k.setdefault("_ns", []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+        return acc, None
+    except Exception as e:                # a profiler hiccup must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def short_kernel_name(n):
+    """Readable name of a (possibly still mangled) kernel: `attn16_fwd_kernel<bf16, float, bf16>`, `chain_bf3_dual_kernel`, ..."""
+    import re
+    t = {"DF16b": "bf16", "DF16_": "fp16", "f": "float"}
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+(\w+?_kernel)I((?:DF16b|DF16_|f)+)E", n)
+    if m:
+        return m.group(1) + "<" + ", ".join(t[x] for x in re.findall(r"DF16b|DF16_|f", m.group(2))) + ">"
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)
+
+
+def nystrom_kernel_counters(B, n, dtype_name, budget_s=110.0):
+    """Per-kernel counters of the Nystrom leg `B x n x 512 <dtype>`, collected NOW by child runs of this script
+    (`--nystrom-child`) under rocprofv3: pass 1 SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe busy share of the launch's SIMD
+    cycles: busy cycles / 1024 SIMDs over GUI-active cycles / 8 XCDs), passes 2 / 3 FETCH_SIZE / WRITE_SIZE (HBM bytes, separate passes,
+    gfx950 correction as for `roofline.traffic`); the later passes are skipped once `budget_s` is spent.  -> dict for the bench line."""
+    tail = ["--nystrom-child", f"{B},{n},{dtype_name}"]
+    t0 = time.time()
+    a, why = pmc_child_pass(["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], tail)
+    if a is None:
+        return {"error": why}
+    fe = wr = None
+    notes = []
+    if time.time() - t0 < budget_s * 0.45:
+        fe, why_f = pmc_child_pass(["FETCH_SIZE"], tail)
+        if fe is None:
+            notes.append("FETCH_SIZE pass: " + why_f)
+        elif time.time() - t0 < budget_s * 0.8:
+            wr, why_w = pmc_child_pass(["WRITE_SIZE"], tail)
+            if wr is None:
+                notes.append("WRITE_SIZE pass: " + why_w)
+        else:
+            notes.append("WRITE_SIZE pass skipped (time budget)")
+    else:
+        notes.append("HBM passes skipped (time budget)")
+    mean = lambda v: sum(v) / len(v)
+    steps = 3
+    rows = []
+    for k, c in a.items():
+        if not any(x in k for x in ("attn16", "gemm_b16", "gemm_f32", "chain_", "resconv", "segment_mean", "nystrom", "pinv", "softmax", "colsum")) or "_ns" not in c:
+            continue
+        us = mean(c["_ns"]) / 1e3
+        row = {"kernel": short_kernel_name(k), "launches_per_step": len(c["_ns"]) / (2.0 * steps), "us": us,        # 3 warm-up + 3 counted executions
+               "mfma_busy": mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / max(mean(c["GRBM_GUI_ACTIVE"]) / 8.0, 1.0)}
+        if fe is not None and wr is not None and k in fe and k in wr and "FETCH_SIZE" in fe[k] and "WRITE_SIZE" in wr[k]:
+            hb = (2.0 * mean(fe[k]["FETCH_SIZE"]) + mean(wr[k]["WRITE_SIZE"])) * 1024.0
+            row["hbm_MB"] = hb / 1e6
+            row["hbm_TBps"] = hb / (us * 1e-6) / 1e12
+            row["hbm_frac_of_6.3TBps"] = row["hbm_TBps"] / 6.3
+        rows.append(row)
+    rows.sort(key=lambda r: -r["us"] * r["launches_per_step"])
+    tot = sum(r["us"] * r["launches_per_step"] for r in rows)
+    for r in rows:
+        r["share_of_kernel_time"] = r["us"] * r["launches_per_step"] / max(tot, 1e-9)
+        if r["kernel"].startswith("attn16_") and "hbm_frac_of_6.3TBps" in r and r["mfma_busy"] > 0:
+            # VERDICT r04 item 3: a QK / AV kernel should be >= 0.40 matrix-pipe busy or >= 0.70 of the achievable HBM rate
+            r["meets_0.40_mfma_or_0.70_hbm"] = bool(r["mfma_busy"] >= 0.40 or r["hbm_frac_of_6.3TBps"] >= 0.70)
+    chain = sum(r["us"] * r["launches_per_step"] for r in rows if r["kernel"].startswith("chain_"))
+    return {"source": "live: child runs of this script under rocprofv3 --pmc (kernel trace only; the child does 3 warm-up + 3 counted steps of the leg, "
+                      "both halves counted in launches_per_step), one counter group per pass" + ("; " + "; ".join(notes) if notes else ""),
+            "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, mean per dispatch",
+            "kernel_time_per_step_ms": tot / 1e3, "newton_schulz_chain_ms": chain / 1e3, "newton_schulz_chain_launches": sum(
+                r["launches_per_step"] for r in rows if r["kernel"].startswith("chain_")), "kernels": rows[:24], "collect_s": time.time() - t0}
+
+
+def live_traffic(kernel_substr, argv_tail, timeout=150):
+    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, collected NOW: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes).
+    gfx950 correction of the guide: FETCH_SIZE counts 128-byte requests as 64 bytes (x 2 for wide coalesced reads); both counters are in
+    KB.  -> (bytes per launch, note) or (None, reason)."""
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="smml_pmc_", dir="/tmp")
-        try:
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), *argv_tail]
-            env = dict(os.environ, TMPDIR="/tmp")
-            # own session = own process group: on a timeout the WHOLE group (the rocprofv3 wrapper and the profiled python it
-            # started) is killed and reaped before this process times anything else on the GPU (ADVICE r02)
-            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-            try:
-                rc = child.wait(timeout=timeout)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(child.pid, signal.SIGKILL)
-                except ProcessLookupError:
-                    pass
-                child.wait()
-                return None, f"CHILD_TIMEOUT: rocprofv3 --pmc {counter} pass exceeded {timeout} s and its process group was killed"
-            if rc < 0:
-                return None, f"CHILD_SIGNAL: rocprofv3 --pmc {counter} pass died by signal {-rc}"
-            if rc != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
-            acc = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            acc.append(float(row["Counter_Value"]))
-            if not acc:
-                return None, f"no {counter} rows for {kernel_substr}"
-            vals[counter] = sum(acc) / len(acc)
-        except Exception as e:        # a profiler hiccup must not cost the bench line
-            return None, f"{type(e).__name__}: {e}"
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+        acc, why = pmc_child_pass([counter], argv_tail, timeout)
+        if acc is None:
+            return None, why
+        v = [x for k, c in acc.items() if kernel_substr in k for x in c.get(counter, [])]
+        if not v:
+            return None, f"no {counter} rows for {kernel_substr}"
+        vals[counter] = sum(v) / len(v)
     return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0, (
         f"live: two child runs of this script under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the "
         f"kernel's dispatches; FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB x 2 (gfx950) + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB")
@@ -411,6 +482,8 @@ def main():
     ap.add_argument("--no-nystrom", action="store_true", help="skip the Nystrom legs (extra key `nystrom`, not part of `value`)")
     ap.add_argument("--no-dp-overhead", action="store_true", help="skip the leg that wraps the headline step in a one-rank RCCL group (extra key `data_parallel_at_world_1`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure `roofline.traffic`")
+    ap.add_argument("--no-nystrom-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs behind `nystrom[1].kernel_counters`")
+    ap.add_argument("--nystrom-child", default=None, help="internal: B,n,dtype - run that Nystrom leg alone (3 + 3 steps) and exit (profiled by the parent)")
     ap.add_argument("--deform-dtype", default=None, choices=[None, "bf16", "fp16"],
                     help="measurement switch: run the HEADLINE step itself with the fused attention core in its 16-bit compute mode (the "
                          "default line stays fp32-grade; the default run reports the 16-bit step in the extra key `deform16`)")
@@ -421,6 +494,11 @@ def main():
     if a.dp_child:
         torch.cuda.set_device(0)
         dp_overhead_child(importlib.import_module(PKG), torch.device("cuda", 0), a.bags, a.grid, a.in_dim, a.steps, a.warmup)
+        return
+    if a.nystrom_child:
+        torch.cuda.set_device(0)
+        nb, nn_, ndt = a.nystrom_child.split(",")
+        nystrom_leg(importlib.import_module(PKG), torch.device("cuda", 0), int(nb), int(nn_), getattr(torch, ndt), steps=3, warmup=3)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -626,6 +704,11 @@ def main():
             # the north_star's Nystrom target, driver-run: BASELINE config 2 shape and the N = 10 000 bag (not part of `value`);
             # timed BEFORE the PMC child runs below so that nothing of theirs can still be on the GPU
             out["nystrom"] = nystrom_legs(pkg, dev)
+            if not a.no_nystrom_pmc and len(out["nystrom"]) > 1 and "error" not in out["nystrom"][1]:
+                try:                                  # per-kernel matrix-pipe busy share and HBM bytes of the 4 x 10 000 bf16 leg, live
+                    out["nystrom"][1]["kernel_counters"] = nystrom_kernel_counters(4, 10000, "bfloat16")
+                except Exception as e:
+                    out["nystrom"][1]["kernel_counters"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and "roofline" in out:
             kname = "deform_region_fwd_kernel" if regions else "cpb_bwd_kernel"
             traffic, tsrc = None, "not collected (--no-traffic)"

@@ -167,6 +167,8 @@ typedef struct SmmlDeformOpts {
   float mask_table_pmax;
   unsigned short* export_masks;          /* tests: smml_deform_attn16_bwd with relu_masks == NULL also writes the decisions it used here
                                             ([B, H, nst / 32, J, 2, 32] u16, the forward's layout), or NULL */
+  int region_lds_cap;                    /* tests: the region entry points keep only regions with an id below this in LDS and take the others from
+                                            global memory (the path of parameter sets with more than 2048 linear regions); 0 = the default (2048) */
 } SmmlDeformOpts;
 #endif
 

@@ -20,7 +20,7 @@ _f = C.c_void_p          # device pointers travel as void*
 class DeformOpts(C.Structure):
     """SmmlDeformOpts of include/smml.h: optional behaviour of ONE fused deformable-attention launch, passed with the call."""
     _fields_ = [("seed_offset", C.c_void_p), ("raw_distance", C.c_int), ("mask_table", C.c_void_p), ("mask_table_pmax", C.c_float),
-                ("export_masks", C.c_void_p)]
+                ("export_masks", C.c_void_p), ("region_lds_cap", C.c_int)]
 
 
 _o = C.POINTER(DeformOpts)
@@ -136,14 +136,14 @@ def lib() -> C.CDLL:
 
 
 def deform_opts(seed_offset: Optional[torch.Tensor] = None, log_distance: bool = True, mask_table: Optional[torch.Tensor] = None,
-                mask_table_pmax: float = 0.0, export_masks: Optional[torch.Tensor] = None):
+                mask_table_pmax: float = 0.0, export_masks: Optional[torch.Tensor] = None, region_lds_cap: int = 0):
     """The `opts` argument of a fused deformable-attention entry point (byref of a DeformOpts), or None when every field is at its default.
     The struct is read during the call only; the tensors it points at must outlive the launch (the callers keep them)."""
-    if seed_offset is None and log_distance and mask_table is None and export_masks is None:
+    if seed_offset is None and log_distance and mask_table is None and export_masks is None and not region_lds_cap:
         return None
     if seed_offset is not None and (seed_offset.dtype != torch.int64 or seed_offset.numel() != 1):
         raise RuntimeError("dropout_seed_offset must be a device int64 tensor with one element")
-    o = DeformOpts(ptr(seed_offset), 0 if log_distance else 1, ptr(mask_table), float(mask_table_pmax), ptr(export_masks))
+    o = DeformOpts(ptr(seed_offset), 0 if log_distance else 1, ptr(mask_table), float(mask_table_pmax), ptr(export_masks), int(region_lds_cap))
     return C.byref(o)
 
 

@@ -540,7 +540,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
     const float* __restrict__ GQ, CpbParams cp, RegionView rv, float* __restrict__ O, float* __restrict__ LSE, float* __restrict__ LT,
-    unsigned short* __restrict__ RID, int N, int J, int H, int NST, float scale, DropCfg dc_in) {
+    unsigned short* __restrict__ RID, int N, int J, int H, int NST, float scale, DropCfg dc_in, int lcap) {
   const DropCfg dc = drop_resolve(dc_in);
   __shared__ __attribute__((aligned(16))) _Float16 Kp[2][KT * FRLD];         // K tile, fp16 hi / lo planes, row image (A operand of S^T)
   __shared__ __attribute__((aligned(16))) _Float16 Vp[2][KT * FTLD];         // V tile, hi / lo planes, read transposed (A operand of O^T)
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   const float* VSb = VS + (size_t)(b * H + h) * J * 2;                       // one head per offset group: group = head
 
   {
-    const int nreg = min((int)rv.hdr->n_regions, RG_LCAP);
+    const int nreg = min((int)rv.hdr->n_regions, lcap);       // lcap <= RG_LCAP: regions resident in LDS (tests lower it)
     for (int i = tid; i < nreg; i += 256) regl[i] = rv.reg[i];
     for (int i = tid; i < CH * CH; i += 256) w2t[(i & 31) * CH + (i >> 5)] = cp.w2[i];      // i = o * 32 + in
     if (tid < KT) {
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #endif
         // (a, c) of the region from LDS, no branch.  Ids beyond the LDS-resident regions and "no region" (~1e-4 of the pairs) read some
         // entry and add nothing here; `spec` tells the wave afterwards whether it has such a pair at all
-        const bool inl = id < (unsigned)RG_LCAP;
+        const bool inl = id < (unsigned)lcap;
 #if SMML_RGN_EXP == 6
         const float4 ac = make_float4(__uint_as_float(id), 0.5f, 0.25f, 0.f);
 #else
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
         const unsigned idr = ridl[wave][acc_row(r, hf)][c];
         const bool kin = acc_row(r, hf) < nk;
         if (idr == RG_NONE) nonemask |= kin ? (1u << r) : 0u;
-        else if (idr >= (unsigned)RG_LCAP) {   // a region beyond the LDS-resident ones (none for up to RG_LCAP regions): from global memory
+        else if (idr >= (unsigned)lcap) {      // a region beyond the LDS-resident ones (none for up to RG_LCAP regions): from global memory
           const float4 ac = rv.reg[idr];
           s[r] += fmaf(ac.x, p0[r], fmaf(ac.y, p1[r], ac.z));
         }
@@ -907,7 +907,7 @@ struct RegionBwdLds {                    // dynamic LDS of cpb_region_bwd_kernel
 __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const float* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, RegionView rv, const unsigned* __restrict__ AMAX, unsigned long long* __restrict__ HIST, unsigned long long* __restrict__ GRAD,
-    float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift) {
+    float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift, int lcap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   RegionBwdLds& L = *reinterpret_cast<RegionBwdLds*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   const int b = blockIdx.z, h = blockIdx.y, chunk = blockIdx.x;
   const int nthreads = blockDim.x;
   {
-    const int nreg = min((int)rv.hdr->n_regions, RG_LCAP);
+    const int nreg = min((int)rv.hdr->n_regions, lcap);       // lcap <= RG_LCAP: regions with LDS accumulators (tests lower it)
     for (int i = tid; i < RG_LCAP * 3; i += nthreads) L.hist[i] = 0ull;
     for (int i = tid; i < RG_GRAD; i += nthreads) L.grad[i] = 0ull;
     for (int i = tid; i < nreg; i += nthreads) { const float4 r = rv.reg[i]; L.reg2[i] = make_float2(r.x, r.y); }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   lds_u64* const hist_l = (lds_u64*)L.hist;
   glb_u64* const hist_g = (glb_u64*)HIST;
   auto flush = [&]() {
-    if (cur < (unsigned)RG_LCAP) {
+    if (cur < (unsigned)lcap) {
       const float2 a = L.reg2[cur];
       dv0 = fmaf(-a.x, u0, dv0); dv1 = fmaf(-a.y, u1, dv1);
       lds_u64* hp = hist_l + cur * 3;

@@ -1376,6 +1376,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
   SMML_REQUIRE((logits_t == nullptr) == (region_ids == nullptr),
                "smml_deform_attn_region_fwd_f32: logits_t and region_ids are saved together (training) or not at all");
   const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
+  const int lcap = (opts && opts->region_lds_cap > 0) ? (opts->region_lds_cap < RG_LCAP ? opts->region_lds_cap : RG_LCAP) : RG_LCAP;
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   const RegionView rv = region_view(const_cast<void*>(tables));
   dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B), block(256);
@@ -1384,10 +1385,10 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   if (region_ids)
     hipLaunchKernelGGL(deform_region_fwd_kernel<true>, grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits_t, region_ids, N, J,
-                       H, nst, scale, dc);
+                       H, nst, scale, dc, lcap);
   else
     hipLaunchKernelGGL(deform_region_fwd_kernel<false>, grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits_t, region_ids, N, J,
-                       H, nst, scale, dc);
+                       H, nst, scale, dc, lcap);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   SMML_LAUNCH_CHECK("smml_deform_attn_region_fwd_f32");
   return SMML_OK;
@@ -1416,6 +1417,7 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
   SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 255) == 0, "smml_deform_attn_region_bwd_f32: workspace must be 256-byte aligned");
   SMML_REQUIRE(pl.wpk >= 1, "smml_deform_attn_region_bwd_f32: too many keys (%d)", J);
   const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
+  const int lcap = (opts && opts->region_lds_cap > 0) ? (opts->region_lds_cap < RG_LCAP ? opts->region_lds_cap : RG_LCAP) : RG_LCAP;
   CpbParams cp{w1, b1, w2, b2, w3, b3};
   hipStream_t st = (hipStream_t)stream;
   const int nst = smml_deform_attn_nst(N);
@@ -1461,7 +1463,7 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
     hipLaunchKernelGGL(cpb_region_bwd_kernel, dim3(pl.chunks, H, B), dim3(64 * pl.nkb * pl.wpk), sizeof(RegionBwdLds), st, dlogits_t,
                        region_ids, vs, gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.wpk, pl.tiles_per_chunk, pl.kbits,
-                       pl.shift);
+                       pl.shift, lcap);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/cpb");
     const size_t n = (size_t)B * H * J;

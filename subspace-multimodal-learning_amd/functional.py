@@ -867,6 +867,7 @@ TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
 # kernels (the cross-check of tests/test_gpu_regions.py, and the path of every other configuration).
 CPB_REGIONS = __import__("os").environ.get("SMML_CPB_REGIONS", "1") != "0"
 REGION_MAX_KEYS = 768
+REGION_LDS_CAP = 0           # tests: regions with an id >= this take the global-memory path of the region kernels (0: the default, 2048)
 
 
 REGION_GRID, REGION_SUB, REGION_SUBCAP, REGION_EDGES, REGION_RCAP = 1024, 8, 16384, 1 << 15, 4096     # csrc/cpb_regions.h
@@ -1000,7 +1001,7 @@ class _DeformAttn(torch.autograd.Function):
                                                          capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.fptr(logits),
                                                          capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
                                                          *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream(),
-                                                         capi.deform_opts(seed_offset)), "deform_attn_region_fwd")
+                                                         capi.deform_opts(seed_offset, region_lds_cap=REGION_LDS_CAP)), "deform_attn_region_fwd")
             ctx.seed_offset = seed_offset
             ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
             ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, rid, tables)
@@ -1118,7 +1119,7 @@ class _DeformAttn(torch.autograd.Function):
             capi.fptr(logits), capi.ptr(rid), capi.fptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
             capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3), capi.ptr(ws), wsb,
             B, N, J, heads, scale, dropout_p, dropout_seed, *TIMER.events("cpb_region_bwd", B * heads * N * J), capi.stream(),
-            capi.deform_opts(ctx.seed_offset)), "deform_attn_region_bwd")
+            capi.deform_opts(ctx.seed_offset, region_lds_cap=REGION_LDS_CAP)), "deform_attn_region_bwd")
         if ctx.fork is not None and ctx.needs_input_grad[0]:
             ctx.fork.dq = dq.view(B, N, -1)
         return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None

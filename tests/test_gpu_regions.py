@@ -147,6 +147,19 @@ def test_region_core_matches_per_pair_mlp(cuda, wkind, B, N, J, p_drop):
     a2 = _run(t, cuda, wo, True, p_drop)
     for n in a:
         assert torch.equal(a[n], a2[n]), f"{n}: the region path is not run-to-run identical"
+    # Parameter sets with more than 2048 linear regions (none of the initialisations tried has more than ~1 850) keep the regions beyond
+    # the 2048th in global memory: coefficients read there, moments added there.  SmmlDeformOpts.region_lds_cap lowers the limit so
+    # that ordinary parameters exercise that path: same forward bits, same gradients up to the order of the moment sums.
+    Fh.REGION_LDS_CAP = 96
+    try:
+        c = _run(t, cuda, wo, True, p_drop)
+    finally:
+        Fh.REGION_LDS_CAP = 0
+    for n in a:
+        scale = max(float(a[n].abs().max()), 1e-30)
+        err = float((a[n] - c[n]).abs().max()) / scale
+        tol = 0.0 if n in ("out",) else (2e-6 if n in ("q", "k", "v") else 2e-5)
+        assert err <= tol, f"{wkind} {B}x{N}x{J}: {n} differs by {err:.2e} between LDS-resident and global-memory regions"
 
 
 def test_region_core_vs_fp64_with_imposed_decisions(cuda):
