@@ -489,7 +489,11 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
       const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&Vp[buf][0][o]);
       const bf16x8 vm = *reinterpret_cast<const bf16x8*>(&Vp[buf][1][o]);
       const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&Vp[buf][2][o]);
+#if SMML_BWD_EXP != 1
       dp = bwd_prod<SMML_BWD_TERMS>(vh, vm, vl, doh[kb], dom[kb], dol[kb], dp);
+#else
+      dp[kb] += __builtin_bit_cast(float, (unsigned)vh[0] << 16) + __builtin_bit_cast(float, (unsigned)vm[1] << 16) + __builtin_bit_cast(float, (unsigned)vl[2] << 16);
+#endif
     }
 
     float ds[16];
@@ -539,8 +543,13 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dq_kernel(
         const bf16x8 kh = lds_frag_tr(&Kp[buf][0][ro + 32 * db], &Kp[buf][0][ro + 32 * db + 8 * KBLD]);
         const bf16x8 km = lds_frag_tr(&Kp[buf][1][ro + 32 * db], &Kp[buf][1][ro + 32 * db + 8 * KBLD]);
         const bf16x8 kl = (SMML_DQ_OUT_TERMS == 3) ? lds_frag_tr(&Kp[buf][2][ro + 32 * db], &Kp[buf][2][ro + 32 * db + 8 * KBLD]) : km;
+#if SMML_BWD_EXP != 2
         if (db == 0) dq0 = bwd_prod<SMML_DQ_OUT_TERMS>(kh, km, kl, sh, sm, sl, dq0);
         else dq1 = bwd_prod<SMML_DQ_OUT_TERMS>(kh, km, kl, sh, sm, sl, dq1);
+#else
+        if (db == 0) dq0[kb] += __builtin_bit_cast(float, (unsigned)kh[0] << 16) * __builtin_bit_cast(float, (unsigned)sh[0] << 16) + __builtin_bit_cast(float, (unsigned)km[1] << 16) * __builtin_bit_cast(float, (unsigned)sm[1] << 16);
+        else dq1[kb] += __builtin_bit_cast(float, (unsigned)kh[2] << 16) * __builtin_bit_cast(float, (unsigned)sh[2] << 16) + __builtin_bit_cast(float, (unsigned)km[3] << 16) * __builtin_bit_cast(float, (unsigned)sm[3] << 16);
+#endif
       }
     }
   }
@@ -700,8 +709,13 @@ __global__ __launch_bounds__(256, 2) void deform_attn_bwd_dkv_kernel(
           const bf16x8 qh = lds_frag_tr(&Qp[buf][0][o], &Qp[buf][0][o + 8 * QBLD]);
           const bf16x8 qm = lds_frag_tr(&Qp[buf][1][o], &Qp[buf][1][o + 8 * QBLD]);
           const bf16x8 ql = (SMML_DKV_TERMS == 3) ? lds_frag_tr(&Qp[buf][2][o], &Qp[buf][2][o + 8 * QBLD]) : qm;
+#if SMML_BWD_EXP != 3
           if (db == 0) { dv0 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv0); dk0 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk0); }
           else { dv1 = bwd_prod<SMML_DKV_TERMS>(ah, am, al, ph, pm, pl, dv1); dk1 = bwd_prod<SMML_DKV_TERMS>(qh, qm, ql, sh, sm, sl, dk1); }
+#else
+          if (db == 0) { dv0[kb] += __builtin_bit_cast(float, (unsigned)ah[0] << 16) * __builtin_bit_cast(float, (unsigned)ph[0] << 16) + __builtin_bit_cast(float, (unsigned)am[1] << 16); dk0[kb] += __builtin_bit_cast(float, (unsigned)qh[0] << 16) * __builtin_bit_cast(float, (unsigned)sh[0] << 16) + __builtin_bit_cast(float, (unsigned)qm[1] << 16); }
+          else { dv1[kb] += __builtin_bit_cast(float, (unsigned)ah[2] << 16) * __builtin_bit_cast(float, (unsigned)ph[2] << 16) + __builtin_bit_cast(float, (unsigned)am[3] << 16); dk1[kb] += __builtin_bit_cast(float, (unsigned)qh[2] << 16) * __builtin_bit_cast(float, (unsigned)sh[2] << 16) + __builtin_bit_cast(float, (unsigned)qm[3] << 16); }
+#endif
         }
       }
     }

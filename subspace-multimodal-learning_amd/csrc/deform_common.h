@@ -48,6 +48,9 @@
                               // is unchanged to three digits vs 3 terms (tests/diag_gterms.py: it is set by ReLU mask flips
                               // and by delta = rowsum(dO . O)), and the kernel is 10 % faster.  3: fp32-grade summands.
 #endif
+#ifndef SMML_BWD_EXP
+#define SMML_BWD_EXP 0        // measurement variants of the dq / dkv passes (wrong results): 1 no dP products, 2 no dQ products, 3 no dK / dV products
+#endif
 #ifndef SMML_BWD_TERMS
 #define SMML_BWD_TERMS 3      // bf16 terms per operand in the dq pass: 3 = fp32-grade (six products per block), 2 = 16-bit operands (hi + mid,
                               // three products: measurement switch - d scores then carry 2^-17 errors, which the position-bias gradients
