@@ -250,9 +250,16 @@ def timed_steps(step, steps, warmup):
     """Runs `step` warmup + steps times on the current stream.  Returns what a reader needs to tell a GPU-bound leg from a host-bound
     one: wall time per step between two synchronisations, the time the HOST needed to enqueue a step (the loop without the final
     synchronisation), and the GPU time of every single step from HIP events recorded on the launch stream (min / median / max)."""
+    import gc
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    # Python's cyclic collector: a full (generation-2) pass over a process that holds a torch model walks ~10^6 objects - 50-130 ms of
+    # host time, once every few hundred steps in steady state but early after the objects of model construction (it landed inside the
+    # ten timed steps of one leg and doubled its wall time).  Collect now and freeze the survivors (what a training script does after
+    # set-up): the timed steps then see young-generation passes only.
+    gc.collect()
+    gc.freeze()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
@@ -262,8 +269,9 @@ def timed_steps(step, steps, warmup):
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
-    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "gc": "collected and frozen before the timed steps",
             "step_ms_events": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
             "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
             "host_gap_ms": max(0.0, 1e3 * dt / steps - per[len(per) // 2]),
@@ -381,6 +389,23 @@ def deform16_leg(pkg, dev, B, S, in_dim, dtype="bf16", steps=10, warmup=10, cpb_
                 n, ms, pairs = kt[key]
                 out[key] = {"avg_ms": ms, "launches": n, "pairs_per_launch": pairs,
                             "note": "forward kernel" if key == "deform_table_fwd" else "d vs (per pair) + d table (two dense products per key on the matrix pipe)"}
+    out["kernel_events"] = {k: {"launches": v[0], "avg_ms": v[1], "pairs_per_launch": v[2]} for k, v in kt.items()}
+    if "deform16_region_fwd" in kt:
+        # the region form of the 16-bit core (the default wherever it applies): the same fp32 lookup of the position bias as the headline
+        # path, single-term 16-bit operands on the matrix pipe, fp16 scores (2 B) + region ids (2 B) saved per pair, bf16 d scores
+        out["workload"] += "; position bias per linear region of its MLP (the headline path's fp32 lookup, csrc/cpb_regions.h)"
+        n, ms, pairs = kt["deform16_region_fwd"]
+        Hh = 8
+        abytes = pairs * 4 + B * Hh * N * (512 + 4) + B * Hh * (pairs // (B * Hh * N)) * (512 + 8)
+        out["roofline_fwd"] = {"kernel": "deform_region_fwd_kernel<true, bf16>", "bound": "hbm", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms, "launches": n,
+                               "algorithmic_bytes_per_launch": abytes, "limiter": "vector issue"}
+        if "cpb16_region_bwd" in kt:
+            n2, ms2, pairs2 = kt["cpb16_region_bwd"]
+            b2 = pairs2 * 4
+            out["roofline"] = {"kernel": "cpb_region_bwd_kernel<bf16 d scores>", "bound": "hbm", "achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms2, "launches": n2,
+                               "algorithmic_bytes_per_launch": b2, "limiter": "vector issue + LDS atomics"}
     if "cpb16_bwd" in kt:
         n, ms, pairs = kt["cpb16_bwd"]
         flop = pairs * 2 * CPB_FWD_FLOP_PER_PAIR
@@ -580,6 +605,9 @@ def main():
     else:
         for _ in range(a.warmup):
             step()
+        import gc
+        gc.collect()                       # (see timed_steps: no full pass of Python's cyclic collector over the model's objects inside the timed steps)
+        gc.freeze()
         fence()
         Fh.TIMER.enabled = True
         t0 = time.perf_counter()

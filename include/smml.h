@@ -234,6 +234,25 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
                                     float* dv, float* dvs, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                                     void* workspace, size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
                                     unsigned long long dropout_seed, void* ev_start, void* ev_stop, void* stream, const SmmlDeformOpts* opts);
+
+/* The same two entry points in the 16-bit compute modes of smml_deform_attn16_fwd / _bwd (dtype 0 = bf16, 1 = fp16: single-term operands on
+ * the matrix pipe, scores saved as fp16 [B, H, nst / 32, J, 32], d scores as bf16): the position bias stays the fp32 lookup per linear
+ * region, so it is MORE exact than the 16-bit per-pair MLP it replaces, and the launch pair costs about half of it.  Same conditions as
+ * above; tables from smml_cpb_regions_build; workspace of the backward: smml_deform_attn_region_bwd_workspace_bytes, 256-byte aligned. */
+int smml_deform_attn16_region_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const void* tables,
+                                  float* out, float* lse, unsigned short* logits16, unsigned short* region_ids, int B, int N, int J, int H,
+                                  float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start, void* ev_stop,
+                                  void* stream, const SmmlDeformOpts* opts);
+int smml_deform_attn16_region_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const void* tables,
+                                  const float* out, const float* dout, const float* lse, const unsigned short* logits16,
+                                  const unsigned short* region_ids, unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs,
+                                  float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* workspace,
+                                  size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
+                                  unsigned long long dropout_seed, int dtype, void* ev_start, void* ev_stop, void* stream,
+                                  const SmmlDeformOpts* opts);
+
 /* 16-bit compute mode of the same fused core (csrc/deform_attn16.hip; BASELINE config 4 names bf16, config 5 fp16): the op sequence of
  * smml_deform_attn_fwd_f32 / _bwd_f32 (models/DeformableAttention2D.py:120-157,284-312; DeformableAttention1D.py:60-102,205-232) with
  * single-term 16-bit operands on the matrix pipe - dtype 0 = bf16, 1 = fp16 for forward-range operands (q, k, v, probabilities, the

@@ -75,6 +75,8 @@ SIGNATURES = {
     "smml_deform_attn_region_fwd_f32": (_i, [_f] * 16 + [_i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
     "smml_deform_attn_region_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "smml_deform_attn_region_bwd_f32": (_i, [_f] * 28 + [_f, _sz, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _f, _f, _f] + [_o]),
+    "smml_deform_attn16_region_fwd": (_i, [_f] * 16 + [_i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
+    "smml_deform_attn16_region_bwd": (_i, [_f] * 28 + [_f, _sz, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
     "smml_deform_attn16_fwd": (_i, [_f] * 15 + [_i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
     "smml_deform_attn16_bwd": (_i, [_f] * 27 + [_f, _sz, _i, _i, _i, _i, _i, _i, _fl, _fl, C.c_ulonglong, _i, _f, _f, _f] + [_o]),
     "smml_cpb_mask_table_cells": (_i, [_i]),

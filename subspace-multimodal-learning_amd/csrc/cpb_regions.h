@@ -23,7 +23,9 @@
 // Nothing is approximated: every pair is evaluated on its own linear piece (or, for kind 3, by the MLP itself), and a decision can
 // differ from an fp64 evaluation of the reference's formula only where the pre-activation is within fp32 rounding of zero.
 #pragma once
+#include <type_traits>
 #include "deform_common.h"
+#include "deform16_types.h"
 
 namespace {
 
@@ -536,11 +538,20 @@ __device__ __forceinline__ float coop_mlp_fwd(const CoopMlp& m, float p0, float 
 // ------------------------------------------------------------------------------------------------
 // forward, position bias per linear region (PD = 2, signed-log offsets, one head per offset group)
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE>
+// T = float: the fp32-grade core (fp16 hi / lo split products, fp32 scores saved).  T = __bf16 / _Float16: the 16-bit compute mode of
+// deform_attn16.hip (single-term T operands, scores saved as fp16 and the forward's own softmax continued on the ROUNDED scores) - the
+// position bias is the same fp32 lookup in every mode.
+template <typename T> struct RegionScore { typedef u16 type; };
+template <> struct RegionScore<float> { typedef float type; };
+template <bool SAVE, typename T = float>
 __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ VS,
-    const float* __restrict__ GQ, CpbParams cp, RegionView rv, float* __restrict__ O, float* __restrict__ LSE, float* __restrict__ LT,
-    unsigned short* __restrict__ RID, int N, int J, int H, int NST, float scale, DropCfg dc_in, int lcap) {
+    const float* __restrict__ GQ, CpbParams cp, RegionView rv, float* __restrict__ O, float* __restrict__ LSE,
+    typename RegionScore<T>::type* __restrict__ LT, unsigned short* __restrict__ RID, int N, int J, int H, int NST, float scale, DropCfg dc_in,
+    int lcap) {
+  constexpr bool F32 = std::is_same<T, float>::value;
+  typedef typename std::conditional<F32, _Float16, T>::type T16;        // element type of the single-term operands (unused for F32)
+  typedef typename Vec8<T16>::type vec8;
   const DropCfg dc = drop_resolve(dc_in);
   __shared__ __attribute__((aligned(16))) _Float16 Kp[2][KT * FRLD];         // K tile, fp16 hi / lo planes, row image (A operand of S^T)
   __shared__ __attribute__((aligned(16))) _Float16 Vp[2][KT * FTLD];         // V tile, hi / lo planes, read transposed (A operand of O^T)
@@ -574,15 +585,19 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 
   // scaled Q of this lane's query as the B operand of S^T = K . Q^T: k-step st holds d = 16 st + 8 hf + j, fp16 hi / lo
   half8 qh[4], ql[4];
+  vec8 qf[4];
   {
     const float* qp = Q + ((size_t)b * N + qi) * HD + h * DH + hf * 8;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * st), t1 = *reinterpret_cast<const float4*>(qp + 16 * st + 4);
       const float x8[8] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale, t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
-      split8(x8, qh[st], ql[st]);
+      if constexpr (F32) split8(x8, qh[st], ql[st]);
+      else qf[st] = cvt8<T16>(x8);
     }
   }
+  T16* const K16 = reinterpret_cast<T16*>(&Kp[0][0]);                  // 16-bit modes: one plane each
+  T16* const V16 = reinterpret_cast<T16*>(&Vp[0][0]);
   const int trq = (lane & 15) >> 2, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // transposed-read lane map
   const float gq0 = GQ[(size_t)qi * 2], gq1 = GQ[(size_t)qi * 2 + 1];
 
@@ -591,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
   const unsigned long long drop_row = dc.seed + ((unsigned long long)(b * H + h) * N + qi) * ((J + 1) >> 1);   // dropout counter of the row's first pair
   const float* Kb = K + (size_t)b * J * HD + h * DH;
   const float* Vb = V + (size_t)b * J * HD + h * DH;
-  float* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;    // this wave's [J][32] block (layout: deform_attn_fwd_kernel)
+  typename RegionScore<T>::type* LTb = LT ? LT + ((size_t)(b * H + h) * NST + q0) * J : nullptr;    // this wave's [J][32] block (layout: deform_attn_fwd_kernel)
   unsigned short* RIDb = RID ? RID + ((size_t)(b * H + h) * NST + q0) * J : nullptr;
 
   // K / V rows of a tile travel global -> registers (one tile ahead) -> fp16 hi / lo images in LDS
@@ -681,11 +696,16 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = (tid >> 4) + 16 * i, d4 = (tid & 15) * 4;
-      uint2v hi, lo;
-      split4_h2(kreg[i], hi, lo);
-      *reinterpret_cast<uint2v*>(&Kp[0][key * FRLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Kp[1][key * FRLD + d4]) = lo;
-      split4_h2(vreg[i], hi, lo);
-      *reinterpret_cast<uint2v*>(&Vp[0][key * FTLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Vp[1][key * FTLD + d4]) = lo;
+      if constexpr (F32) {
+        uint2v hi, lo;
+        split4_h2(kreg[i], hi, lo);
+        *reinterpret_cast<uint2v*>(&Kp[0][key * FRLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Kp[1][key * FRLD + d4]) = lo;
+        split4_h2(vreg[i], hi, lo);
+        *reinterpret_cast<uint2v*>(&Vp[0][key * FTLD + d4]) = hi; *reinterpret_cast<uint2v*>(&Vp[1][key * FTLD + d4]) = lo;
+      } else {
+        *reinterpret_cast<uint2v*>(&K16[key * FRLD + d4]) = pack4<T16>(kreg[i]);
+        *reinterpret_cast<uint2v*>(&V16[key * FTLD + d4]) = pack4<T16>(vreg[i]);
+      }
     }
     if (tid < KT) { vsl[(kt + 1) & 1][tid][0] = vsn.x; vsl[(kt + 1) & 1][tid][1] = vsn.y; }     // the NEXT tile's sample positions
     lds_barrier();
@@ -695,10 +715,14 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int o = c * FRLD + 16 * st + 8 * hf;
-      const half8 kh = *reinterpret_cast<const half8*>(&Kp[0][o]), kl = *reinterpret_cast<const half8*>(&Kp[1][o]);
-      s = mfma16(kl, qh[st], s);
-      s = mfma16(kh, ql[st], s);
-      s = mfma16(kh, qh[st], s);
+      if constexpr (F32) {
+        const half8 kh = *reinterpret_cast<const half8*>(&Kp[0][o]), kl = *reinterpret_cast<const half8*>(&Kp[1][o]);
+        s = mfma16(kl, qh[st], s);
+        s = mfma16(kh, ql[st], s);
+        s = mfma16(kh, qh[st], s);
+      } else {
+        s = mma(*reinterpret_cast<const vec8*>(&K16[o]), qf[st], s);
+      }
     }
 
     const int nk = min(KT, J - j0);
@@ -792,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r += 2) keepbits |= drop_keep2_z(dc, z0 + (unsigned)(acc_row(r, 0) >> 1)) << r;
     }
-    if (SAVE) {                               // rows are padded to whole workgroup tiles: lanes past N write padding
+    if constexpr (SAVE && F32) {              // rows are padded to whole workgroup tiles: lanes past N write padding
       if (dc.thresh) {
         tmax = -INFINITY;
 #pragma unroll
@@ -811,6 +835,38 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
           if (key < nk && SMML_RGN_EXP != 3) LTb[(size_t)(j0 + key) * 32 + c] = s[r];
         }
       }
+    }
+    if constexpr (SAVE && !F32) {
+      // 16-bit modes (deform16_fwd_kernel's rule): the scores are rounded to fp16 for storage, the keep decision replaces the stored
+      // score's lowest bit, and the forward's own softmax continues on the stored values - forward and backward agree on the
+      // probabilities
+      if (nk == KT) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          unsigned w = pack_score(s[r], s[r + 1]);
+          if (dc.thresh) w = stash_keep16x2(w, keepbits >> r);
+          const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          LTb[(size_t)(j0 + acc_row(r, hf)) * 32 + c] = (u16)lo;
+          LTb[(size_t)(j0 + acc_row(r + 1, hf)) * 32 + c] = (u16)hi;
+          s[r] = score_of(lo); s[r + 1] = score_of(hi);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const unsigned w = pack_score(s[r], s[r + 1]);
+          unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          const int k0 = acc_row(r, hf), k1 = acc_row(r + 1, hf);
+          if (dc.thresh) {
+            if (k0 < nk) lo = stash_keep16(lo, (keepbits >> r) & 1u);
+            if (k1 < nk) hi = stash_keep16(hi, (keepbits >> (r + 1)) & 1u);
+          }
+          if (k0 < nk) { LTb[(size_t)(j0 + k0) * 32 + c] = (u16)lo; s[r] = score_of(lo); }
+          if (k1 < nk) { LTb[(size_t)(j0 + k1) * 32 + c] = (u16)hi; s[r + 1] = score_of(hi); }
+        }
+      }
+      tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
     }
     // The next tile's K / V rows (and the sample positions of the tile after it) and its cell codes: in flight during the softmax, the
     // P V products and the top of the next tile.  Vector-memory operations - loads AND stores - retire in the order of issue, and a wait
@@ -848,13 +904,19 @@ __global__ __launch_bounds__(256, 2) void deform_region_fwd_kernel(
       float p8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) p8[j] = s[8 * kb + j];
-      half8 ph, pl;
-      split8(p8, ph, pl);
       const int ro = (16 * kb + 4 * hf + trq) * FTLD + trc;
-      const half8 vh0 = lds_frag_tr_h(&Vp[0][ro], &Vp[0][ro + 8 * FTLD]), vl0 = lds_frag_tr_h(&Vp[1][ro], &Vp[1][ro + 8 * FTLD]);
-      const half8 vh1 = lds_frag_tr_h(&Vp[0][ro + 32], &Vp[0][ro + 32 + 8 * FTLD]), vl1 = lds_frag_tr_h(&Vp[1][ro + 32], &Vp[1][ro + 32 + 8 * FTLD]);
-      oacc0 = mfma16(vl0, ph, oacc0); oacc0 = mfma16(vh0, pl, oacc0); oacc0 = mfma16(vh0, ph, oacc0);
-      oacc1 = mfma16(vl1, ph, oacc1); oacc1 = mfma16(vh1, pl, oacc1); oacc1 = mfma16(vh1, ph, oacc1);
+      if constexpr (F32) {
+        half8 ph, pl;
+        split8(p8, ph, pl);
+        const half8 vh0 = lds_frag_tr_h(&Vp[0][ro], &Vp[0][ro + 8 * FTLD]), vl0 = lds_frag_tr_h(&Vp[1][ro], &Vp[1][ro + 8 * FTLD]);
+        const half8 vh1 = lds_frag_tr_h(&Vp[0][ro + 32], &Vp[0][ro + 32 + 8 * FTLD]), vl1 = lds_frag_tr_h(&Vp[1][ro + 32], &Vp[1][ro + 32 + 8 * FTLD]);
+        oacc0 = mfma16(vl0, ph, oacc0); oacc0 = mfma16(vh0, pl, oacc0); oacc0 = mfma16(vh0, ph, oacc0);
+        oacc1 = mfma16(vl1, ph, oacc1); oacc1 = mfma16(vh1, pl, oacc1); oacc1 = mfma16(vh1, ph, oacc1);
+      } else {
+        const vec8 pt = cvt8<T16>(p8);
+        oacc0 = mma(frag_tr<T16>(&V16[ro], &V16[ro + 8 * FTLD]), pt, oacc0);
+        oacc1 = mma(frag_tr<T16>(&V16[ro + 32], &V16[ro + 32 + 8 * FTLD]), pt, oacc1);
+      }
     }
   }
 
@@ -904,8 +966,10 @@ struct RegionBwdLds {                    // dynamic LDS of cpb_region_bwd_kernel
 // three moments of a RUN of queries in the same region (~4 on the query grid) and the run's two d vs sums are kept in registers and go to
 // the region's LDS accumulators with three 64-bit integer adds when the region changes.  The query is the same for all lanes: its position
 // comes from a lane of the tile's position register into scalar registers, the second coordinate's log / reciprocal only when it changes.
+// DS = float: the fp32-grade core's d scores; DS = u16: the bf16 d scores of the 16-bit modes (deform16_bwd_dq_kernel).
+template <typename DS>
 __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
-    const float* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
+    const DS* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, RegionView rv, const unsigned* __restrict__ AMAX, unsigned long long* __restrict__ HIST, unsigned long long* __restrict__ GRAD,
     float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift, int lcap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -963,7 +1027,8 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     }
   };
 
-  float4 dbn[8];
+  constexpr bool DS32 = std::is_same<DS, float>::value;
+  float4 dbn[DS32 ? 8 : 4];                                         // (16-bit d scores: 8 per 16-byte word)
   uint4 ridn[4];
   float2 gqn;                                                       // lane c: position of query c of the tile (one coalesced load per tile)
   auto fetch = [&](int tile) {
@@ -971,7 +1036,7 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const float4* dp = reinterpret_cast<const float4*>(dLT + row);
     const uint4* rp = reinterpret_cast<const uint4*>(RID + row);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dbn[i] = dp[i];
+    for (int i = 0; i < (DS32 ? 8 : 4); ++i) dbn[i] = dp[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ridn[i] = rp[i];
     gqn = reinterpret_cast<const float2*>(GQ)[min(tile * QT + c, N - 1)];
@@ -982,8 +1047,17 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const int nq = min(QT, N - q0);
     float dbr[32];
     unsigned ridw[16];
+    if constexpr (DS32) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dbr[4 * i] = dbn[i].x; dbr[4 * i + 1] = dbn[i].y; dbr[4 * i + 2] = dbn[i].z; dbr[4 * i + 3] = dbn[i].w; }
+      for (int i = 0; i < 8; ++i) { dbr[4 * i] = dbn[i].x; dbr[4 * i + 1] = dbn[i].y; dbr[4 * i + 2] = dbn[i].z; dbr[4 * i + 3] = dbn[i].w; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned w4[4] = {__float_as_uint(dbn[i].x), __float_as_uint(dbn[i].y), __float_as_uint(dbn[i].z), __float_as_uint(dbn[i].w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dbr[8 * i + 2 * j] = bf_lo(w4[j]); dbr[8 * i + 2 * j + 1] = bf_hi(w4[j]); }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ridw[4 * i] = ridn[i].x; ridw[4 * i + 1] = ridn[i].y; ridw[4 * i + 2] = ridn[i].z; ridw[4 * i + 3] = ridn[i].w; }
     if (!kvalid) {                                                  // lanes beyond the last key: no region, nothing accumulated
@@ -1024,11 +1098,14 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
       const int l = __ffsll((long long)todo) - 1;
       const float v0 = __shfl(vs0, l), v1 = __shfl(vs1, l);
       const int kl = __shfl(keyc, l);
-      const float* drow = dLT + ((size_t)(b * H + h) * NST + (size_t)q0) * J + (size_t)kl * 32;
+      const DS* drow = dLT + ((size_t)(b * H + h) * NST + (size_t)q0) * J + (size_t)kl * 32;
       for (unsigned m = (unsigned)__shfl((int)nonemask, l); m; m &= m - 1) {
         const int q = __ffs((int)m) - 1;
         const float d0 = GQ[(size_t)(q0 + q) * 2] - v0, d1 = GQ[(size_t)(q0 + q) * 2 + 1] - v1;
-        const float pp0 = slog1p(d0), pp1 = slog1p(d1), dbl = drow[q];
+        const float pp0 = slog1p(d0), pp1 = slog1p(d1);
+        float dbl;
+        if constexpr (DS32) dbl = drow[q];
+        else dbl = tof<__bf16>((unsigned)drow[q]);
         float h1; bool on2;
         (void)coop_mlp_fwd(mlp, pp0, pp1, c, h1, on2);
         float x2 = mlp.b2;                                          // x2 of unit c again (the forward helper returns only its sign)
@@ -1173,4 +1250,84 @@ __global__ __launch_bounds__(256) void region_final2_kernel(const double* __rest
 }
 
 // decisions of a pair for the parity tests: (D1, D2) of its region as two 32-bit words (tests only; pairs without a region: 0, flag)
+// ------------------------------------------------------------------------------------------------
+// host side shared by the fp32-grade (deform_attn.hip) and the 16-bit (deform_attn16.hip) region entry points
+// ------------------------------------------------------------------------------------------------
+static int ceil_log2_u64(unsigned long long x) { int k = 0; while ((1ull << k) < x && k < 63) ++k; return k; }
+struct RegionBwdPlan {
+  int chunks, tiles_per_chunk, nkb, wpk, kbits, shift;
+  size_t amax, hist, grad, dvs, part, total;       // byte offsets behind the dq / dkv workspace
+};
+static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
+  RegionBwdPlan p;
+  const int ntq = (N + QT - 1) / QT;
+  p.chunks = (512 + B * H - 1) / (B * H);
+  if (p.chunks < 1) p.chunks = 1;
+  if (p.chunks > ntq) p.chunks = ntq;
+  p.tiles_per_chunk = (ntq + p.chunks - 1) / p.chunks;
+  p.chunks = (ntq + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+  p.nkb = (J + 63) / 64;
+  p.wpk = p.nkb <= 12 ? 12 / p.nkb : 0;        // at most 12 waves per workgroup (three per SIMD at <= 168 registers)
+  if (p.wpk > p.tiles_per_chunk) p.wpk = p.tiles_per_chunk;
+  // fixed point: |d bias (1, p0, p1)| <= 4 amax (|p| <= log(1 + |d|) < 4 for any reachable offset); a workgroup adds at most
+  // tiles_per_chunk 32 J values into an LDS accumulator, the launch at most B H N J into a global one - both stay below 2^62
+  const int kl = 60 - ceil_log2_u64((unsigned long long)p.tiles_per_chunk * QT * J) - 2;
+  const int kg = 60 - ceil_log2_u64((unsigned long long)B * H * N * J) - 2;
+  p.kbits = kl < 38 ? kl : 38;
+  const int kgl = kg < p.kbits ? kg : p.kbits;
+  p.shift = p.kbits - kgl;
+  size_t o = (bwd_workspace(B, N, J, H).total * sizeof(float) + 255) & ~(size_t)255;
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+  p.amax = take(256);
+  p.hist = take((size_t)RG_RCAP * 3 * 8);
+  p.grad = take((size_t)RG_GRAD * 8);
+  p.dvs = take((size_t)p.chunks * B * H * J * 2 * sizeof(float));
+  p.part = take((size_t)(RG_RCAP / RG_FIN) * RG_GRAD * 8);
+  p.total = o;
+  return p;
+}
+
+static int check_region(const char* fn, int B, int N, int J, int H) {
+  SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0, "%s: non-positive dimension", fn);
+  SMML_REQUIRE(deform_dims_ok(B, N, J, H), "%s: B, H <= 65535, N <= 2^26, J <= 2^22 (got B %d N %d J %d H %d)", fn, B, N, J, H);
+  SMML_REQUIRE(J <= 768, "%s: the region kernels take at most 768 keys (got %d)", fn, J);
+  return SMML_OK;
+}
+
+
+// pass 3 of a region backward: d vs per pair, region moments (cpb_region_bwd_kernel<DS>), then the dense pass to the six parameter gradients.
+// wsb: the call's workspace (bytes), pl: its plan; amax | hist | grad were zeroed and amax filled by the dq pass of the caller.
+template <typename DS>
+static int region_bias_bwd_launch(const char* fn, const DS* dlogits, const unsigned short* region_ids, const float* vs, const float* gq, CpbParams cp,
+                                  const void* tables, char* wsb, const RegionBwdPlan& pl, int B, int N, int J, int H, int nst, int lcap, float* dvs,
+                                  float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* ev_start, void* ev_stop,
+                                  hipStream_t st) {
+  const RegionTables rt = region_tables(const_cast<void*>(tables));
+  const RegionView rv = region_view(const_cast<void*>(tables));
+  unsigned* amax = reinterpret_cast<unsigned*>(wsb + pl.amax);
+  unsigned long long* hist = reinterpret_cast<unsigned long long*>(wsb + pl.hist);
+  unsigned long long* grad = reinterpret_cast<unsigned long long*>(wsb + pl.grad);
+  float* dvs_slab = reinterpret_cast<float*>(wsb + pl.dvs);
+  double* part = reinterpret_cast<double*>(wsb + pl.part);
+  {   // 89 KB of dynamic LDS: above the 64 KB a kernel gets without asking (a host-side attribute of the function: cheap, idempotent)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_region_bwd_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(RegionBwdLds));
+    SMML_REQUIRE(e == hipSuccess, "%s: hipFuncSetAttribute failed: %s", fn, hipGetErrorString(e));
+  }
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  hipLaunchKernelGGL(cpb_region_bwd_kernel<DS>, dim3(pl.chunks, H, B), dim3(64 * pl.nkb * pl.wpk), sizeof(RegionBwdLds), st, dlogits, region_ids, vs,
+                     gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.wpk, pl.tiles_per_chunk, pl.kbits, pl.shift, lcap);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK(fn);
+  const size_t n = (size_t)B * H * J;
+  hipLaunchKernelGGL(region_dvs_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(dvs_slab),
+                     reinterpret_cast<float2*>(dvs), n, pl.chunks);
+  const int groups = RG_RCAP / RG_FIN;
+  hipLaunchKernelGGL(region_final1_kernel, dim3(groups), dim3(256), 0, st, rt, hist, part);
+  hipLaunchKernelGGL(region_final2_kernel, dim3((RG_GRAD + 255) / 256), dim3(256), 0, st, part, groups, grad, amax, pl.kbits - pl.shift, dw1, db1,
+                     dw2, db2, dw3, db3);
+  SMML_LAUNCH_CHECK(fn);
+  return SMML_OK;
+}
+
 }  // namespace

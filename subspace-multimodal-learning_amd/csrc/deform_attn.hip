@@ -1322,40 +1322,6 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
 // ------------------------------------------------------------------------------------------------
 // position bias per linear region (cpb_regions.h): exact, 2-D signed-log offsets, one head per offset group
 // ------------------------------------------------------------------------------------------------
-static int ceil_log2_u64(unsigned long long x) { int k = 0; while ((1ull << k) < x && k < 63) ++k; return k; }
-struct RegionBwdPlan {
-  int chunks, tiles_per_chunk, nkb, wpk, kbits, shift;
-  size_t amax, hist, grad, dvs, part, total;       // byte offsets behind the dq / dkv workspace
-};
-static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
-  RegionBwdPlan p;
-  const int ntq = (N + QT - 1) / QT;
-  p.chunks = (512 + B * H - 1) / (B * H);
-  if (p.chunks < 1) p.chunks = 1;
-  if (p.chunks > ntq) p.chunks = ntq;
-  p.tiles_per_chunk = (ntq + p.chunks - 1) / p.chunks;
-  p.chunks = (ntq + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
-  p.nkb = (J + 63) / 64;
-  p.wpk = p.nkb <= 12 ? 12 / p.nkb : 0;        // at most 12 waves per workgroup (three per SIMD at <= 168 registers)
-  if (p.wpk > p.tiles_per_chunk) p.wpk = p.tiles_per_chunk;
-  // fixed point: |d bias (1, p0, p1)| <= 4 amax (|p| <= log(1 + |d|) < 4 for any reachable offset); a workgroup adds at most
-  // tiles_per_chunk 32 J values into an LDS accumulator, the launch at most B H N J into a global one - both stay below 2^62
-  const int kl = 60 - ceil_log2_u64((unsigned long long)p.tiles_per_chunk * QT * J) - 2;
-  const int kg = 60 - ceil_log2_u64((unsigned long long)B * H * N * J) - 2;
-  p.kbits = kl < 38 ? kl : 38;
-  const int kgl = kg < p.kbits ? kg : p.kbits;
-  p.shift = p.kbits - kgl;
-  size_t o = (bwd_workspace(B, N, J, H).total * sizeof(float) + 255) & ~(size_t)255;
-  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-  p.amax = take(256);
-  p.hist = take((size_t)RG_RCAP * 3 * 8);
-  p.grad = take((size_t)RG_GRAD * 8);
-  p.dvs = take((size_t)p.chunks * B * H * J * 2 * sizeof(float));
-  p.part = take((size_t)(RG_RCAP / RG_FIN) * RG_GRAD * 8);
-  p.total = o;
-  return p;
-}
-
 size_t smml_cpb_regions_bytes(void) { return region_layout().total; }
 
 int smml_cpb_regions_build(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
@@ -1367,13 +1333,6 @@ int smml_cpb_regions_build(const float* w1, const float* b1, const float* w2, co
   SMML_REQUIRE((reinterpret_cast<size_t>(tables) & 255) == 0, "smml_cpb_regions_build: table buffer must be 256-byte aligned");
   region_build_launch(CpbParams{w1, b1, w2, b2, w3, b3}, pmax, tables, (hipStream_t)stream);
   SMML_LAUNCH_CHECK("smml_cpb_regions_build");
-  return SMML_OK;
-}
-
-static int check_region(const char* fn, int B, int N, int J, int H) {
-  int rc = check_common(fn, B, N, J, H, H, 2);
-  if (rc) return rc;
-  SMML_REQUIRE(J <= 768, "%s: the region kernels take at most 768 keys (got %d)", fn, J);
   return SMML_OK;
 }
 
@@ -1441,8 +1400,6 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
   float* wsf = reinterpret_cast<float*>(workspace);
   char* wsb = reinterpret_cast<char*>(workspace);
   unsigned* amax = reinterpret_cast<unsigned*>(wsb + pl.amax);
-  unsigned long long* hist = reinterpret_cast<unsigned long long*>(wsb + pl.hist);
-  unsigned long long* grad = reinterpret_cast<unsigned long long*>(wsb + pl.grad);
   // the accumulators of this launch: amax | hist | grad are contiguous
   (void)hipMemsetAsync(wsb + pl.amax, 0, pl.dvs - pl.amax, st);
   // pass 1: dS^T, dQ, max |dS|
@@ -1464,31 +1421,9 @@ int smml_deform_attn_region_bwd_f32(const float* q, const float* k, const float*
     SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/dkv_reduce");
   }
   // pass 3: position bias - d vs per pair, region moments, then the dense pass to the six parameter gradients
-  {
-    const RegionTables rt = region_tables(const_cast<void*>(tables));
-    const RegionView rv = region_view(const_cast<void*>(tables));
-    float* dvs_slab = reinterpret_cast<float*>(wsb + pl.dvs);
-    double* part = reinterpret_cast<double*>(wsb + pl.part);
-    {   // 89 KB of dynamic LDS: above the 64 KB a kernel gets without asking (a host-side attribute of the function: cheap, idempotent)
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cpb_region_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(RegionBwdLds));
-      SMML_REQUIRE(e == hipSuccess, "smml_deform_attn_region_bwd_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    }
-    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-    hipLaunchKernelGGL(cpb_region_bwd_kernel, dim3(pl.chunks, H, B), dim3(64 * pl.nkb * pl.wpk), sizeof(RegionBwdLds), st, dlogits_t,
-                       region_ids, vs, gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.wpk, pl.tiles_per_chunk, pl.kbits,
-                       pl.shift, lcap);
-    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
-    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/cpb");
-    const size_t n = (size_t)B * H * J;
-    hipLaunchKernelGGL(region_dvs_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float2*>(dvs_slab), reinterpret_cast<float2*>(dvs), n, pl.chunks);
-    const int groups = RG_RCAP / RG_FIN;
-    hipLaunchKernelGGL(region_final1_kernel, dim3(groups), dim3(256), 0, st, rt, hist, part);
-    hipLaunchKernelGGL(region_final2_kernel, dim3((RG_GRAD + 255) / 256), dim3(256), 0, st, part, groups, grad, amax, pl.kbits - pl.shift, dw1,
-                       db1, dw2, db2, dw3, db3);
-    SMML_LAUNCH_CHECK("smml_deform_attn_region_bwd_f32/final");
-  }
+  rc = region_bias_bwd_launch<float>("smml_deform_attn_region_bwd_f32", dlogits_t, region_ids, vs, gq, cp, tables, wsb, pl, B, N, J, H, nst, lcap, dvs,
+                                     dw1, db1, dw2, db2, dw3, db3, ev_start, ev_stop, st);
+  if (rc) return rc;
   return SMML_OK;
 }
 

@@ -18,6 +18,8 @@
 // max, normaliser, log-sum-exp), delta = rowsum(dO . O), all parameter-gradient sums, q / k / v / out and their gradients in memory.
 // Per (key, 32 queries) that is 3 + 8/32 MFMAs forward (7 + 24/32 in the fp32-grade path) and 8 backward (12).
 #include "deform_common.h"
+#include "deform16_types.h"
+#include "cpb_regions.h"
 
 // measurement knobs of this file (tests/build_variants.py)
 #ifndef SMML16_FWD_WPS
@@ -40,60 +42,6 @@
 #endif
 
 namespace {
-
-typedef unsigned short u16;
-
-// ---- element-type plumbing: T = _Float16 or __bf16 ----
-template <typename T> struct Vec8;
-template <> struct Vec8<_Float16> { typedef half8 type; };
-template <> struct Vec8<__bf16> { typedef bf16x8 type; };
-__device__ __forceinline__ floatx16 mma(half8 a, half8 b, floatx16 c) { return mfma16(a, b, c); }
-__device__ __forceinline__ floatx16 mma(bf16x8 a, bf16x8 b, floatx16 c) { return mfma16b(a, b, c); }
-// two fp32 -> one 32-bit word of two T (round to nearest even; element 0 in the low half)
-template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
-template <> __device__ __forceinline__ unsigned pack2<_Float16>(float a, float b) {
-  const float2v v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2v));
-}
-template <> __device__ __forceinline__ unsigned pack2<__bf16>(float a, float b) {
-  const float2v v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-template <typename T> __device__ __forceinline__ typename Vec8<T>::type cvt8(const float (&x)[8]) {
-  const uint4v w = {pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]), pack2<T>(x[4], x[5]), pack2<T>(x[6], x[7])};
-  return __builtin_bit_cast(typename Vec8<T>::type, w);
-}
-template <typename T> __device__ __forceinline__ uint2v pack4(const float4 v) {
-  return (uint2v){pack2<T>(v.x, v.y), pack2<T>(v.z, v.w)};
-}
-// 16-bit pattern -> fp32
-template <typename T> __device__ __forceinline__ float tof(unsigned u16bits);
-template <> __device__ __forceinline__ float tof<__bf16>(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-template <> __device__ __forceinline__ float tof<_Float16>(unsigned u) { return (float)__builtin_bit_cast(_Float16, (u16)u); }
-__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
-// MFMA fragment of an operand stored k-major in LDS (two hardware-transposed reads, smml_common.h lds_frag_tr), any 16-bit type
-template <typename T> __device__ __forceinline__ typename Vec8<T>::type frag_tr(const T* p0, const T* p1) {
-  typedef short short4v __attribute__((ext_vector_type(4)));
-  typedef short short8v __attribute__((ext_vector_type(8)));
-  typedef __attribute__((address_space(3))) short4v lds_s4;
-  const short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p0);
-  const short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)p1);
-  const short8v r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-  return __builtin_bit_cast(typename Vec8<T>::type, r);
-}
-// Stored scores are fp16 in BOTH modes: they are of forward range (softmax logits; clamped to +-60000 so that nothing rounds to inf)
-// and fp16's 11 significant bits keep exp(score - lse) to 2^-11 |score| - eight times finer than bf16 at the same two bytes.
-__device__ __forceinline__ unsigned pack_score(float a, float b) {
-  return pack2<_Float16>(fminf(fmaxf(a, -60000.f), 60000.f), fminf(fmaxf(b, -60000.f), 60000.f));
-}
-__device__ __forceinline__ float score_of(unsigned u) { return tof<_Float16>(u); }
-// The dropout keep decision REPLACES the lowest mantissa bit of a stored fp16 score (one v_and_or per pair; the fp32 path nudges the
-// value by a zero-mean ulp instead - at fp16's 2^-11 the half-ulp this costs is below the rounding the score already carries)
-__device__ __forceinline__ unsigned stash_keep16(unsigned u, bool keep) { return (u & 0xFFFEu) | (keep ? 1u : 0u); }
-__device__ __forceinline__ unsigned stash_keep16x2(unsigned w, unsigned two_bits) {      // bit 0 -> low half, bit 1 -> high half
-  return (w & 0xFFFEFFFEu) | (two_bits & 1u) | ((two_bits & 2u) << 15);
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward.  One wave = 32 queries on the lane axis (deform_attn.hip's mapping); K / V tiles are converted to T when staged
@@ -397,9 +345,10 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
     const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O, const float* __restrict__ dO,
     const float* __restrict__ LSE, const u16* __restrict__ LT, u16* __restrict__ dLT, float* __restrict__ dQ, int N, int J,
-    int H, int NST, float scale, DropCfg dc_in) {
+    int H, int NST, float scale, DropCfg dc_in, unsigned* __restrict__ AMAX = nullptr) {
   typedef typename Vec8<T>::type vec8;
   const DropCfg dc = drop_resolve(dc_in);
+  float amax = 0.f;      // max |d scores| of this lane (region backward: scale of its fixed-point moment sums); AMAX may be null
   __shared__ __attribute__((aligned(16))) T Vp[2][KT * VBLD];          // V in the FORWARD's operand type (dP = V dO^T must see the V that made O)
   __shared__ __attribute__((aligned(16))) __bf16 Kp[2][KT * KBLD];
 
@@ -520,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
         }
         v2[e] = v;
         ds[r + e] = v;
+        amax = fmaxf(amax, fabsf(v));
       }
       const unsigned w = pack2<__bf16>(v2[0], v2[1]);
       const int k0 = acc_row(r, hf), k1 = acc_row(r + 1, hf);
@@ -537,6 +487,10 @@ __global__ __launch_bounds__(256, 2) void deform16_bwd_dq_kernel(
       dq0 = mfma16b(lds_frag_tr(&Kp[buf][ro], &Kp[buf][ro + 8 * KBLD]), sb, dq0);
       dq1 = mfma16b(lds_frag_tr(&Kp[buf][ro + 32], &Kp[buf][ro + 32 + 8 * KBLD]), sb, dq1);
     }
+  }
+  if (AMAX) {                                               // non-negative floats order like their bit patterns
+    amax = wave_max_all(amax);
+    if (lane == 0 && amax > 0.f) atomicMax(AMAX, __float_as_uint(amax));
   }
   if (qvalid) {
     float* qp = dQ + ((size_t)b * N + qi) * HD + h * DH;
@@ -1600,6 +1554,101 @@ int smml_deform_attn16_bwd(const float* q, const float* k, const float* v, const
     SMML_LAUNCH_CHECK("smml_deform_attn16_bwd/reduce");
   }
   return SMML_OK;
+}
+
+// ---- position bias per linear region (cpb_regions.h) in the 16-bit compute modes: the bias is the fp32 lookup of the fp32-grade path, the
+// attention core runs on single-term T operands with fp16 scores / bf16 d scores (2-D signed-log offsets, one head per offset group)
+int smml_deform_attn16_region_fwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const void* tables,
+                                  float* out, float* lse, unsigned short* logits16, unsigned short* region_ids, int B, int N, int J, int H,
+                                  float scale, float dropout_p, unsigned long long dropout_seed, int dtype, void* ev_start, void* ev_stop,
+                                  void* stream, const SmmlDeformOpts* opts) {
+  int rc = check_region("smml_deform_attn16_region_fwd", B, N, J, H);
+  if (rc) return rc;
+  SMML_REQUIRE(dtype == 0 || dtype == 1, "smml_deform_attn16_region_fwd: dtype must be 0 (bf16) or 1 (fp16), got %d", dtype);
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_region_fwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && tables && out && lse, "smml_deform_attn16_region_fwd: null pointer");
+  SMML_REQUIRE((logits16 == nullptr) == (region_ids == nullptr),
+               "smml_deform_attn16_region_fwd: logits16 and region_ids are saved together (training) or not at all");
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
+  const int lcap = (opts && opts->region_lds_cap > 0) ? (opts->region_lds_cap < RG_LCAP ? opts->region_lds_cap : RG_LCAP) : RG_LCAP;
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  const RegionView rv = region_view(const_cast<void*>(tables));
+  dim3 grid((N + QT * WAVES - 1) / (QT * WAVES), H, B), block(256);
+  const int nst = smml_deform_attn_nst(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (dtype == 1) {
+    if (region_ids)
+      hipLaunchKernelGGL((deform_region_fwd_kernel<true, _Float16>), grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits16, region_ids, N, J, H, nst, scale, dc, lcap);
+    else
+      hipLaunchKernelGGL((deform_region_fwd_kernel<false, _Float16>), grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits16, region_ids, N, J, H, nst, scale, dc, lcap);
+  } else {
+    if (region_ids)
+      hipLaunchKernelGGL((deform_region_fwd_kernel<true, __bf16>), grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits16, region_ids, N, J, H, nst, scale, dc, lcap);
+    else
+      hipLaunchKernelGGL((deform_region_fwd_kernel<false, __bf16>), grid, block, 0, st, q, k, v, vs, gq, cp, rv, out, lse, logits16, region_ids, N, J, H, nst, scale, dc, lcap);
+  }
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  SMML_LAUNCH_CHECK("smml_deform_attn16_region_fwd");
+  return SMML_OK;
+}
+
+/* workspace: smml_deform_attn_region_bwd_workspace_bytes (the fp32-grade region backward's), 256-byte aligned */
+int smml_deform_attn16_region_bwd(const float* q, const float* k, const float* v, const float* vs, const float* gq, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, const void* tables,
+                                  const float* out, const float* dout, const float* lse, const unsigned short* logits16,
+                                  const unsigned short* region_ids, unsigned short* dlogits16, float* dq, float* dk, float* dv, float* dvs,
+                                  float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* workspace,
+                                  size_t workspace_bytes, int B, int N, int J, int H, float scale, float dropout_p,
+                                  unsigned long long dropout_seed, int dtype, void* ev_start, void* ev_stop, void* stream,
+                                  const SmmlDeformOpts* opts) {
+  int rc = check_region("smml_deform_attn16_region_bwd", B, N, J, H);
+  if (rc) return rc;
+  SMML_REQUIRE(dtype == 0 || dtype == 1, "smml_deform_attn16_region_bwd: dtype must be 0 (bf16) or 1 (fp16), got %d", dtype);
+  SMML_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "smml_deform_attn16_region_bwd: dropout_p must be in [0, 1)");
+  SMML_REQUIRE(q && k && v && vs && gq && w1 && b1 && w2 && b2 && w3 && b3 && tables && out && dout && lse && logits16 && region_ids &&
+                   dlogits16 && dq && dk && dv && dvs && dw1 && db1 && dw2 && db2 && dw3 && db3 && workspace,
+               "smml_deform_attn16_region_bwd: null pointer");
+  const RegionBwdPlan pl = region_bwd_plan(B, N, J, H);
+  SMML_REQUIRE(workspace_bytes >= pl.total, "smml_deform_attn16_region_bwd: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+  SMML_REQUIRE((reinterpret_cast<size_t>(workspace) & 255) == 0, "smml_deform_attn16_region_bwd: workspace must be 256-byte aligned");
+  SMML_REQUIRE(pl.wpk >= 1, "smml_deform_attn16_region_bwd: too many keys (%d)", J);
+  const DropCfg dc = make_drop(dropout_p, dropout_seed, opts);
+  const int lcap = (opts && opts->region_lds_cap > 0) ? (opts->region_lds_cap < RG_LCAP ? opts->region_lds_cap : RG_LCAP) : RG_LCAP;
+  CpbParams cp{w1, b1, w2, b2, w3, b3};
+  hipStream_t st = (hipStream_t)stream;
+  const int nst = smml_deform_attn_nst(N);
+  const int qtiles = (N + QT * WAVES - 1) / (QT * WAVES);
+  dim3 block(256);
+  const BwdWorkspace wsl = bwd_workspace(B, N, J, H);
+  float* wsf = reinterpret_cast<float*>(workspace);
+  char* wsb = reinterpret_cast<char*>(workspace);
+  unsigned* amax = reinterpret_cast<unsigned*>(wsb + pl.amax);
+  (void)hipMemsetAsync(wsb + pl.amax, 0, pl.dvs - pl.amax, st);        // amax | hist | grad are contiguous
+  // pass 1: d scores (bf16), dQ, max |d scores|
+  if (dtype == 1)
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<_Float16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc, amax);
+  else
+    hipLaunchKernelGGL(deform16_bwd_dq_kernel<__bf16>, dim3(qtiles, H, B), block, 0, st, k, v, out, dout, lse, logits16, dlogits16, dq, N, J, H, nst, scale, dc, amax);
+  SMML_LAUNCH_CHECK("smml_deform_attn16_region_bwd/dq");
+  // pass 2: dK, dV (query-sliced partial sums, then a fixed-order reduction)
+  {
+    const int nkg = (J + DKV_KEYS - 1) / DKV_KEYS, nqt = (N + QT - 1) / QT;
+    const int parts = dkv_parts(B, N, J, H), tpp = (nqt + parts - 1) / parts;
+    const int nslices = parts * H * B;
+    const dim3 gk(((nslices + 7) / 8) * 8 * nkg);
+    hipLaunchKernelGGL(deform16_bwd_dkv_kernel, gk, block, 0, st, q, dout, lse, logits16, dlogits16, wsf + wsl.dkp, wsf + wsl.dvp, N, J, H, nst, nkg, tpp, parts, B, dc);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_region_bwd/dkv");
+    const size_t n4 = (size_t)B * J * H * DH / 4;
+    hipLaunchKernelGGL(dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), block, 0, st,
+                       reinterpret_cast<const float4*>(wsf + wsl.dkp), reinterpret_cast<const float4*>(wsf + wsl.dvp),
+                       reinterpret_cast<float4*>(dk), reinterpret_cast<float4*>(dv), n4, parts, scale);
+    SMML_LAUNCH_CHECK("smml_deform_attn16_region_bwd/dkv_reduce");
+  }
+  // pass 3: position bias per region on the bf16 d scores
+  return region_bias_bwd_launch<u16>("smml_deform_attn16_region_bwd", dlogits16, region_ids, vs, gq, cp, tables, wsb, pl, B, N, J, H, nst, lcap, dvs,
+                                     dw1, db1, dw2, db2, dw3, db3, ev_start, ev_stop, st);
 }
 
 // mask table of the table-forward backward (include/smml.h): cells per axis, and the kernel that fills one

@@ -159,8 +159,8 @@ class DeformCrossAttention2D(nn.Module):
         return Fh.table_pmax(gqb, vsb)
 
     def _regions_apply(self) -> bool:
-        return (Fh.CPB_REGIONS and self.compute_dtype is None and not self.consistent_grid_norm and self.heads == self.offset_groups
-                and self.rel_pos_bias.mlp[0][0].weight.is_cuda)
+        return (Fh.CPB_REGIONS and not self.cpb_table and not self.consistent_grid_norm and self.heads == self.offset_groups
+                and self.rel_pos_bias.mlp[0][0].weight.is_cuda)          # fp32-grade core and the 16-bit compute modes alike
 
     def prefetch_regions(self, n_tokens: int) -> None:
         """Starts the build of the position bias's region tables on a side stream (functional.RegionPrefetch); the next forward_tokens on
@@ -198,7 +198,7 @@ class DeformCrossAttention2D(nn.Module):
         lo_q, lo_k = max(min(Hh, Ww) - 1, 1), max(min(th, tw) - 1, 1)
         gqb = max(1.0, abs(2.0 * (max(Hh, Ww) - 1) / lo_q - 1.0))
         vsb = max(abs(2.0 * (max(th, tw) - 1 + self.offset_scale) / lo_k - 1.0), 1.0 + 2.0 * self.offset_scale / lo_k)
-        if self.compute_dtype is None and not self.consistent_grid_norm:
+        if not self.cpb_table and not self.consistent_grid_norm:
             # the square the region tables of the position bias cover (no host sync), and the build started by prefetch_regions, if any
             tab = {"cpb_region_pmax": self._region_pmax(Hh, Ww), "cpb_region_prefetch": getattr(self, "_prefetch", None)}
             self._prefetch = None

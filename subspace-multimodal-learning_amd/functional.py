@@ -983,8 +983,8 @@ class _DeformAttn(torch.autograd.Function):
         tabfwd = table_pmax_fwd is not None           # 16-bit mode, forward bias from the table; the backward takes layer 2's decisions from a mask table
         ctx.table_pmax = table_pmax_fwd               # (or recomputes layer 2 per pair: TABLE_FORWARD_MASKS)
         ctx.export_masks = None
-        regions = (region_pmax is not None and m16 is None and not tabfwd and posdim == 2 and log_distance and heads == groups
-                   and J <= REGION_MAX_KEYS and tuple(w3.shape) == (1, 32))
+        regions = (region_pmax is not None and not tabfwd and posdim == 2 and log_distance and heads == groups
+                   and J <= REGION_MAX_KEYS and tuple(w3.shape) == (1, 32))        # fp32-grade core or (m16) the 16-bit core, same lookup
         ctx.regions = regions
         if regions:
             if region_prefetch is not None and region_prefetch.matches(w1, b1, w2, b2, w3, b3, region_pmax):
@@ -994,14 +994,23 @@ class _DeformAttn(torch.autograd.Function):
             rid = None
             if need_grad:
                 nst = L.smml_deform_attn_nst(N)
-                logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32)
+                logits = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.float32 if m16 is None else torch.float16)
                 rid = torch.empty(B, heads, nst // 32, J, 32, device=q.device, dtype=torch.int16)      # the linear piece of every pair
-            capi.check(L.smml_deform_attn_region_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
-                                                         capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
-                                                         capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.fptr(logits),
-                                                         capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
-                                                         *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream(),
-                                                         capi.deform_opts(seed_offset, region_lds_cap=REGION_LDS_CAP)), "deform_attn_region_fwd")
+            ropts = capi.deform_opts(seed_offset, region_lds_cap=REGION_LDS_CAP)
+            if m16 is None:
+                capi.check(L.smml_deform_attn_region_fwd_f32(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                                             capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                                             capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.fptr(logits),
+                                                             capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
+                                                             *TIMER.events("deform_region_fwd", B * heads * N * J), capi.stream(), ropts),
+                           "deform_attn_region_fwd")
+            else:
+                capi.check(L.smml_deform_attn16_region_fwd(capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq),
+                                                           capi.fptr(w1), capi.fptr(b1), capi.fptr(w2), capi.fptr(b2), capi.fptr(w3),
+                                                           capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(lse), capi.ptr(logits),
+                                                           capi.ptr(rid), B, N, J, heads, float(scale), float(dropout_p), int(dropout_seed),
+                                                           m16[0], *TIMER.events("deform16_region_fwd", B * heads * N * J), capi.stream(), ropts),
+                           "deform_attn16_region_fwd")
             ctx.seed_offset = seed_offset
             ctx.cfg = (heads, groups, float(scale), float(dropout_p), int(dropout_seed), m16)
             ctx.save_for_backward(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, out, lse, logits, rid, tables)
@@ -1107,12 +1116,24 @@ class _DeformAttn(torch.autograd.Function):
         J = k.shape[1]
         L = capi.lib()
         dout = _c(dout)
-        dlogits = torch.empty_like(logits)
+        m16 = ctx.cfg[5]
+        dlogits = torch.empty_like(logits) if m16 is None else torch.empty(logits.shape, device=q.device, dtype=torch.bfloat16)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dvs = torch.empty_like(vs)
         dw1, db1, dw2, db2, dw3, db3 = (torch.empty_like(t) for t in (w1, b1, w2, b2, w3, b3))
         wsb = L.smml_deform_attn_region_bwd_workspace_bytes(B, N, J, heads)
         ws = torch.empty(wsb, device=q.device, dtype=torch.uint8)
+        if m16 is not None:
+            capi.check(L.smml_deform_attn16_region_bwd(
+                capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1), capi.fptr(w2),
+                capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
+                capi.ptr(logits), capi.ptr(rid), capi.ptr(dlogits), capi.fptr(dq), capi.fptr(dk), capi.fptr(dv), capi.fptr(dvs),
+                capi.fptr(dw1), capi.fptr(db1), capi.fptr(dw2), capi.fptr(db2), capi.fptr(dw3), capi.fptr(db3), capi.ptr(ws), wsb,
+                B, N, J, heads, scale, dropout_p, dropout_seed, m16[0], *TIMER.events("cpb16_region_bwd", B * heads * N * J), capi.stream(),
+                capi.deform_opts(ctx.seed_offset, region_lds_cap=REGION_LDS_CAP)), "deform_attn16_region_bwd")
+            if ctx.fork is not None and ctx.needs_input_grad[0]:
+                ctx.fork.dq = dq.view(B, N, -1)
+            return dq, dk, dv, dvs, None, dw1, db1, dw2, db2, dw3, db3, None, None, None, None, None, None, None, None, None, None, None, None
         capi.check(L.smml_deform_attn_region_bwd_f32(
             capi.fptr(q), capi.fptr(k), capi.fptr(v), capi.fptr(vs), capi.fptr(gq), capi.fptr(w1), capi.fptr(b1), capi.fptr(w2),
             capi.fptr(b2), capi.fptr(w3), capi.fptr(b3), capi.ptr(tables), capi.fptr(out), capi.fptr(dout), capi.fptr(lse),
@@ -1281,7 +1302,7 @@ def deform_attention(q, k, v, vs, gq, w1, b1, w2, b2, w3, b3, *, heads: int, gro
     # overrides the default, cpb_region_pmax = half-width of the tabulated square in signed-log units (None: from the data, one host sync)
     use_regions = CPB_REGIONS if cpb_regions is None else bool(cpb_regions)
     region_pmax = None
-    if (use_regions and compute_dtype is None and log_distance and vs.shape[-1] == 2 and heads == groups and k.shape[1] <= REGION_MAX_KEYS
+    if (use_regions and log_distance and vs.shape[-1] == 2 and heads == groups and k.shape[1] <= REGION_MAX_KEYS
             and tuple(w3.shape) == (1, 32)):
         if cpb_region_pmax is not None:
             region_pmax = cpb_region_pmax

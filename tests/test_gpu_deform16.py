@@ -68,8 +68,10 @@ def test_fused_core16_random_shapes(cuda, mode, tabfwd, monkeypatch):
             # tabfwd: the forward's bias comes from the table (cpb_table='forward'), the backward recomputes layer 2 (always one bf16 term) and
             # exports the decisions it took - everything below then applies unchanged
             tkw = dict(cpb_table="forward", cpb_table_pmax=Fh.table_pmax(1.0, 1.2)) if tabfwd else {}
+            # (cpb_regions=False: this test pins the per-pair MLP kernels of the 16-bit core; the region form of the same core is covered by
+            # tests/test_gpu_regions.py and by the module-level tests below, which take it wherever it applies)
             out = Fh.deform_attention(*(dev[n] for n in names), heads=heads, groups=groups, scale=0.125, dropout_p=p_drop,
-                                      dropout_seed=seed, compute_dtype=mode, **tkw)
+                                      dropout_seed=seed, compute_dtype=mode, cpb_regions=False, **tkw)
         finally:
             smml.functional.DECISION_TAP = None
         (out * wo.to(cuda)).sum().backward()

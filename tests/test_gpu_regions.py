@@ -109,13 +109,13 @@ def _problem(gen, B, N, J, heads, wkind="random", vs_scale=1.2):
                 w1=w[0], b1=w[1], w2=w[2], b2=w[3], w3=w[4], b3=w[5])
 
 
-def _run(t, cuda, wo, regions, p_drop=0.0, seed=3, heads=8, tap=False):
+def _run(t, cuda, wo, regions, p_drop=0.0, seed=3, heads=8, tap=False, compute_dtype=None):
     dev = {n: x.to(cuda).requires_grad_(n != "gq") for n, x in t.items()}
     if tap:
         Fh.DECISION_TAP = tapped = []
     try:
         out = Fh.deform_attention(*(dev[n] for n in NAMES), heads=heads, groups=heads, scale=0.125, dropout_p=p_drop, dropout_seed=seed,
-                                  cpb_regions=regions)
+                                  cpb_regions=regions, compute_dtype=compute_dtype)
     finally:
         if tap:
             Fh.DECISION_TAP = None
@@ -160,6 +160,33 @@ def test_region_core_matches_per_pair_mlp(cuda, wkind, B, N, J, p_drop):
         err = float((a[n] - c[n]).abs().max()) / scale
         tol = 0.0 if n in ("out",) else (2e-6 if n in ("q", "k", "v") else 2e-5)
         assert err <= tol, f"{wkind} {B}x{N}x{J}: {n} differs by {err:.2e} between LDS-resident and global-memory regions"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("wkind,B,N,J,p_drop", [("random", 2, 700, 150, 0.1), ("bench", 1, 1500, 144, 0.0), ("torch", 3, 129, 33, 0.25), ("random", 2, 5, 3, 0.0)])
+def test_region_core_in_the_16bit_modes(cuda, mode, wkind, B, N, J, p_drop):
+    """The region form of the 16-bit compute modes (smml_deform_attn16_region_fwd / _bwd: single-term operands, fp16 scores, bf16 d scores,
+    the position bias by the SAME fp32 lookup) against the fp32-grade region kernels on the same inputs: same region ids (the lookup does
+    not depend on the mode), outputs and gradients within the 16-bit bounds of tests/test_gpu_deform16.py, and run-to-run identical.
+    Its parity with the fp64 oracle under imposed decisions is checked at module level (test_deform2d_16bit_vs_oracle,
+    test_cfg4_full_fusion_16bit: both take this path)."""
+    gen = torch.Generator().manual_seed(200 + N + J)
+    t = _problem(gen, B, N, J, 8, wkind)
+    wo = torch.randn(B, N, 512, generator=gen).to(cuda)
+    a, tap_a = _run(t, cuda, wo, True, p_drop, tap=True)
+    b, tap_b = _run(t, cuda, wo, True, p_drop, tap=True, compute_dtype=mode)
+    assert tap_b[0].get("region_ids") is not None, "the 16-bit call did not take the region path"
+    assert torch.equal(tap_a[0]["region_ids"], tap_b[0]["region_ids"]), "the region ids depend on the compute mode"
+    for n in a:
+        scale = max(float(a[n].abs().max()), 1e-30)
+        if n == "b3" or float(a[n].abs().max()) < 1e-9:       # (d b3 = sum of all d scores: zero in exact arithmetic, rounding in both paths)
+            continue
+        err = float((a[n] - b[n]).abs().max()) / scale
+        tol = 1.5e-2 if n == "out" else (3e-2 if n in ("q", "k", "v", "vs") else 6e-2)
+        assert err <= tol, f"{mode} {wkind} {B}x{N}x{J}: {n} differs by {err:.2e} of its scale from the fp32-grade region kernels"
+    b2 = _run(t, cuda, wo, True, p_drop, compute_dtype=mode)
+    for n in b:
+        assert torch.equal(b[n], b2[n]), f"{n}: the 16-bit region path is not run-to-run identical"
 
 
 def test_region_core_vs_fp64_with_imposed_decisions(cuda):
