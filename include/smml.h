@@ -211,7 +211,7 @@ int smml_deform_attn_bwd_f32(const float* q, const float* k, const float* v, con
  * several kinks cross are refined once, what is left evaluates the MLP itself), and the forward / backward below replace the per-pair MLP
  * by a lookup + 2 FMAs, resp. by three fixed-point moment sums per region from which all six parameter gradients follow linearly.
  * Results are those of smml_deform_attn_fwd_f32 / _bwd_f32 to fp32 rounding (no tolerance added: tests/test_gpu_parity.py runs both);
- * posdim = 2, signed-log offsets, one head per offset group (G = H), J <= 768.
+ * posdim = 2, signed-log offsets, one head per offset group (G = H), J <= 16384.
  *   tables: caller-allocated scratch of smml_cpb_regions_bytes() bytes, 256-byte aligned; built per forward call (the parameters change
  *           every step), handed unchanged to the backward of the same call.  pmax >= max |slog(gq - vs)| for speed only: pairs
  *           outside the square evaluate the MLP.

@@ -32,6 +32,7 @@ namespace {
 #ifndef SMML_RGN_EXP
 #define SMML_RGN_EXP 0                   // measurement variants of the region forward (tests/build_variants.py): 1 no cell gather, 2 no record /
 #endif                                   // sub-cell resolution, 3 no score store, 4 no region-id store, 5 no signed logs, 6 no LDS (a, c) read
+constexpr int RG_MAX_KEYS = 16384;       // keys per (bag, head) the region entry points accept
 constexpr int RG_G = 1024;               // level-0 cells per axis
 constexpr int RG_SUB = 8;                // sub-cells per axis of a refined cell
 constexpr int RG_SUBC = (RG_SUB + 1) * (RG_SUB + 1);
@@ -959,7 +960,9 @@ struct RegionBwdLds {                    // dynamic LDS of cpb_region_bwd_kernel
   float2 dvs[16][64];                    // per-wave d vs of its key block (combined in a fixed order at the end)
 };
 
-// grid (chunks, H, B); block = 64 * nkb * wpk threads (<= 768): wave w owns the keys lane * nkb + (w % nkb) (lane = key; keys of one
+// grid (chunks * key groups, H, B); block = 64 * nkbg * wpk threads (<= 768), nkbg = key blocks of one group (all nkb = ceil(J / 64) of
+// them up to 768 keys; more keys: groups of <= 12 key blocks, each group its own workgroups): wave w of group g owns the keys
+// lane * nkb + g * nkbg + (w % nkbg) (lane = key; keys of one
 // wave are nkb apart, so that its lanes fall into different regions: no same-address serialisation of the LDS adds) and every wpk-th
 // query tile (32 queries) of the chunk.  For each of its tiles a lane reads its key's 32 d scores and 32 region ids (one 128-byte and
 // one 64-byte row, the next tile's rows and query positions in flight meanwhile) and walks the queries: no cross-lane sums for d vs; the
@@ -971,12 +974,13 @@ template <typename DS>
 __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
     const DS* __restrict__ dLT, const unsigned short* __restrict__ RID, const float* __restrict__ VS, const float* __restrict__ GQ,
     CpbParams cp, RegionView rv, const unsigned* __restrict__ AMAX, unsigned long long* __restrict__ HIST, unsigned long long* __restrict__ GRAD,
-    float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int wpk, int tiles_per_chunk, int kbits, int shift, int lcap) {
+    float* __restrict__ dvs_slab, int N, int J, int H, int NST, int nkb, int nkbg, int chunks, int wpk, int tiles_per_chunk, int kbits, int shift,
+    int lcap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   RegionBwdLds& L = *reinterpret_cast<RegionBwdLds*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform in a scalar register: tile indices, bounds and the query positions stay scalar
-  const int b = blockIdx.z, h = blockIdx.y, chunk = blockIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y, chunk = blockIdx.x % chunks, grp = blockIdx.x / chunks;
   const int nthreads = blockDim.x;
   {
     const int nreg = min((int)rv.hdr->n_regions, lcap);       // lcap <= RG_LCAP: regions with LDS accumulators (tests lower it)
@@ -993,9 +997,9 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   asm("s_mov_b32 %0, 0x71800000" : "=s"(big));
 
   // (the division runs on the vector unit: back to scalar registers)
-  const int kb = __builtin_amdgcn_readfirstlane(wave % nkb), tslot = __builtin_amdgcn_readfirstlane(wave / nkb);   // waves beyond nkb * wpk do not exist (block size)
+  const int kb = grp * nkbg + __builtin_amdgcn_readfirstlane(wave % nkbg), tslot = __builtin_amdgcn_readfirstlane(wave / nkbg);   // waves beyond nkbg * wpk do not exist (block size)
   const int key = lane * nkb + kb;
-  const bool kvalid = key < J;
+  const bool kvalid = key < J && kb < nkb;                          // (the last key group may have key blocks to spare: kb >= nkb would alias lane + 1's keys)
   const int keyc = min(key, J - 1);
   const float vs0 = VS[((size_t)(b * H + h) * J + keyc) * 2], vs1 = VS[((size_t)(b * H + h) * J + keyc) * 2 + 1];
   const int ntq = (N + QT - 1) / QT;
@@ -1141,9 +1145,9 @@ __global__ __launch_bounds__(768) void cpb_region_bwd_kernel(
   L.dvs[wave][lane] = make_float2(dv0, dv1);
   __syncthreads();
   // d vs of this chunk: the wpk waves of a key block in a fixed order -> slab [chunk][b, h][J]
-  if (wave < nkb && kvalid) {
+  if (wave < nkbg && kvalid) {
     float2 sum = L.dvs[wave][lane];
-    for (int s2 = 1; s2 < wpk; ++s2) { const float2 t = L.dvs[wave + s2 * nkb][lane]; sum.x += t.x; sum.y += t.y; }
+    for (int s2 = 1; s2 < wpk; ++s2) { const float2 t = L.dvs[wave + s2 * nkbg][lane]; sum.x += t.x; sum.y += t.y; }
     reinterpret_cast<float2*>(dvs_slab)[((size_t)chunk * gridDim.z * gridDim.y + (size_t)(b * H + h)) * J + key] = sum;
   }
   // moments and direct gradient sums -> global 64-bit accumulators (coarser scale: 2^-shift, rounded)
@@ -1255,7 +1259,7 @@ __global__ __launch_bounds__(256) void region_final2_kernel(const double* __rest
 // ------------------------------------------------------------------------------------------------
 static int ceil_log2_u64(unsigned long long x) { int k = 0; while ((1ull << k) < x && k < 63) ++k; return k; }
 struct RegionBwdPlan {
-  int chunks, tiles_per_chunk, nkb, wpk, kbits, shift;
+  int chunks, tiles_per_chunk, nkb, nkbg, ngrp, wpk, kbits, shift;
   size_t amax, hist, grad, dvs, part, total;       // byte offsets behind the dq / dkv workspace
 };
 static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
@@ -1267,7 +1271,9 @@ static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
   p.tiles_per_chunk = (ntq + p.chunks - 1) / p.chunks;
   p.chunks = (ntq + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
   p.nkb = (J + 63) / 64;
-  p.wpk = p.nkb <= 12 ? 12 / p.nkb : 0;        // at most 12 waves per workgroup (three per SIMD at <= 168 registers)
+  p.ngrp = (p.nkb + 11) / 12;                  // at most 12 waves per workgroup (three per SIMD at <= 168 registers): more than 768 keys
+  p.nkbg = (p.nkb + p.ngrp - 1) / p.ngrp;      // are split into groups of key blocks, each group with workgroups of its own
+  p.wpk = 12 / p.nkbg;
   if (p.wpk > p.tiles_per_chunk) p.wpk = p.tiles_per_chunk;
   // fixed point: |d bias (1, p0, p1)| <= 4 amax (|p| <= log(1 + |d|) < 4 for any reachable offset); a workgroup adds at most
   // tiles_per_chunk 32 J values into an LDS accumulator, the launch at most B H N J into a global one - both stay below 2^62
@@ -1290,7 +1296,7 @@ static RegionBwdPlan region_bwd_plan(int B, int N, int J, int H) {
 static int check_region(const char* fn, int B, int N, int J, int H) {
   SMML_REQUIRE(B > 0 && N > 0 && J > 0 && H > 0, "%s: non-positive dimension", fn);
   SMML_REQUIRE(deform_dims_ok(B, N, J, H), "%s: B, H <= 65535, N <= 2^26, J <= 2^22 (got B %d N %d J %d H %d)", fn, B, N, J, H);
-  SMML_REQUIRE(J <= 768, "%s: the region kernels take at most 768 keys (got %d)", fn, J);
+  SMML_REQUIRE(J <= RG_MAX_KEYS, "%s: the region kernels take at most %d keys (got %d)", fn, RG_MAX_KEYS, J);
   return SMML_OK;
 }
 
@@ -1315,8 +1321,9 @@ static int region_bias_bwd_launch(const char* fn, const DS* dlogits, const unsig
     SMML_REQUIRE(e == hipSuccess, "%s: hipFuncSetAttribute failed: %s", fn, hipGetErrorString(e));
   }
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  hipLaunchKernelGGL(cpb_region_bwd_kernel<DS>, dim3(pl.chunks, H, B), dim3(64 * pl.nkb * pl.wpk), sizeof(RegionBwdLds), st, dlogits, region_ids, vs,
-                     gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.wpk, pl.tiles_per_chunk, pl.kbits, pl.shift, lcap);
+  hipLaunchKernelGGL(cpb_region_bwd_kernel<DS>, dim3(pl.chunks * pl.ngrp, H, B), dim3(64 * pl.nkbg * pl.wpk), sizeof(RegionBwdLds), st, dlogits,
+                     region_ids, vs, gq, cp, rv, amax, hist, grad, dvs_slab, N, J, H, nst, pl.nkb, pl.nkbg, pl.chunks, pl.wpk, pl.tiles_per_chunk,
+                     pl.kbits, pl.shift, lcap);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   SMML_LAUNCH_CHECK(fn);
   const size_t n = (size_t)B * H * J;

@@ -1368,7 +1368,7 @@ int smml_deform_attn_region_fwd_f32(const float* q, const float* k, const float*
 }
 
 size_t smml_deform_attn_region_bwd_workspace_bytes(int B, int N, int J, int H) {
-  if (!deform_dims_ok(B, N, J, H) || J > 768) return 0;
+  if (!deform_dims_ok(B, N, J, H) || J > RG_MAX_KEYS) return 0;
   return region_bwd_plan(B, N, J, H).total;
 }
 

@@ -866,7 +866,7 @@ TABLE_FORWARD_MASKS = __import__("os").environ.get("SMML_TABFWD_MASKS", "table")
 # default wherever it applies (signed-log offsets, one head per offset group, J <= 1024).  SMML_CPB_REGIONS=0 keeps the per-pair MLP
 # kernels (the cross-check of tests/test_gpu_regions.py, and the path of every other configuration).
 CPB_REGIONS = __import__("os").environ.get("SMML_CPB_REGIONS", "1") != "0"
-REGION_MAX_KEYS = 768
+REGION_MAX_KEYS = 16384      # RG_MAX_KEYS of csrc/cpb_regions.h
 REGION_LDS_CAP = 0           # tests: regions with an id >= this take the global-memory path of the region kernels (0: the default, 2048)
 
 

@@ -126,7 +126,8 @@ def _run(t, cuda, wo, regions, p_drop=0.0, seed=3, heads=8, tap=False, compute_d
 
 
 @pytest.mark.parametrize("wkind,B,N,J,p_drop", [("random", 2, 700, 150, 0.1), ("bench", 1, 2500, 144, 0.0), ("star", 1, 333, 70, 0.0),
-                                                ("torch", 3, 129, 33, 0.25), ("random", 1, 1, 65, 0.0), ("random", 2, 5, 1, 0.0)])
+                                                ("torch", 3, 129, 33, 0.25), ("random", 1, 1, 65, 0.0), ("random", 2, 5, 1, 0.0),
+                                                ("random", 1, 200, 900, 0.1), ("bench", 1, 130, 1601, 0.0)])      # > 768 keys: key groups in the bias backward
 def test_region_core_matches_per_pair_mlp(cuda, wkind, B, N, J, p_drop):
     """Same inputs through the region kernels and through the per-pair MLP kernels: every output agrees to fp32 rounding (both sit
     within the parity gate of the fp64 oracle; here they are held against EACH OTHER at 2e-5 of each tensor's scale - an order
@@ -143,6 +144,9 @@ def test_region_core_matches_per_pair_mlp(cuda, wkind, B, N, J, p_drop):
             continue
         # parameter gradients of the bias MLP are sums over all pairs in which single ReLU flips at rounding level show (test_gpu_parity)
         tol = 2e-5 if n in ("out", "q", "k", "v") else 5e-4
+        if J > 768 and n not in ("out", "q", "k", "v"):   # few queries per key: ONE pair decided differently at a pre-activation within rounding
+            tol = 2e-2 if n == "vs" else 2e-3             # of zero shows at 1 / N of a key's d vs (these shapes are also in the decision-imposed
+                                                          # fp64 test below, which is the gate)
         assert err <= tol, f"{wkind} {B}x{N}x{J}: {n} differs by {err:.2e} of its scale between the region and the per-pair kernels"
     a2 = _run(t, cuda, wo, True, p_drop)
     for n in a:
@@ -193,7 +197,8 @@ def test_region_core_vs_fp64_with_imposed_decisions(cuda):
     """The region kernels against plain torch in fp64 and fp32 with the decisions the kernels stand for (the ReLU patterns of each
     pair's region) imposed on both - the rule of tests/test_gpu_parity.py::test_fused_core_random_shapes, same bounds."""
     gen = torch.Generator().manual_seed(77)
-    for case, (wkind, B, N, J, p_drop) in enumerate([("random", 2, 300, 90, 0.0), ("bench", 1, 500, 144, 0.25), ("star", 2, 129, 40, 0.0)]):
+    for case, (wkind, B, N, J, p_drop) in enumerate([("random", 2, 300, 90, 0.0), ("bench", 1, 500, 144, 0.25), ("star", 2, 129, 40, 0.0),
+                                                            ("random", 1, 200, 900, 0.1), ("bench", 1, 130, 1601, 0.0)]):
         t = _problem(gen, B, N, J, 8, wkind)
         wo = torch.randn(B, N, 512, generator=gen)
         res, tapped = _run(t, cuda, wo.to(cuda), True, p_drop, seed=17 + case, tap=True)

@@ -1,4 +1,4 @@
-"""Soak of the region kernels on random ragged shapes (N, J off the 32 / 128 tiles, J up to the 768-key limit, with and without dropout, four
+"""Soak of the region kernels on random ragged shapes (N, J off the 32 / 128 tiles, J up to 2048, with and without dropout, four
 parameter families): the fp32-grade region path against the per-pair MLP kernels, the 16-bit region path against the fp32-grade one, and
 the global-memory region path (region_lds_cap) against the LDS-resident one.  Prints the worst relative difference per tensor class;
 exits 1 on a violation of the bounds of tests/test_gpu_regions.py.   python tests/tools/soak_regions.py [cases = 40] [seed = 1]"""
@@ -13,7 +13,7 @@ cuda = torch.device("cuda", 0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 gen = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
-forced = [(1, 1, 768), (1, 31, 767), (2, 33, 65), (1, 257, 2), (1, 1000, 31), (3, 128, 32), (1, 129, 640)]
+forced = [(1, 1, 768), (1, 31, 767), (2, 33, 65), (1, 257, 2), (1, 1000, 31), (3, 128, 32), (1, 129, 640), (1, 200, 900), (1, 97, 1601), (2, 64, 2048), (1, 40, 769)]
 worst = {}
 bad = 0
 for case in range(cases + len(forced)):
