@@ -947,6 +947,9 @@ class RegionPrefetch:
             cpb_regions_build(w1.detach(), b1.detach(), w2.detach(), b2.detach(), w3.detach(), b3.detach(), pmax, self.tables)
             self.event = torch.cuda.Event()
             self.event.record(side)
+        # a prefetch that is dropped without join() (the forward found other parameters or another square) frees the block on the main
+        # stream while the side stream may still be writing it: the allocator must not hand it out before the side stream is done
+        self.tables.record_stream(side)
 
     def matches(self, w1, b1, w2, b2, w3, b3, pmax: float) -> bool:
         return (self.pmax == float(pmax) and
